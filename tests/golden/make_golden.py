@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  For every fixture it (1) runs the reference's own code on seeded inputs,
+(2) runs the oracle restatement on the same inputs and asserts agreement, and
+(3) writes inputs that cannot be regenerated from a seed plus the reference's outputs.
+
+Recipe for a deterministic, differentiable reference:
+train mode, every nn.Dropout / nn.Dropout3d forward replaced by `t.clone()`.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+from model import trans_block as R_tb            # noqa: E402  (reference)
+from model import Unet_3Dblock as R_ub           # noqa: E402  (reference)
+from model.trans_3DUnet import get_model_dict    # noqa: E402  (reference)
+from loss import criterions as R_loss            # noqa: E402  (reference)
+from loss import multi_criterions as R_mloss     # noqa: E402  (reference)
+
+from oracle import net as O_net                  # noqa: E402
+from oracle import roi as O_roi                  # noqa: E402
+from oracle import losses as O_loss              # noqa: E402
+from oracle import step as O_step                # noqa: E402
+from oracle import seedgen                       # noqa: E402
+
+TOL = 1e-5
+
+
+def close(a, b, what, tol=TOL):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    scale = max(1.0, b.abs().max().item()) if b.numel() else 1.0
+    assert err <= tol * scale, f'{what}: oracle differs from reference by {err:.3e}'
+    return err
+
+
+def np32(t):
+    return t.detach().to(torch.float32).numpy()
+
+
+def kill_dropout(model):
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout3d)):
+            m.forward = lambda t: t.clone()
+
+
+class _CloneDrop(torch.nn.Module):
+    def forward(self, t):
+        return t.clone()
+
+
+# ----------------------------------------------------------------------------- micro fixtures
+
+def fx_linattn():
+    out = {}
+    for tag in seedgen.LINATTN_CASES:
+        q, k, v, go = seedgen.linattn_case(tag)
+        q, k, v = (t.requires_grad_(True) for t in (q, k, v))
+        ref, _ = R_tb.linear_attention(q, k, v, dropout=_CloneDrop())
+        ref.backward(go)
+        mine = O_net.linear_attention(q.detach(), k.detach(), v.detach())
+        close(mine, ref, 'linear_attention')
+        out.update({f'{tag}_out': np32(ref), f'{tag}_dq': np32(q.grad), f'{tag}_dk': np32(k.grad), f'{tag}_dv': np32(v.grad)})
+    np.savez(os.path.join(HERE, 'linattn.npz'), **out)
+
+
+def fx_attn_layer():
+    d, B, N = 64, 2, 40
+    torch.manual_seed(5)
+    layer = R_tb.SelfAttentionLayer(d_model=d, nhead=d // 32, dim_feedforward=2 * d, dropout=0.3)
+    kill_dropout(layer)
+    layer.train()
+    shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+    P = seedgen.seeded_params(shapes, seed=21)
+    layer.load_state_dict(P)
+    x = seedgen.seeded_volume((B, N, d), 22).requires_grad_(True)
+    go = seedgen.seeded_volume((B, N, d), 23)
+    y = layer(x)
+    y.backward(go)
+    Pq = {'L.' + k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    yo = O_net.attn_layer(Pq, 'L', xo)
+    yo.backward(go)
+    close(yo, y, 'attn_layer.out')
+    close(xo.grad, x.grad, 'attn_layer.dx')
+    grads = {}
+    for k, p in layer.named_parameters():
+        close(Pq['L.' + k].grad, p.grad, 'attn_layer.d' + k)
+        grads['g_' + k] = np32(p.grad)
+    np.savez(os.path.join(HERE, 'attn_layer.npz'), out=np32(y), dx=np32(x.grad), **grads)
+
+
+def _bridge(roi_size):
+    torch.manual_seed(0)
+    br = R_ub.ROIBridge(in_dim=8, d_model=32, nhead=1, dropout=0.3, N=1, roi_size=roi_size)
+    return br
+
+
+def fx_roi():
+    """Box finder on hand-made masks (incl. empty / tiny / huge), index maps, both warps."""
+    out = {}
+    cases = []
+    g = torch.Generator().manual_seed(3)
+    H, W, D = 40, 36, 4
+    m = torch.zeros(1, 1, H, W, D, dtype=torch.bool); cases.append(('empty', m, 20))
+    m = torch.zeros(1, 1, H, W, D, dtype=torch.bool); m[0, 0, 17, 20, 2] = True; cases.append(('one_voxel', m, 20))
+    m = torch.zeros(1, 1, H, W, D, dtype=torch.bool); m[0, 0, 5:30, 8:25, 1:3] = True; cases.append(('block', m, 20))
+    m = torch.ones(1, 1, H, W, D, dtype=torch.bool); cases.append(('full', m, 20))
+    m = torch.rand(1, 1, H, W, D, generator=g) > 0.97; cases.append(('sparse', m, 20))
+    m = torch.zeros(1, 1, H, W, D, dtype=torch.bool); m[0, 0, 0:3, 33:36, :] = True; cases.append(('corner', m, 20))
+    # the benchmark regime: image smaller than the ROI grid -> both rules fire
+    m = torch.rand(1, 1, 16, 16, 8, generator=g) > 0.6; cases.append(('small_img', m, 40))
+    m = torch.zeros(1, 1, 8, 8, 4, dtype=torch.bool); cases.append(('small_empty', m, 25))
+    for name, mask, roi_size in cases:
+        br = _bridge(roi_size)
+        geo = O_roi.roi_geometry(roi_size)
+        assert (geo['eval_h'], geo['eval_w'], geo['min_h'], geo['min_w'], geo['h_roi'], geo['w_roi']) == \
+            (br.eval_h_roi_size, br.eval_w_roi_size, br.min_h_roi, br.min_w_roi, br.h_roi_size, br.w_roi_size)
+        ref_box = br.get_mask_boundary2(mask.clone())
+        my_box = O_roi.find_boxes(mask, geo['min_h'], geo['min_w'])
+        close(my_box, ref_box, f'box[{name}]', 0)
+        h, w = mask.shape[2], mask.shape[3]
+        x0, y0, _, x1, y1, _ = torch.split(ref_box, 1, dim=1)
+        fx = R_ub.get_transfer_index(x0, x1, h - 1, br.h_roi_size, br.eval_h_roi_size, device='cpu')
+        fy = R_ub.get_transfer_index(y0, y1, w - 1, br.w_roi_size, br.eval_w_roi_size, device='cpu')
+        bx = R_ub.get_transfer_back_index(x0, x1, h - 1, br.h_roi_size, br.eval_h_roi_size, 'cpu')
+        by = R_ub.get_transfer_back_index(y0, y1, w - 1, br.w_roi_size, br.eval_w_roi_size, 'cpu')
+        close(O_roi.index_map_fwd(x0, x1, h - 1, geo['h_roi'], geo['eval_h']), fx, f'fx[{name}]', 0)
+        close(O_roi.index_map_back(y0, y1, w - 1, geo['w_roi'], geo['eval_w']), by, f'by[{name}]', 0)
+        feat = torch.randn(1, 2, h, w, mask.shape[4], generator=g, requires_grad=True)
+        roi = br.roi_alignment2(feat, ref_box)
+        close(O_roi.warp_to_roi(feat.detach(), ref_box, geo), roi, f'warp[{name}]')
+        groi = torch.randn(roi.shape, generator=g)
+        roi.backward(groi)
+        roi_in = torch.randn(roi.shape, generator=g, requires_grad=True)
+        back = br.post_processing2(feat.detach(), roi_in, ref_box)
+        close(O_roi.warp_from_roi(feat.detach(), roi_in.detach(), ref_box, geo), back, f'unwarp[{name}]')
+        gback = torch.randn(back.shape, generator=g)
+        back.backward(gback)
+        out.update({f'{name}_mask': mask.numpy(), f'{name}_roi_size': np.int64(roi_size), f'{name}_box': np32(ref_box),
+                    f'{name}_fx': np32(fx), f'{name}_fy': np32(fy), f'{name}_bx': np32(bx), f'{name}_by': np32(by),
+                    f'{name}_feat': np32(feat), f'{name}_roi': np32(roi), f'{name}_groi': np32(groi),
+                    f'{name}_dfeat': np32(feat.grad), f'{name}_roi_in': np32(roi_in), f'{name}_back': np32(back),
+                    f'{name}_gback': np32(gback), f'{name}_droi_in': np32(roi_in.grad)})
+    out['names'] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, 'roi.npz'), **out)
+
+
+def fx_losses():
+    g = torch.Generator().manual_seed(9)
+    out = {}
+    for C in (2, 3):
+        logits = torch.randn(2, C, 8, 6, 4, generator=g)
+        p = torch.softmax(logits * 2, dim=1).requires_grad_(True)
+        lab = (torch.rand(2, 1, 8, 6, 4, generator=g) * C).long().clamp(max=C - 1)
+        out[f'c{C}_p'], out[f'c{C}_lab'] = np32(p), lab.numpy().astype(np.uint8)
+        if C == 2:
+            pairs = [('CrossEntroLoss', R_loss.CrossEntroLoss(), O_loss.weighted_ce),
+                     ('DiceClassLoss', R_loss.DiceClassLoss(), O_loss.dice_class),
+                     ('BalanceDiceLoss', R_loss.BalanceDiceLoss(), O_loss.balanced_dice)]
+            for name, ref_fn, my_fn in pairs:
+                p.grad = None
+                v = ref_fn(p, lab)
+                v.backward()
+                close(my_fn(p.detach(), lab), v, name)
+                out[f'c2_{name}'], out[f'c2_{name}_dp'] = np32(v), np32(p.grad)
+        else:
+            onehot = torch.nn.functional.one_hot(lab[:, 0], C).permute(0, 4, 1, 2, 3).contiguous()
+            pairs = [('CrossEntroLoss', R_mloss.CrossEntroLoss(), lambda a, t: O_loss.weighted_ce(a, None, onehot=t)),
+                     ('DiceClassLoss0', R_mloss.DiceClassLoss0(), None),
+                     ('DiceClassLoss', R_mloss.DiceClassLoss(), lambda a, t: O_loss.dice_class_onehot(a, t, 1)),
+                     ('DiceClassLoss2', R_mloss.DiceClassLoss2(), lambda a, t: O_loss.dice_class_onehot(a, t, 2))]
+            for name, ref_fn, my_fn in pairs:
+                p.grad = None
+                v = ref_fn(p, onehot)
+                v.backward()
+                if my_fn is not None:
+                    close(my_fn(p.detach(), onehot), v, 'multi.' + name)
+                out[f'c3_{name}'], out[f'c3_{name}_dp'] = np32(v), np32(p.grad)
+    np.savez(os.path.join(HERE, 'losses.npz'), **out)
+
+
+# ----------------------------------------------------------------------------- whole model
+
+def run_reference_model(cfg: O_net.NetConfig, P, x, label, weights):
+    Model = get_model_dict('MaskTransUnet')
+    model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
+                  dim_input=cfg.dim_input, dim_output=cfg.dim_output, kernel_size=3)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert ref_shapes == O_net.param_shapes(cfg), 'state_dict surface differs'
+    model.load_state_dict(P, strict=True)
+    kill_dropout(model)
+    model.train()
+    boxes = []
+    for m in model.modules():
+        if isinstance(m, R_ub.ROIBridge):
+            orig = m.get_mask_boundary2
+            m.get_mask_boundary2 = (lambda o: (lambda mask: (boxes.append(o(mask)), boxes[-1])[1]))(orig)
+    predict, masks = model(x)
+    crits = [R_loss.get_criterions(['CrossEntroLoss', 'BalanceDiceLoss'])] * 3 + \
+            [R_loss.get_criterions(['CrossEntroLoss', 'DiceClassLoss'])] * 2
+    # replay of utils/utils_3D_embed_full.py:63-82 against the reference's own modules
+    F = torch.nn.functional
+    temp = F.max_pool3d(label.float(), kernel_size=(2, 2, 1), stride=(2, 2, 1))
+    loss_list = []
+    for lvl in range(len(weights)):
+        if lvl == 0:
+            vals = [l(predict, label.long()) for l in crits[-lvl - 1].values()]
+        else:
+            vals = [l(masks[-lvl], temp.long()) for l in crits[-lvl - 1].values()]
+            k = 2 if lvl % 2 == 0 else (2, 2, 1)
+            temp = F.max_pool3d(temp, kernel_size=k, stride=k)
+        loss_list.append(vals)
+    total = sum(sum(v) * w for v, w in zip(loss_list, weights))
+    total.backward()
+    model.eval()
+    with torch.no_grad():
+        onehot = model(x)
+    grads = {k: (p.grad if p.grad is not None else None) for k, p in model.named_parameters()}
+    return predict, masks, boxes, loss_list, total, grads, onehot
+
+
+def fx_model(tag, cfg, size, batch, wseed, full_arrays):
+    shapes = O_net.param_shapes(cfg)
+    P = seedgen.seeded_params(shapes, wseed)
+    x = seedgen.seeded_volume((batch, 1) + size, wseed + 1)
+    label = seedgen.seeded_label((batch, 1) + size, wseed + 2)
+    weights = O_step.dynamic_weights(0)
+    predict, masks, boxes, loss_list, total, grads, onehot = run_reference_model(cfg, P, x, label, weights)
+
+    Pq = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    my_boxes = []
+    o_pred, o_masks = O_net.forward(Pq, cfg, x, True, my_boxes)
+    o_total, o_levels = O_step.total_loss(o_pred, o_masks, label, weights)
+    o_total.backward()
+    errs = {'out': close(o_pred, predict, tag + '.out')}
+    for i, (a, b) in enumerate(zip(o_masks, masks)):
+        errs[f'mask{i}'] = close(a, b, f'{tag}.mask{i}')
+    for i, (a, b) in enumerate(zip(my_boxes, boxes)):
+        close(a, b, f'{tag}.box{i}', 0)
+    close(o_total, total, tag + '.total')
+    n_none = 0
+    gerr = 0.0
+    for k, gr in grads.items():
+        if gr is None:
+            n_none += 1
+            assert Pq[k].grad is None, k
+            continue
+        gerr = max(gerr, close(Pq[k].grad, gr, f'{tag}.grad[{k}]', 2e-4))
+    with torch.no_grad():
+        close(O_net.forward(P, cfg, x, training=False), onehot, tag + '.eval_onehot', 0)
+    dice = R_loss.DiceClassLoss()(predict, label.long())
+    print(f'[{tag}] out err {errs["out"]:.2e}, grad err {gerr:.2e}, params without grad {n_none}, '
+          f'total loss {total.item():.6f}, dice loss {dice.item():.6f}')
+
+    keys = sorted(k for k, v in grads.items() if v is not None)
+    out = dict(total=np32(total), dice=np32(dice),
+               level_losses=np.array([[v.item() for v in vals] for vals in loss_list], dtype=np.float64),
+               weights=np.array(weights, dtype=np.float64),
+               grad_keys=np.array(keys), grad_norms=np.array([grads[k].double().norm().item() for k in keys]),
+               nograd_keys=np.array(sorted(k for k, v in grads.items() if v is None)),
+               onehot_fg_count=np.int64(onehot[:, 1].sum().item()))
+    for i, b in enumerate(boxes):
+        out[f'box{i}'] = np32(b)
+    if full_arrays:
+        out['out'] = np32(predict)
+        for i, m in enumerate(masks):
+            out[f'mask{i}'] = np32(m)
+        for k in ('encode.input_block.weight', 'decode.final_block.weight', 'decode.att_conv_list.0.psi.0.weight',
+                  'decode.bridge_list.1.transformer.layers.0.self_attn.linears.1.weight',
+                  'decode.bridge_list.1.transformer.pos_encoder.proj.weight',
+                  'decode.bridge_list.4.transformer.layers.7.layer_norm2.weight',
+                  'decode.mask_conv_list.3.bias', 'encode.block_list.3.conv2.weight'):
+            out['grad::' + k] = np32(grads[k])
+    else:
+        flat = predict.detach().flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 4096).long()
+        out['out_idx'], out['out_sample'] = idx.numpy(), np32(flat[idx])
+        out['out_mean'], out['out_std'] = np.float64(predict.double().mean().item()), np.float64(predict.double().std().item())
+        for i, m in enumerate(masks):
+            out[f'mask{i}'] = np32(m) if m.numel() <= 70000 else np32(m.flatten()[:: max(1, m.numel() // 4096)])
+            out[f'mask{i}_mean'] = np.float64(m[:, 1].double().mean().item())
+    np.savez_compressed(os.path.join(HERE, f'model_{tag}.npz'), **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    fx_linattn()
+    fx_attn_layer()
+    fx_roi()
+    fx_losses()
+    small = O_net.NetConfig(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
+    fx_model('small', small, (32, 32, 32), 2, 100, full_arrays=True)
+    fx_model('small_wide', small, (64, 96, 16), 1, 200, full_arrays=False)
+    fx_model('full32', O_net.NetConfig(), (32, 32, 32), 1, 300, full_arrays=False)
+    print('golden vectors written to', HERE)
+
+
+if __name__ == '__main__':
+    main()
