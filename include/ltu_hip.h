@@ -1,0 +1,176 @@
+/* C-ABI of libltu_hip.so — the MI355X (gfx950) kernels behind the LinTransUNet hot path.
+ *
+ * The reference (freshman97/LinTransUNet) is pure PyTorch and has no FFI of its own; each entry
+ * point below replaces the ATen op(s) reached from the cited reference lines (paths relative to
+ * the reference root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - Activations are channels-last: a reference tensor [B,C,H,W,D] lives in HBM as [B,H,W,D,C]
+ *     (C fastest), so a voxel is a token and 1x1x1 convs / Linear layers are the same GEMM.
+ *   - `dtype` is the storage type of activations (LTU_F32 / LTU_BF16); weights, statistics,
+ *     probabilities and gradients of weights are fp32; all accumulation is fp32.
+ *   - Ownership: the caller allocates every buffer (outputs, workspaces, saved statistics).  The
+ *     library never allocates, frees, retains pointers or synchronises; all work is enqueued on
+ *     `stream`.  Functions are stateless and re-entrant.
+ *   - Dropout: (p, seed) select a counter-based Philox mask; the backward entry points regenerate
+ *     the mask from the same (p, seed) instead of reading a stored one.  p = 0 disables.
+ *   - Return value: 0 = LTU_OK, negative = LTU_E_* argument error, positive = hipError_t.
+ */
+#ifndef LTU_HIP_H
+#define LTU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ltu_stream_t; /* hipStream_t */
+
+enum { LTU_F32 = 0, LTU_BF16 = 1 };
+enum { LTU_OK = 0, LTU_E_DTYPE = -1, LTU_E_SHAPE = -2, LTU_E_ALIGN = -3, LTU_E_ARG = -4 };
+enum { LTU_ACT_NONE = 0, LTU_ACT_LRELU = 1 };
+
+int ltu_version(void);
+
+/* ---- window embedding: model/Unet_3Dblock.py:123-136 ------------------------------------------
+ * x f32 [B,1,H,W,D] (reference layout) -> y T [B,H/2,W/2,D,8]; channel kh*2+kw, channels 4..7 = 0
+ * (padding so that the stem conv gathers whole vectors). */
+int ltu_window_embed(const float* x, void* y, int dtype, int B, int H, int W, int D, ltu_stream_t s);
+
+/* ---- weight repacking (weights are tiny; done per step) ----------------------------------------
+ * conv weight [Co,Ci,3,3,3] -> wf [CoP][27][CiP] (forward / weight-gradient operand) and/or
+ * wd [CiP][27][CoP] (data-gradient operand), zero padded; either output may be NULL. */
+int ltu_pack_conv_weight(const float* w, float* wf, float* wd, int Co, int Ci, int CoP, int CiP, ltu_stream_t s);
+/* gradient back to the PyTorch layout: dwf [CoP][27][CiP] -> dw [Co,Ci,3,3,3] */
+int ltu_unpack_conv_wgrad(const float* dwf, float* dw, int Co, int Ci, int CiP, ltu_stream_t s);
+/* out[c*ldo + col_off + r] = in[r*C + c]  (Linear weight for the data-gradient GEMM) */
+int ltu_transpose_f32(const float* in, float* out, int R, int C, int ldo, int col_off, ltu_stream_t s);
+
+/* ---- dense projections: nn.Linear (model/trans_block.py:144,156,166,187,189) and 1x1x1 convs
+ *      (model/Unet_3Dblock.py:200-215).  y[M,N] (+)= a[M,K] . w[N,K]^T + bias.
+ * Up to three weight blocks of N/nw rows each may be given (q,k,v fused: nw = 3); bias entries may
+ * be NULL.  accumulate != 0 adds to y. */
+int ltu_linear_fwd(const void* a, int lda, const float* const* w, int nw, const float* const* bias, void* y, int ldy,
+                   int M, int N, int K, int accumulate, int dtype, ltu_stream_t s);
+/* dw[N,K] += g[M,N]^T . a[M,K];  db[N] += colsum(g).  dw/db fp32, caller zero-fills; db may be NULL. */
+int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* dw, float* db, int M, int N, int K,
+                     int dtype, ltu_stream_t s);
+
+/* ---- 3x3x3 convolution, padding 1: model/Unet_3Dblock.py:310,314,375,421,523,528,588,1328,1353 --
+ * x0 [B,Hi,Wi,Di,C0] (+ optional x1 [..,C1]: the channel concat of Unet_3Dblock.py:553 without
+ * materialising it), wf [Co][27][C0+C1], stride (sh,sw,sd) in {1,2}; ups != 0: the conv reads the
+ * nearest-neighbour x2 upsampling of x0 (nn.Upsample of Unet_3Dblock.py:421), (Hi,Wi,Di) are then
+ * the physical dims.  y [B,Ho,Wo,Do,Co]. */
+int ltu_conv3d_fwd(const void* x0, const void* x1, const float* wf, const float* bias, void* y, int B, int Hi, int Wi,
+                   int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype, ltu_stream_t s);
+/* data gradient: g [B,Ho,Wo,Do,Co], wd [C0+C1][27][Co] -> dx0 [B,Hl,Wl,Dl,C0] (+ dx1 [..,C1]); (Hl,Wl,Dl)
+ * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
+int ltu_conv3d_dgrad(const void* g, const float* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,
+                     int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s);
+/* weight gradient into the packed layout dwf [Co][27][C0+C1] (+=, caller zero-fills), db[Co] += */
+int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi, int Wi,
+                     int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype, ltu_stream_t s);
+/* y[b,h,w,d,c] = sum of the 2x2x2 children of x [B,2H,2W,2D,C] (adjoint of nearest x2 upsampling) */
+int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int dtype, ltu_stream_t s);
+
+/* ---- linear attention core: model/trans_block.py:41-67 -----------------------------------------
+ * qkv [B*N][3d] (q | k | v; head h = columns h*32..h*32+31 of each third) -> out [B*N][d].
+ * Saved for backward: ctx [B*H][32][32], colstats [B*H][64] (column max | column sum of exp),
+ * qstat [B*N][H][2] (row max, 1/(rowsum*sqrt(32))).  part_ws: B * ltu_linattn_splits(B,N) * H * 1088 floats. */
+int ltu_linattn_splits(int B, int N);
+int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws, int B, int N,
+                    int d, int dtype, ltu_stream_t s);
+/* dqkv [B*N][3d] from dout [B*N][d]; dctx [B*H][32][32] and tvec [B*H][32] are scratch outputs */
+int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const float* colstats, const float* qstat,
+                    void* dqkv, float* dctx, float* tvec, float* part_ws, int B, int N, int d, int dtype, ltu_stream_t s);
+
+/* ---- InstanceNorm3d (+LeakyReLU, residual, dropout): model/Unet_3Dblock.py:312-339,526-556,593 ----
+ * x [B][S][C].  sums [B][C][3] = {shift, sum(x-shift), sum((x-shift)^2)} (zero-filled by the caller).
+ * apply: y = dropout(act((x-mean)*rstd)) + res (res may be NULL). */
+int ltu_instnorm_stats(const void* x, float* sums, int B, long long S, int C, int dtype, ltu_stream_t s);
+int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C, int act,
+                       float slope, float p, uint64_t seed, int dtype, ltu_stream_t s);
+/* dx from dy; bsums [B][C][2] zero-filled scratch */
+int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, void* dx, int B, long long S, int C,
+                     int act, float slope, float p, uint64_t seed, int dtype, ltu_stream_t s);
+
+/* ---- residual LayerNorm: model/trans_block.py:205-206,209-210 -----------------------------------
+ * y = LN(x + dropout(r)) * gamma + beta over rows of d in {32,64,128,256}; r is OVERWRITTEN with the
+ * pre-norm sum z; stat [M][2] = {mean, rstd}. */
+int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat, long long M,
+                      int d, float eps, float p, uint64_t seed, int dtype, ltu_stream_t s);
+/* dz (gradient of x) and dr = dz*dropmask (dr may alias dz when p = 0); dgamma/dbeta += (zero-filled) */
+int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
+                      float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, int dtype, ltu_stream_t s);
+
+/* ---- GELU(erf) + dropout: model/trans_block.py:208 ---------------------------------------------- */
+int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, int dtype, ltu_stream_t s);
+int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, float p, uint64_t seed, int dtype,
+                         ltu_stream_t s);
+
+/* ---- class-probability heads ---------------------------------------------------------------------
+ * mask head softmax (model/Unet_3Dblock.py:1380-1381): logits T [M][CP] (first C valid) -> p f32 [M][C] */
+int ltu_head_softmax_fwd(const void* z, float* p, long long M, int C, int CP, int dtype, ltu_stream_t s);
+int ltu_head_softmax_bwd(const float* dp, const float* p, void* dz, long long M, int C, int CP, int dtype, ltu_stream_t s);
+/* final head (model/Unet_3Dblock.py:1392-1394): z [B,h,w,D,4C] -> window un-embedding + softmax -> p f32 [B,2h,2w,D,C] */
+int ltu_final_softmax_fwd(const void* z, float* p, int B, int h, int w, int D, int C, int dtype, ltu_stream_t s);
+int ltu_final_softmax_bwd(const float* dp, const float* p, void* dz, int B, int h, int w, int D, int C, int dtype,
+                          ltu_stream_t s);
+/* eval branch (model/trans_3DUnet.py:199-202): one-hot of the arg-max class, p/o f32 [M][C] */
+int ltu_onehot_argmax(const float* p, float* o, long long M, int C, ltu_stream_t s);
+
+/* ---- attention gate: model/Unet_3Dblock.py:217-221 + 1385 ---------------------------------------
+ * u1 = Wx.skip, u2 = Wg.up ([B][S][C], from ltu_linear_fwd), sums1/sums2 their InstanceNorm sums.
+ * a = sigmoid(psi . relu(IN(u1)+IN(u2)) + b) -> a_out f32 [B*S]; out = skip * a. */
+int ltu_gate_fwd(const void* u1, const void* u2, const float* sums1, const float* sums2, const float* psi_w,
+                 const float* psi_b, const void* skip, float* a_out, void* out, int B, long long S, int C, int dtype,
+                 ltu_stream_t s);
+/* -> dskip (direct path), du1, du2, dpsi_w[C] +=, dpsi_b[1] +=; ds_ws f32 [B*S], bs1/bs2 [B][C][2] zero-filled scratch */
+int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* sums1, const float* sums2,
+                 const float* psi_w, const void* skip, const float* a_in, void* dskip, float* ds_ws, float* dpsi_w,
+                 float* dpsi_b, float* bs1, float* bs2, void* du1, void* du2, int B, long long S, int C, int dtype,
+                 ltu_stream_t s);
+
+/* ---- positional depthwise conv: model/trans_block.py:86-96 on the grid of Unet_3Dblock.py:267-270 ----
+ * y = chan_dropout(x + dwconv3x3x3(x) + bias), x [B,H,W,D,C]; w [C,1,3,3,3] with the reference's kernel
+ * axes (D,H,W); nn.Dropout3d draws one keep/drop per (sample, channel). */
+int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C, float p,
+                   uint64_t seed, int dtype, ltu_stream_t s);
+/* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller) */
+int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int B, int H, int W,
+                   int D, int C, float p, uint64_t seed, int dtype, ltu_stream_t s);
+
+/* ---- dynamic ROI: model/Unet_3Dblock.py:821-873, 37-49 (box), 51-82 (index maps), 985-1117 (warps) ----
+ * prob f32 [B,H,W,D,C]: foreground = (1 - prob[...,0]) >= thr.  Writes box [B][6] = (x0,y0,0,x1,y1,D-1)
+ * and the sampling plans (sizes from ltu_roi_plan_size) used by ltu_roi_resample. */
+int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n_int, long long* n_float);
+int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C, int roi_size, float thr, float* box, int* plan_i,
+                 float* plan_f, ltu_stream_t s);
+/* which = 0: image [B,H,W,D,C] -> ROI grid [B,eh,ew,D,C] (roi_alignment2); which = 1: ROI grid -> image
+ * (post_processing2).  adjoint != 0 applies the transposed operator to a gradient (in has the shape of the
+ * forward output, out the shape of the forward input). */
+int ltu_roi_resample(const void* in, void* out, int* plan_i, float* plan_f, int which, int adjoint, int B, int H, int W,
+                     int D, int C, int roi_size, int dtype, ltu_stream_t s);
+
+/* ---- trilinear x(2,2,sd) upsampling, align_corners=True: model/Unet_3Dblock.py:1341-1345,1375-1378 ----
+ * forward: in [B,H,W,D,C] -> out [B,2H,2W,sd*D,C]; adjoint != 0: in = gradient of the output. */
+int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
+                     ltu_stream_t s);
+
+/* ---- deep-supervision losses of one level: loss/criterions.py:35-70,416-442,696-735;
+ *      loss/multi_criterions.py:58-110,594-615 ------------------------------------------------------
+ * p f32 [B][S][C] probabilities, label u8 [B][S].  total = w_ce*CE + w_bal*BalancedDice + sum_c w_dice[c]*Dice_c.
+ * values[0] = total, [1] = CE, [2] = balanced Dice, [3+c] = Dice_c;  sums [B][C][4] zero-filled scratch;
+ * coef [B][C][3] feeds ltu_loss_bwd: dp = gscale[0] * dTotal/dp. */
+int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
+                 float w_ce, float w_bal, const float* w_dice, ltu_stream_t s);
+int ltu_loss_bwd(const float* p, const uint8_t* label, const float* coef, const float* gscale, float* dp, int B,
+                 long long S, int C, ltu_stream_t s);
+/* label pyramid (utils/utils_3D_embed_full.py:64,73-76): u8 [B,H,W,D] -> max over (2,2,kd) windows */
+int ltu_label_maxpool(const uint8_t* x, uint8_t* y, int B, int H, int W, int D, int kd, ltu_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTU_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libltu_hip.so (declared in include/ltu_hip.h).
+
+The product path has no fallback: if the shared library is missing or a symbol cannot be
+resolved, importing the ops raises immediately.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libltu_hip.so')
+
+P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_uint64
+
+# name -> argument types (return type is always int).  Mirrors include/ltu_hip.h one to one.
+SIGNATURES = {
+    'ltu_version': [],
+    'ltu_window_embed': [P, P, I, I, I, I, I, P],
+    'ltu_pack_conv_weight': [P, P, P, I, I, I, I, P],
+    'ltu_unpack_conv_wgrad': [P, P, I, I, I, P],
+    'ltu_transpose_f32': [P, P, I, I, I, I, P],
+    'ltu_linear_fwd': [P, I, P, I, P, P, I, I, I, I, I, I, P],
+    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P],
+    'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],
+    'ltu_linattn_splits': [I, I],
+    'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],
+    'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    'ltu_instnorm_stats': [P, P, I, L, I, I, P],
+    'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, I, P],
+    'ltu_instnorm_bwd': [P, P, P, P, P, I, L, I, I, F, F, U, I, P],
+    'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, I, P],
+    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, L, I, F, U, I, P],
+    'ltu_gelu_dropout_fwd': [P, P, L, F, U, I, P],
+    'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, I, P],
+    'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],
+    'ltu_head_softmax_bwd': [P, P, P, L, I, I, I, P],
+    'ltu_final_softmax_fwd': [P, P, I, I, I, I, I, I, P],
+    'ltu_final_softmax_bwd': [P, P, P, I, I, I, I, I, I, P],
+    'ltu_onehot_argmax': [P, P, L, I, P],
+    'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, I, P],
+    'ltu_dwconv_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, U, I, P],
+    'ltu_roi_plan_size': [I, I, I, I, P, P],
+    'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P],
+    'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    'ltu_trilinear_up': [P, P, I, I, I, I, I, I, I, I, P],
+    'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P],
+    'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
+    'ltu_label_maxpool': [P, P, I, I, I, I, I, P],
+}
+
+_lib = None
+
+
+class LtuError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raises if it is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LtuError(f'{LIB_PATH} is missing: the HIP extension has not been built; there is no fallback path')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: 'LTU_E_DTYPE', -2: 'LTU_E_SHAPE', -3: 'LTU_E_ALIGN', -4: 'LTU_E_ARG'}
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise LtuError(f'{name} failed: {_ERR.get(rc, "hipError_t " + str(rc))}')

@@ -1,0 +1,169 @@
+// Shared device helpers for the gfx950 kernels of the LinTransUNet hot path.
+// Activations are stored as T in {float, bf16}; all arithmetic is fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/ltu_hip.h"
+
+#define LTU_WAVE 64
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct bf16_t {
+  uint16_t bits;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// ---- 4-wide vector access (the unit every pointwise kernel works in) ---------------------------
+template <typename T>
+struct Vec4;
+
+template <>
+struct Vec4<float> {
+  static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+
+template <>
+struct Vec4<bf16_t> {
+  static __device__ __forceinline__ float4 load(const bf16_t* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    float4 v;
+    v.x = __uint_as_float(r.x << 16);
+    v.y = __uint_as_float(r.x & 0xffff0000u);
+    v.z = __uint_as_float(r.y << 16);
+    v.w = __uint_as_float(r.y & 0xffff0000u);
+    return v;
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, float4 v) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p);
+template <>
+__device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(p->bits); }
+
+template <typename T>
+__device__ __forceinline__ void st1(T* p, float v);
+template <>
+__device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+
+__device__ __forceinline__ float& f4at(float4& v, int i) { return reinterpret_cast<float*>(&v)[i]; }
+__device__ __forceinline__ float f4at(const float4& v, int i) { return reinterpret_cast<const float*>(&v)[i]; }
+
+// ---- wave / block reductions (64-wide wavefronts) ----------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce over aligned groups of G lanes (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- counter-based dropout RNG -----------------------------------------------------------------
+// Philox4x32-7 keyed by (seed, stream id); counter = index of the 4-element group.  The backward
+// kernels regenerate the same mask from (seed, stream, index) instead of storing it.
+__device__ __forceinline__ uint4 philox4(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
+  uint32_t c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+struct DropCfg {       // p == 0 disables
+  float p;
+  float scale;         // 1/(1-p)
+  uint32_t thresh;     // keep iff r >= thresh, thresh = p * 2^32
+  uint32_t seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed) {
+  DropCfg d;
+  d.p = p;
+  d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  d.thresh = p > 0.f ? (uint32_t)fminf(p * 4294967296.f, 4294967295.f) : 0u;
+  d.seed_lo = (uint32_t)seed;
+  d.seed_hi = (uint32_t)(seed >> 32);
+  return d;
+}
+
+// multiplies the 4 values of group `g4` (a 64-bit element index / 4) by their keep-mask * scale
+__device__ __forceinline__ float4 drop4(const DropCfg& d, uint64_t g4, float4 v) {
+  if (d.p <= 0.f) return v;
+  uint4 r = philox4((uint32_t)g4, (uint32_t)(g4 >> 32), d.seed_lo, d.seed_hi);
+  v.x = r.x >= d.thresh ? v.x * d.scale : 0.f;
+  v.y = r.y >= d.thresh ? v.y * d.scale : 0.f;
+  v.z = r.z >= d.thresh ? v.z * d.scale : 0.f;
+  v.w = r.w >= d.thresh ? v.w * d.scale : 0.f;
+  return v;
+}
+// keep-mask*scale factors only (used by backward kernels)
+__device__ __forceinline__ float4 dropmask4(const DropCfg& d, uint64_t g4) {
+  return drop4(d, g4, make_float4(1.f, 1.f, 1.f, 1.f));
+}
+
+// ---- misc ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int ltu_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LTU_OK : (int)e;
+}
+
+static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+// dtype dispatch for host wrappers
+#define LTU_DISPATCH_T(dtype, ...)                           \
+  do {                                                       \
+    if ((dtype) == LTU_F32) {                                \
+      typedef float T;                                       \
+      __VA_ARGS__                                            \
+    } else if ((dtype) == LTU_BF16) {                        \
+      typedef bf16_t T;                                      \
+      __VA_ARGS__                                            \
+    } else {                                                 \
+      return LTU_E_DTYPE;                                    \
+    }                                                        \
+  } while (0)

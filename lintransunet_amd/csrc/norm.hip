@@ -1,0 +1,356 @@
+// InstanceNorm3d(+LeakyReLU +residual +dropout) and residual LayerNorm for gfx950, fwd + bwd.
+// All kernels are HBM-streaming: 16-byte (fp32) / 8-byte (bf16) vector accesses along the channel
+// axis of channels-last tensors, fp32 statistics, wavefront (64-lane) reductions.
+//
+// InstanceNorm (model/Unet_3Dblock.py:312,316,526,531,593 and 204,210,380,427): per (sample, channel)
+// mean / biased variance over the S voxels, eps 1e-5, no affine.
+//   stats   : sums[b][c] = { shift, sum(x-shift), sum((x-shift)^2) }   shift = x[b,0,c]  (fp32 atomics)
+//   apply   : y = drop(act((x-mean)*rstd)) + res
+//   bwd     : g = dy*dropmask*act'(xhat);  s1 = sum g, s2 = sum g*xhat;  dx = rstd*(g - s1/S - xhat*s2/S)
+// LayerNorm (model/trans_block.py:205-206, 209-210, eps 1e-6): y = LN(x + drop(r)) * gamma + beta; the
+// pre-norm sum z = x + drop(r) overwrites r (it is what the backward pass needs).
+#include "common.h"
+
+#define IN_EPS 1e-5f
+
+struct InStat {
+  float mean, rstd;
+};
+__device__ __forceinline__ InStat in_stat(const float* sums, float invS) {
+  const float m1 = sums[1] * invS;
+  float var = sums[2] * invS - m1 * m1;
+  var = fmaxf(var, 0.f);
+  InStat s;
+  s.mean = sums[0] + m1;
+  s.rstd = rsqrtf(var + IN_EPS);
+  return s;
+}
+
+// grid (nchunks, B), block 256.  x [B][S][C]; sums [B][C][3] must be zero on entry.
+template <typename T>
+__global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, long long S, int C,
+                                      int rows_per_block) {
+  extern __shared__ float red[];   // [rowgroups][C][2]
+  const int b = blockIdx.y;
+  const int cv = C / 4;                       // vectors per row
+  const int tid = threadIdx.x;
+  const int v = tid % cv, rg = tid / cv, nrg = blockDim.x / cv;
+  const T* xb = x + (long long)b * S * C;
+  float4 shift = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 a1 = shift, a2 = shift;
+  if (rg < nrg) {
+    shift = Vec4<T>::load(xb + v * 4);
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > S) r1 = S;
+    for (long long r = r0 + rg; r < r1; r += nrg) {
+      float4 t = Vec4<T>::load(xb + r * C + v * 4);
+      t.x -= shift.x; t.y -= shift.y; t.z -= shift.z; t.w -= shift.w;
+      a1.x += t.x; a1.y += t.y; a1.z += t.z; a1.w += t.w;
+      a2.x += t.x * t.x; a2.y += t.y * t.y; a2.z += t.z * t.z; a2.w += t.w * t.w;
+    }
+    float* dst = red + ((long long)rg * C + v * 4) * 2;
+    dst[0] = a1.x; dst[1] = a2.x; dst[2] = a1.y; dst[3] = a2.y; dst[4] = a1.z; dst[5] = a2.z; dst[6] = a1.w; dst[7] = a2.w;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * 2; i += blockDim.x) {
+    float acc = 0.f;
+    for (int g = 0; g < nrg; ++g) acc += red[(long long)g * C * 2 + i];
+    const int c = i >> 1, which = i & 1;
+    float* s = sums + ((long long)b * C + c) * 3;
+    atomicAdd(s + 1 + which, acc);
+    if (blockIdx.x == 0 && which == 0) s[0] = ld1<T>(xb + c);
+  }
+}
+
+// y = drop(act(xhat)) + res.   grid-stride over 4-vectors.
+template <typename T>
+__global__ void instnorm_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums, const T* __restrict__ res,
+                                      T* __restrict__ y, long long S, int C, int B, int act, float slope, float p,
+                                      uint64_t seed) {
+  const long long nvec = (long long)B * S * C / 4;
+  const float invS = 1.f / (float)S;
+  const DropCfg dc = make_drop(p, seed);
+  const long long per_b = S * C / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_b);
+    const int c = (int)((i * 4) % C);
+    float4 v = Vec4<T>::load(x + i * 4);
+    float4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
+      float h = (f4at(v, k) - st.mean) * st.rstd;
+      if (act == LTU_ACT_LRELU) h = h > 0.f ? h : h * slope;
+      f4at(o, k) = h;
+    }
+    o = drop4(dc, (uint64_t)i, o);
+    if (res) {
+      const float4 r = Vec4<T>::load(res + i * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    Vec4<T>::store(y + i * 4, o);
+  }
+}
+
+// backward reductions: bsums[b][c][2] += { sum g, sum g*xhat },  g = dy*mask*act'(xhat)
+template <typename T>
+__global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
+                                          float* __restrict__ bsums, long long S, int C, int rows_per_block, int act,
+                                          float slope, float p, uint64_t seed) {
+  extern __shared__ float red[];
+  const int b = blockIdx.y;
+  const int cv = C / 4;
+  const int tid = threadIdx.x;
+  const int v = tid % cv, rg = tid / cv, nrg = blockDim.x / cv;
+  const float invS = 1.f / (float)S;
+  const DropCfg dc = make_drop(p, seed);
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  if (rg < nrg) {
+    InStat st[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[k] = in_stat(sums + ((long long)b * C + v * 4 + k) * 3, invS);
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > S) r1 = S;
+    for (long long r = r0 + rg; r < r1; r += nrg) {
+      const long long e = ((long long)b * S + r) * C + v * 4;
+      const float4 xv = Vec4<T>::load(x + e);
+      float4 g = Vec4<T>::load(dy + e);
+      const float4 mk = dropmask4(dc, (uint64_t)(e >> 2));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float h = (f4at(xv, k) - st[k].mean) * st[k].rstd;
+        float gg = f4at(g, k) * f4at(mk, k);
+        if (act == LTU_ACT_LRELU && h <= 0.f) gg *= slope;
+        f4at(a1, k) += gg;
+        f4at(a2, k) += gg * h;
+      }
+    }
+    float* dst = red + ((long long)rg * C + v * 4) * 2;
+    dst[0] = a1.x; dst[1] = a2.x; dst[2] = a1.y; dst[3] = a2.y; dst[4] = a1.z; dst[5] = a2.z; dst[6] = a1.w; dst[7] = a2.w;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * 2; i += blockDim.x) {
+    float acc = 0.f;
+    for (int g = 0; g < nrg; ++g) acc += red[(long long)g * C * 2 + i];
+    atomicAdd(bsums + (long long)b * C * 2 + i, acc);
+  }
+}
+
+template <typename T>
+__global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
+                                          const float* __restrict__ bsums, T* __restrict__ dx, long long S, int C, int B,
+                                          int act, float slope, float p, uint64_t seed) {
+  const long long nvec = (long long)B * S * C / 4;
+  const float invS = 1.f / (float)S;
+  const DropCfg dc = make_drop(p, seed);
+  const long long per_b = S * C / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_b);
+    const int c = (int)((i * 4) % C);
+    const float4 xv = Vec4<T>::load(x + i * 4);
+    const float4 g = Vec4<T>::load(dy + i * 4);
+    const float4 mk = dropmask4(dc, (uint64_t)i);
+    float4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
+      const float* bs = bsums + ((long long)b * C + c + k) * 2;
+      const float h = (f4at(xv, k) - st.mean) * st.rstd;
+      float gg = f4at(g, k) * f4at(mk, k);
+      if (act == LTU_ACT_LRELU && h <= 0.f) gg *= slope;
+      f4at(o, k) = st.rstd * (gg - bs[0] * invS - h * bs[1] * invS);
+    }
+    Vec4<T>::store(dx + i * 4, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One row (d <= 256 channels) per group of d/4 lanes; groups never straddle a wavefront.
+// z = x + drop(r) is written over r; y = (z-mean)*rstd*gamma + beta; stat[row] = {mean, rstd}
+template <typename T, int G>
+__global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ stat,
+                                     long long M, float eps, float p, uint64_t seed) {
+  const int d = G * 4;
+  const int gl = threadIdx.x % G;
+  const long long rows_per_block = blockDim.x / G;
+  const long long row = (long long)blockIdx.x * rows_per_block + threadIdx.x / G;
+  const DropCfg dc = make_drop(p, seed);
+  const bool ok = row < M;
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    const long long e = row * d + gl * 4;
+    z = Vec4<T>::load(x + e);
+    float4 rv = Vec4<T>::load(r + e);
+    rv = drop4(dc, (uint64_t)(e >> 2), rv);
+    z.x += rv.x; z.y += rv.y; z.z += rv.z; z.w += rv.w;
+    Vec4<T>::store(r + e, z);
+  }
+  const float mean = group_sum<G>(z.x + z.y + z.z + z.w) / (float)d;
+  const float dx0 = z.x - mean, dx1 = z.y - mean, dx2 = z.z - mean, dx3 = z.w - mean;
+  const float var = group_sum<G>(dx0 * dx0 + dx1 * dx1 + dx2 * dx2 + dx3 * dx3) / (float)d;
+  const float rstd = rsqrtf(var + eps);
+  if (ok) {
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + gl * 4);
+    float4 o = make_float4(dx0 * rstd * gm.x + bt.x, dx1 * rstd * gm.y + bt.y, dx2 * rstd * gm.z + bt.z, dx3 * rstd * gm.w + bt.w);
+    Vec4<T>::store(y + row * d + gl * 4, o);
+    if (gl == 0) {
+      stat[row * 2] = mean;
+      stat[row * 2 + 1] = rstd;
+    }
+  }
+}
+
+// dz = rstd*(g*gamma - mean_d(g*gamma) - xhat*mean_d(g*gamma*xhat));  dr = dz*dropmask;
+// dgamma += sum_rows g*xhat, dbeta += sum_rows g   (block partials through LDS, then fp32 atomics)
+template <typename T, int G>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ stat,
+                                     const float* __restrict__ gamma, T* __restrict__ dz, T* __restrict__ dr,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int rows_per_block,
+                                     float p, uint64_t seed) {
+  extern __shared__ float red[];   // [rowgroups][d][2]
+  const int d = G * 4;
+  const int gl = threadIdx.x % G, rg = threadIdx.x / G, nrg = blockDim.x / G;
+  const DropCfg dc = make_drop(p, seed);
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  for (long long rb = r0; rb < r1; rb += nrg) {
+    const long long row = rb + rg;
+    const bool ok = row < r1;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), h = g;
+    float rstd = 0.f;
+    if (ok) {
+      const long long e = row * d + gl * 4;
+      g = Vec4<T>::load(dy + e);
+      const float4 zv = Vec4<T>::load(z + e);
+      const float mean = stat[row * 2];
+      rstd = stat[row * 2 + 1];
+      h = make_float4((zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd);
+      ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+      ag.x += g.x * h.x; ag.y += g.y * h.y; ag.z += g.z * h.z; ag.w += g.w * h.w;
+    }
+    const float4 gg = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
+    const float m1 = group_sum<G>(gg.x + gg.y + gg.z + gg.w) / (float)d;
+    const float m2 = group_sum<G>(gg.x * h.x + gg.y * h.y + gg.z * h.z + gg.w * h.w) / (float)d;
+    if (ok) {
+      const long long e = row * d + gl * 4;
+      float4 o = make_float4(rstd * (gg.x - m1 - h.x * m2), rstd * (gg.y - m1 - h.y * m2), rstd * (gg.z - m1 - h.z * m2),
+                             rstd * (gg.w - m1 - h.w * m2));
+      Vec4<T>::store(dz + e, o);
+      if (dr != dz) Vec4<T>::store(dr + e, drop4(dc, (uint64_t)(e >> 2), o));
+    }
+  }
+  float* dst = red + ((long long)rg * d + gl * 4) * 2;
+  dst[0] = ag.x; dst[1] = ab.x; dst[2] = ag.y; dst[3] = ab.y; dst[4] = ag.z; dst[5] = ab.z; dst[6] = ag.w; dst[7] = ab.w;
+  __syncthreads();
+  for (int i = threadIdx.x; i < d * 2; i += blockDim.x) {
+    float acc = 0.f;
+    for (int g = 0; g < nrg; ++g) acc += red[(long long)g * d * 2 + i];
+    atomicAdd(((i & 1) ? dbeta : dgamma) + (i >> 1), acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int stats_rows(long long S, int B, int* nchunks) {
+  long long want = 2048 / (B > 0 ? B : 1);
+  if (want < 1) want = 1;
+  long long rows = (S + want - 1) / want;
+  if (rows < 64) rows = 64;
+  *nchunks = (int)((S + rows - 1) / rows);
+  return (int)rows;
+}
+
+extern "C" int ltu_instnorm_stats(const void* x, float* sums, int B, long long S, int C, int dtype, ltu_stream_t s) {
+  if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  int nchunks;
+  const int rows = stats_rows(S, B, &nchunks);
+  const int block = 256;
+  const int nrg = block / (C / 4);
+  if (nrg < 1) return LTU_E_SHAPE;
+  const size_t lds = (size_t)nrg * C * 2 * sizeof(float);
+  LTU_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((instnorm_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)x, sums, S, C, rows);
+  });
+  return ltu_check_launch();
+}
+
+static unsigned stream_grid(long long nvec) {
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C,
+                                  int act, float slope, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+  if (C % 4 != 0) return LTU_E_SHAPE;
+  const long long nvec = (long long)B * S * C / 4;
+  LTU_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((instnorm_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)x, sums,
+                       (const T*)res, (T*)y, S, C, B, act, slope, p, seed);
+  });
+  return ltu_check_launch();
+}
+
+extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, void* dx, int B, long long S,
+                                int C, int act, float slope, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+  if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  int nchunks;
+  const int rows = stats_rows(S, B, &nchunks);
+  const int block = 256;
+  const int nrg = block / (C / 4);
+  if (nrg < 1) return LTU_E_SHAPE;
+  const size_t lds = (size_t)nrg * C * 2 * sizeof(float);
+  const long long nvec = (long long)B * S * C / 4;
+  LTU_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)dy,
+                       (const T*)x, sums, bsums, S, C, rows, act, slope, p, seed);
+    hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
+                       (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed);
+  });
+  return ltu_check_launch();
+}
+
+#define LN_DISPATCH_G(d, ...)                                \
+  do {                                                       \
+    if ((d) == 32) { constexpr int G = 8; __VA_ARGS__ }      \
+    else if ((d) == 64) { constexpr int G = 16; __VA_ARGS__ } \
+    else if ((d) == 128) { constexpr int G = 32; __VA_ARGS__ } \
+    else if ((d) == 256) { constexpr int G = 64; __VA_ARGS__ } \
+    else return LTU_E_SHAPE;                                 \
+  } while (0)
+
+extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat,
+                                 long long M, int d, float eps, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+  LTU_DISPATCH_T(dtype, {
+    LN_DISPATCH_G(d, {
+      const int rows = 256 / G;
+      hipLaunchKernelGGL((layernorm_fwd_kernel<T, G>), dim3(cdiv(M, rows)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)r,
+                         gamma, beta, (T*)y, stat, M, eps, p, seed);
+    });
+  });
+  return ltu_check_launch();
+}
+
+extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
+                                 float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, int dtype,
+                                 ltu_stream_t s) {
+  LTU_DISPATCH_T(dtype, {
+    LN_DISPATCH_G(d, {
+      const int nrg = 256 / G;
+      long long rows = (M + 1023) / 1024;
+      if (rows < nrg) rows = nrg;
+      rows = (rows + nrg - 1) / nrg * nrg;
+      const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(cdiv(M, rows)), dim3(256), lds, (hipStream_t)s, (const T*)dy,
+                         (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, M, (int)rows, p, seed);
+    });
+  });
+  return ltu_check_launch();
+}

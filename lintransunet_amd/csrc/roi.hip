@@ -1,0 +1,417 @@
+// Dynamic-ROI machinery for gfx950: per-sample box finder, separable sampling plans, and the
+// crop-and-warp / warp-back bilinear resamplers (forward + adjoint), all on device with no host sync.
+//
+// Reference: model/Unet_3Dblock.py 821-873 + 37-49 (box), 51-82 (piecewise-linear index maps),
+// 985-1039 / 1080-1117 (F.grid_sample bilinear, zeros padding, align_corners=True on every depth slice).
+// The sampling grid is an outer product of a 1-D map along H and a 1-D map along W, so a "plan" holds,
+// per axis and sample, for every destination index its two source taps (gather form, used forward) and
+// for every source index the list of destinations that touch it (CSR form, used by the adjoint - no
+// atomics).  The index arithmetic repeats the reference's fp32 operation order without fma contraction.
+#include "common.h"
+
+#define ROI_MAX_LEN 512
+
+struct AxisPlan {
+  int* src0;     // [B][ND]      first source tap (clamped into range)
+  float* wt;     // [B][ND][2]   weights of taps src0, src0+1 (0 where the tap is outside the source)
+  int* cnt;      // [B][NS]
+  int* lidx;     // [B][NS][L]   destinations touching this source index
+  float* lw;     // [B][NS][L]
+  int ND, NS, L;
+};
+
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+
+// model/Unet_3Dblock.py:51-64
+__device__ float map_fwd(float idx, float x0, float x1, int span, int roi, int eval_roi) {
+  const float k2 = fdiv(fsub(x1, x0), (float)(roi - 1));
+  const float k1 = fdiv(fadd(fsub((float)span, x1), x0), (float)(eval_roi - roi));
+  float pos = fadd(fmul(idx, k2), fmul(x0, fsub(1.f, fdiv(k2, k1))));
+  const float r = fdiv(k1, k2);
+  if (pos <= x0) pos = fadd(fmul(pos, r), fmul(x0, fsub(1.f, r)));
+  if (pos >= x1) pos = fadd(fmul(pos, r), fmul(x1, fsub(1.f, r)));
+  return fsub(fdiv(fmul(pos, 2.f), (float)span), 1.f);
+}
+// model/Unet_3Dblock.py:66-82
+__device__ float map_back(float idx, float x0, float x1, int span, int roi, int eval_roi) {
+  const float k2 = fdiv((float)roi, fsub(x1, x0));
+  const float k1 = fdiv((float)(eval_roi - roi), fadd(fsub((float)span, x1), x0));
+  const float p0 = fmul(x0, k1);
+  const float p1 = fsub((float)eval_roi, fmul(fsub((float)span, x1), k1));
+  float pos = fadd(fmul(idx, k2), fmul(p0, fsub(1.f, fdiv(k2, k1))));
+  const float r = fdiv(k1, k2);
+  if (pos <= p0) pos = fadd(fmul(pos, r), fmul(p0, fsub(1.f, r)));
+  if (pos >= p1) pos = fadd(fmul(pos, r), fmul(p1, fsub(1.f, r)));
+  return fsub(fdiv(fmul(pos, 2.f), (float)eval_roi), 1.f);
+}
+
+// grid_sample tap of a normalised coordinate (align_corners=True, zeros padding).  src0 may be -1
+// (then only tap src0+1 = 0 can carry weight); taps outside the source get weight 0.
+__device__ void make_tap(float g, int size, int* src0, float* w0, float* w1) {
+  const float ix = fmul(fdiv(fadd(g, 1.f), 2.f), (float)(size - 1));
+  const float fl = floorf(ix);
+  if (!(fl >= -1.f && fl <= (float)(size - 1))) {   // entirely outside, or NaN
+    *src0 = 0; *w0 = 0.f; *w1 = 0.f;
+    return;
+  }
+  const int i0 = (int)fl;
+  float a = fsub(fadd(fl, 1.f), ix), b = fsub(ix, fl);
+  if (i0 < 0) a = 0.f;
+  if (i0 + 1 > size - 1) b = 0.f;
+  *src0 = i0; *w0 = a; *w1 = b;
+}
+
+__device__ void quantiles(const int* hist, int len, float* lo, float* hi, float* center) {
+  int total = 0;
+  for (int i = 0; i < len; ++i) total += hist[i];
+  if (total == 0) {
+    const float mid = (float)len / 2.f;
+    *lo = mid - 1.f; *hi = mid + 1.f; *center = mid;
+    return;
+  }
+  int l = len, h = len, m = len, run = 0;
+  const float ft = (float)total;
+  for (int i = 0; i < len; ++i) {
+    run += hist[i];
+    const float ratio = fdiv((float)run, ft);
+    if (l == len && ratio >= 0.001f) l = i;
+    if (h == len && ratio > 0.999f) h = i;
+    if (m == len && ratio > 0.5f) m = i;
+  }
+  *lo = (float)l; *hi = (float)h; *center = (float)m;
+}
+
+__device__ void fit_extent(float lo, float hi, float center, int full, int min_len, float* out_lo, float* out_hi) {
+  const float size = hi - lo;
+  float a = lo, b = hi;
+  if (size < (float)min_len) {
+    const float half = (float)min_len / 2.f;
+    a = fmaxf(center - half, 0.f);
+    b = fminf(center + half, (float)full);
+  }
+  if (size > (float)(full - min_len)) {
+    const float half = (float)(full - min_len) / 2.f;
+    a = fmaxf(center - half, 0.f);
+    b = fminf(center + half, (float)full);
+  }
+  *out_lo = a; *out_hi = b;
+}
+
+struct RoiArgs {
+  const float* prob;   // [B][H][W][D][C] class probabilities; foreground = 1 - prob[..., 0]
+  int B, H, W, D, C;
+  float thr;
+  int h_roi, w_roi, eval_h, eval_w, min_h, min_w;
+  float* box;          // [B][6]
+  AxisPlan fh, fw, bh, bw;
+};
+
+__device__ void build_axis(const AxisPlan& p, int b, bool forward, float x0, float x1, int span, int roi, int eval_roi) {
+  for (int i = threadIdx.x; i < p.ND; i += blockDim.x) {
+    const float g = forward ? map_fwd((float)i, x0, x1, span, roi, eval_roi) : map_back((float)i, x0, x1, span, roi, eval_roi);
+    int s0; float w0, w1;
+    make_tap(g, p.NS, &s0, &w0, &w1);
+    p.src0[(long long)b * p.ND + i] = s0;
+    p.wt[((long long)b * p.ND + i) * 2] = w0;
+    p.wt[((long long)b * p.ND + i) * 2 + 1] = w1;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < p.NS; x += blockDim.x) {
+    int n = 0;
+    int* li = p.lidx + ((long long)b * p.NS + x) * p.L;
+    float* lw = p.lw + ((long long)b * p.NS + x) * p.L;
+    for (int i = 0; i < p.ND; ++i) {
+      const int s0 = p.src0[(long long)b * p.ND + i];
+      const float w0 = p.wt[((long long)b * p.ND + i) * 2], w1 = p.wt[((long long)b * p.ND + i) * 2 + 1];
+      if (s0 == x && w0 != 0.f && n < p.L) { li[n] = i; lw[n] = w0; ++n; }
+      if (s0 + 1 == x && w1 != 0.f && n < p.L) { li[n] = i; lw[n] = w1; ++n; }
+    }
+    p.cnt[(long long)b * p.NS + x] = n;
+  }
+  __syncthreads();
+}
+
+__global__ void roi_plan_kernel(const RoiArgs a) {
+  __shared__ int hx[ROI_MAX_LEN], hy[ROI_MAX_LEN];
+  __shared__ float bx[4];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < ROI_MAX_LEN; i += blockDim.x) { hx[i] = 0; hy[i] = 0; }
+  __syncthreads();
+  const long long n = (long long)a.H * a.W * a.D;
+  const float* pb = a.prob + (long long)b * n * a.C;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float fg = fsub(1.f, pb[i * a.C]);
+    if (fg >= a.thr) {
+      const long long hw = i / a.D;
+      atomicAdd(&hx[(int)(hw / a.W)], 1);
+      atomicAdd(&hy[(int)(hw % a.W)], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float lo, hi, c;
+    quantiles(hx, a.H, &lo, &hi, &c);
+    fit_extent(lo, hi, c, a.H, a.min_h, &bx[0], &bx[2]);
+    quantiles(hy, a.W, &lo, &hi, &c);
+    fit_extent(lo, hi, c, a.W, a.min_w, &bx[1], &bx[3]);
+    float* o = a.box + b * 6;
+    o[0] = bx[0]; o[1] = bx[1]; o[2] = 0.f; o[3] = bx[2]; o[4] = bx[3]; o[5] = (float)(a.D - 1);
+  }
+  __syncthreads();
+  const float x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+  build_axis(a.fh, b, true, x0, x1, a.H - 1, a.h_roi, a.eval_h);
+  build_axis(a.fw, b, true, y0, y1, a.W - 1, a.w_roi, a.eval_w);
+  build_axis(a.bh, b, false, x0, x1, a.H - 1, a.h_roi, a.eval_h);
+  build_axis(a.bw, b, false, y0, y1, a.W - 1, a.w_roi, a.eval_w);
+}
+
+// plan buffers: ints  = [src0 B*ND | cnt B*NS | lidx B*NS*L],  floats = [wt B*ND*2 | lw B*NS*L],  L = 2*ND
+static void carve_plan(AxisPlan& p, int B, int ND, int NS, int* ibuf, float* fbuf, long long* ioff, long long* foff) {
+  p.ND = ND; p.NS = NS; p.L = 2 * ND;
+  p.src0 = ibuf + *ioff; *ioff += (long long)B * ND;
+  p.cnt = ibuf + *ioff; *ioff += (long long)B * NS;
+  p.lidx = ibuf + *ioff; *ioff += (long long)B * NS * p.L;
+  p.wt = fbuf + *foff; *foff += (long long)B * ND * 2;
+  p.lw = fbuf + *foff; *foff += (long long)B * NS * p.L;
+}
+static void carve_all(RoiArgs& a, int B, int H, int W, int eval_h, int eval_w, int* ibuf, float* fbuf, long long* ni, long long* nf) {
+  long long io = 0, fo = 0;
+  carve_plan(a.fh, B, eval_h, H, ibuf, fbuf, &io, &fo);
+  carve_plan(a.fw, B, eval_w, W, ibuf, fbuf, &io, &fo);
+  // the warp-back reads the un-embedded grid, whose H/W are 2*ceil(eval/2) (stride-2 embed, nearest x2 un-embed);
+  // the reference normalises by eval and lets grid_sample un-normalise by the actual size (Unet_3Dblock.py:1101-1112)
+  carve_plan(a.bh, B, H, 2 * ((eval_h + 1) / 2), ibuf, fbuf, &io, &fo);
+  carve_plan(a.bw, B, W, 2 * ((eval_w + 1) / 2), ibuf, fbuf, &io, &fo);
+  *ni = io; *nf = fo;
+}
+
+extern "C" int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n_int, long long* n_float) {
+  RoiArgs a;
+  const int eval_h = (int)(1.2 * roi_size), eval_w = (int)(eval_h * 0.6);
+  carve_all(a, B, H, W, eval_h, eval_w, nullptr, nullptr, n_int, n_float);
+  return LTU_OK;
+}
+
+extern "C" int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C, int roi_size, float thr, float* box, int* plan_i,
+                            float* plan_f, ltu_stream_t s) {
+  if (H > ROI_MAX_LEN || W > ROI_MAX_LEN) return LTU_E_SHAPE;
+  RoiArgs a;
+  a.prob = prob; a.B = B; a.H = H; a.W = W; a.D = D; a.C = C; a.thr = thr; a.box = box;
+  a.h_roi = roi_size;
+  a.w_roi = (int)(roi_size * 0.6);
+  a.eval_h = (int)(1.2 * roi_size);
+  a.eval_w = (int)(a.eval_h * 0.6);
+  a.min_h = a.eval_h / 2;
+  a.min_w = a.eval_w / 2;
+  long long ni, nf;
+  carve_all(a, B, H, W, a.eval_h, a.eval_w, plan_i, plan_f, &ni, &nf);
+  hipLaunchKernelGGL(roi_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  return ltu_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ resamplers
+// dst[b,i,j,d,:] = sum_{a,e} wh[i][a] ww[j][e] src[b, h0(i)+a, w0(j)+e, d, :]
+template <typename T>
+__global__ void plan_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const AxisPlan ph, const AxisPlan pw, int B,
+                                   int D, int C) {
+  const int cv = C / 4;
+  const long long n = (long long)B * ph.ND * pw.ND * D * cv;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(t % cv);
+    long long r = t / cv;
+    const int d = (int)(r % D); r /= D;
+    const int j = (int)(r % pw.ND); r /= pw.ND;
+    const int i = (int)(r % ph.ND);
+    const int b = (int)(r / ph.ND);
+    const int h0 = ph.src0[(long long)b * ph.ND + i], w0 = pw.src0[(long long)b * pw.ND + j];
+    const float* wh = ph.wt + ((long long)b * ph.ND + i) * 2;
+    const float* ww = pw.wt + ((long long)b * pw.ND + j) * 2;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float w = wh[a] * ww[e];
+        if (w == 0.f) continue;
+        const int hs = min(max(h0 + a, 0), ph.NS - 1), ws = min(max(w0 + e, 0), pw.NS - 1);
+        const float4 q = Vec4<T>::load(src + ((((long long)b * ph.NS + hs) * pw.NS + ws) * D + d) * C + v * 4);
+        acc.x += q.x * w; acc.y += q.y * w; acc.z += q.z * w; acc.w += q.w * w;
+      }
+    Vec4<T>::store(dst + t * 4, acc);
+  }
+}
+
+// adjoint: dsrc[b,x,y,d,:] = sum_{(i,wi) in list_h(x)} sum_{(j,wj) in list_w(y)} wi wj ddst[b,i,j,d,:]
+template <typename T>
+__global__ void plan_scatter_kernel(const T* __restrict__ ddst, T* __restrict__ dsrc, const AxisPlan ph, const AxisPlan pw, int B,
+                                    int D, int C) {
+  const int cv = C / 4;
+  const long long n = (long long)B * ph.NS * pw.NS * D * cv;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(t % cv);
+    long long r = t / cv;
+    const int d = (int)(r % D); r /= D;
+    const int y = (int)(r % pw.NS); r /= pw.NS;
+    const int x = (int)(r % ph.NS);
+    const int b = (int)(r / ph.NS);
+    const int nh = ph.cnt[(long long)b * ph.NS + x], nw = pw.cnt[(long long)b * pw.NS + y];
+    const int* lih = ph.lidx + ((long long)b * ph.NS + x) * ph.L;
+    const float* lwh = ph.lw + ((long long)b * ph.NS + x) * ph.L;
+    const int* liw = pw.lidx + ((long long)b * pw.NS + y) * pw.L;
+    const float* lww = pw.lw + ((long long)b * pw.NS + y) * pw.L;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < nh; ++a) {
+      const int i = lih[a];
+      const float wi = lwh[a];
+      for (int e = 0; e < nw; ++e) {
+        const float w = wi * lww[e];
+        const float4 q = Vec4<T>::load(ddst + ((((long long)b * ph.ND + i) * pw.ND + liw[e]) * D + d) * C + v * 4);
+        acc.x += q.x * w; acc.y += q.y * w; acc.z += q.z * w; acc.w += q.w * w;
+      }
+    }
+    Vec4<T>::store(dsrc + t * 4, acc);
+  }
+}
+
+static unsigned rgrid(long long n) {
+  long long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// which: 0 = image -> ROI grid (roi_alignment2), 1 = ROI grid -> image (post_processing2); adjoint != 0 runs the transpose.
+extern "C" int ltu_roi_resample(const void* in, void* out, int* plan_i, float* plan_f, int which, int adjoint, int B, int H, int W,
+                                int D, int C, int roi_size, int dtype, ltu_stream_t s) {
+  if (C % 4) return LTU_E_SHAPE;
+  RoiArgs a;
+  const int eval_h = (int)(1.2 * roi_size), eval_w = (int)(eval_h * 0.6);
+  long long ni, nf;
+  carve_all(a, B, H, W, eval_h, eval_w, plan_i, plan_f, &ni, &nf);
+  const AxisPlan& ph = which == 0 ? a.fh : a.bh;
+  const AxisPlan& pw = which == 0 ? a.fw : a.bw;
+  LTU_DISPATCH_T(dtype, {
+    if (!adjoint) {
+      const long long n = (long long)B * ph.ND * pw.ND * D * (C / 4);
+      hipLaunchKernelGGL((plan_gather_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, ph, pw, B, D, C);
+    } else {
+      const long long n = (long long)B * ph.NS * pw.NS * D * (C / 4);
+      hipLaunchKernelGGL((plan_scatter_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, ph, pw, B, D, C);
+    }
+  });
+  return ltu_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ trilinear x2
+// nn.Upsample(scale (2,2,2) | (2,2,1), trilinear, align_corners=True)  (model/Unet_3Dblock.py:1341-1345)
+// src coordinate of output o along an axis: o * (in-1)/(out-1) in fp32, taps floor and floor+1 (clamped).
+__device__ __forceinline__ void tri_tap(int o, int in, int out, int* i0, int* i1, float* l0, float* l1) {
+  if (in == out) { *i0 = o; *i1 = o; *l0 = 1.f; *l1 = 0.f; return; }
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)o;
+  int a = (int)src;
+  if (a > in - 1) a = in - 1;
+  const int p = a < in - 1 ? 1 : 0;
+  const float lam = src - (float)a;
+  *i0 = a; *i1 = a + p; *l1 = lam; *l0 = 1.f - lam;
+}
+
+template <typename T>
+__global__ void trilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int D, int C, int Ho, int Wo,
+                                     int Do) {
+  const int cv = C / 4;
+  const long long n = (long long)B * Ho * Wo * Do * cv;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(t % cv);
+    long long r = t / cv;
+    const int d = (int)(r % Do); r /= Do;
+    const int w = (int)(r % Wo); r /= Wo;
+    const int h = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    int h0, h1, w0, w1, d0, d1;
+    float lh0, lh1, lw0, lw1, ld0, ld1;
+    tri_tap(h, H, Ho, &h0, &h1, &lh0, &lh1);
+    tri_tap(w, W, Wo, &w0, &w1, &lw0, &lw1);
+    tri_tap(d, D, Do, &d0, &d1, &ld0, &ld1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int hs[2] = {h0, h1}, ws[2] = {w0, w1}, dsv[2] = {d0, d1};
+    const float lh[2] = {lh0, lh1}, lw[2] = {lw0, lw1}, ld[2] = {ld0, ld1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const float wgt = lh[a] * lw[e] * ld[f];
+          if (wgt == 0.f) continue;
+          const float4 q = Vec4<T>::load(x + ((((long long)b * H + hs[a]) * W + ws[e]) * D + dsv[f]) * C + v * 4);
+          acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
+        }
+    Vec4<T>::store(y + t * 4, acc);
+  }
+}
+
+// adjoint in gather form: candidates o with src(o) in (i-1, i+1), tested with the forward's own tap function
+__device__ __forceinline__ int tri_cands(int i, int in, int out, int* os, float* wsum) {
+  if (in == out) { os[0] = i; wsum[0] = 1.f; return 1; }
+  int n = 0;
+  const float inv = (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1);
+  int lo = (int)floorf((float)(i - 1) * inv) - 1, hi = (int)ceilf((float)(i + 1) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+  for (int o = lo; o <= hi && n < 8; ++o) {
+    int i0, i1; float l0, l1;
+    tri_tap(o, in, out, &i0, &i1, &l0, &l1);
+    float w = 0.f;
+    if (i0 == i) w += l0;
+    if (i1 == i) w += l1;
+    if (w != 0.f) { os[n] = o; wsum[n] = w; ++n; }
+  }
+  return n;
+}
+
+template <typename T>
+__global__ void trilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int D, int C, int Ho, int Wo,
+                                     int Do) {
+  const int cv = C / 4;
+  const long long n = (long long)B * H * W * D * cv;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(t % cv);
+    long long r = t / cv;
+    const int d = (int)(r % D); r /= D;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    int oh[8], ow[8], od[8];
+    float wh[8], ww[8], wd[8];
+    const int nh = tri_cands(h, H, Ho, oh, wh), nw = tri_cands(w, W, Wo, ow, ww), nd = tri_cands(d, D, Do, od, wd);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < nh; ++a)
+      for (int e = 0; e < nw; ++e)
+        for (int f = 0; f < nd; ++f) {
+          const float wgt = wh[a] * ww[e] * wd[f];
+          const float4 q = Vec4<T>::load(dy + ((((long long)b * Ho + oh[a]) * Wo + ow[e]) * Do + od[f]) * C + v * 4);
+          acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
+        }
+    Vec4<T>::store(dx + t * 4, acc);
+  }
+}
+
+extern "C" int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
+                                ltu_stream_t s) {
+  if (C % 4 || (sd != 1 && sd != 2)) return LTU_E_SHAPE;
+  const int Ho = 2 * H, Wo = 2 * W, Do = sd * D;
+  LTU_DISPATCH_T(dtype, {
+    if (!adjoint) {
+      const long long n = (long long)B * Ho * Wo * Do * (C / 4);
+      hipLaunchKernelGGL((trilinear_fwd_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W, D, C, Ho, Wo, Do);
+    } else {
+      const long long n = (long long)B * H * W * D * (C / 4);
+      hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W, D, C, Ho, Wo, Do);
+    }
+  });
+  return ltu_check_launch();
+}

@@ -1,0 +1,110 @@
+"""Loss surface of loss/criterions.py (binary labels) and loss/multi_criterions.py (class labels) over
+the fused HIP loss kernels.
+
+`get_criterions(name_list) -> {name: nn.Module}` keeps the reference contract (loss/criterions.py:773-782):
+every module is `forward(predict[N,C,...], target) -> 0-dim tensor`.  `target` is an integer label
+volume [N,1,...] (or a one-hot [N,C,...] tensor, as the multi-class scripts pass).  All losses of one
+decoder level share one streaming reduction (`LevelCriterion`).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _channels_last(predict):
+    """[N,C,...] (any strides) -> contiguous fp32 [N,...,C]"""
+    nd = predict.dim()
+    cl = predict.permute(0, *range(2, nd), 1)
+    if cl.dtype != torch.float32:
+        cl = cl.float()
+    return cl.contiguous()
+
+
+def _labels(target, n_class):
+    """[N,1,...] integer labels, or one-hot [N,C,...], -> uint8 [N,...]"""
+    if target.dim() >= 2 and target.shape[1] == n_class and n_class > 1 and target.shape[1] != 1:
+        target = target.argmax(dim=1, keepdim=True)
+    return target.reshape(target.shape[0], *target.shape[2:]).to(torch.uint8).contiguous()
+
+
+class LevelCriterion(nn.Module):
+    """Weighted sum of CE / balanced Dice / per-class Dice on one prediction, one kernel pass.
+
+    spec: {'CrossEntroLoss': w, 'BalanceDiceLoss': w, 'DiceClassLoss': w (class 1), 'DiceClassLoss2': w (class 2),
+           'DiceClassLoss0c': w (class 0)}.  Returns (total, {name: value}) with values detached.
+    """
+    _DICE = {'DiceClassLoss': 1, 'DiceClassLoss2': 2, 'DiceClassLoss0c': 0}
+
+    def __init__(self, spec: dict, scale: float = 1.0):
+        super().__init__()
+        unknown = set(spec) - {'CrossEntroLoss', 'BalanceDiceLoss', *self._DICE}
+        if unknown:
+            raise KeyError(f'no HIP kernel for losses {sorted(unknown)}')
+        self.spec = dict(spec)
+        self.scale = scale
+
+    def forward(self, predict, target):
+        p = _channels_last(predict)
+        C = p.shape[-1]
+        lab = _labels(target, C)
+        sc = self.scale
+        wd = [0.0] * 4
+        for name, cls in self._DICE.items():
+            if name in self.spec:
+                wd[cls] += self.spec[name] * sc
+        total, values = ops.level_loss(p, lab, self.spec.get('CrossEntroLoss', 0.0) * sc,
+                                       self.spec.get('BalanceDiceLoss', 0.0) * sc, wd)
+        named = {}
+        for name in self.spec:
+            if name == 'CrossEntroLoss':
+                named[name] = values[1]
+            elif name == 'BalanceDiceLoss':
+                named[name] = values[2]
+            else:
+                named[name] = values[3 + self._DICE[name]]
+        return total, named
+
+
+class _Single(nn.Module):
+    NAME = None
+
+    def __init__(self):
+        super().__init__()
+        self.impl = LevelCriterion({self.NAME: 1.0})
+
+    def forward(self, predict, target):
+        return self.impl(predict, target)[0]
+
+
+class CrossEntroLoss(_Single):
+    """loss/criterions.py:696-735"""
+    NAME = 'CrossEntroLoss'
+
+
+class DiceClassLoss(_Single):
+    """loss/criterions.py:35-70 (class 1)"""
+    NAME = 'DiceClassLoss'
+
+
+class DiceClassLoss2(_Single):
+    """loss/multi_criterions.py:85-110 (class 2)"""
+    NAME = 'DiceClassLoss2'
+
+
+class BalanceDiceLoss(_Single):
+    """loss/criterions.py:416-442"""
+    NAME = 'BalanceDiceLoss'
+
+
+Loss_Dict = {
+    'CrossEntroLoss': CrossEntroLoss,
+    'DiceClassLoss': DiceClassLoss,
+    'DiceClassLoss2': DiceClassLoss2,
+    'BalanceDiceLoss': BalanceDiceLoss,
+}
+
+
+def get_criterions(name_list):
+    """loss/criterions.py:773-782"""
+    return {name: Loss_Dict[name]() for name in name_list}

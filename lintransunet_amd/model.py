@@ -1,0 +1,224 @@
+"""MaskTransUnet on MI355X: the nn.Module surface of model/trans_3DUnet.py:150-222 over HIP kernels.
+
+Drop-in contract:
+  * `get_model_dict('MaskTransUnet')(num_layers, roi_size_list, is_roi_list, dim_input, dim_output,
+    kernel_size=3, dropout=0.3)` builds a module whose `state_dict()` has exactly the reference's
+    614 keys / shapes (checkpoints load with strict=True, including the 14 unused
+    `decode.bridge_list.4.transformer.pos_encoders.{1..7}` tensors).
+  * `forward(x[B,1,H,W,D])` returns `(probs[B,C,H,W,D], [mask]*4)` in training mode and the one-hot
+    arg-max tensor in eval mode.  Returned tensors are channels-last in memory, exposed through a
+    permuted view so indexing/shape follow the reference.
+
+The parameter containers are plain torch modules (they provide names, initialisation and the
+optimizer/DDP plumbing); their own forward() is never called - all arithmetic goes through
+`ops` (libltu_hip.so).  The module fails loudly on CPU tensors: there is no fallback path.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+HEAD_DIM = 32      # model/Unet_3Dblock.py:1294
+N_LAYERS = 8
+
+
+def _cl(t):
+    """logical [B,C,H,W,D] view of a channels-last [B,H,W,D,C] tensor"""
+    return t.permute(0, 4, 1, 2, 3)
+
+
+class _Group(nn.Module):
+    """anonymous parameter container"""
+
+
+def _conv_pair(cin, cout):
+    g = _Group()
+    g.conv1 = nn.Conv3d(cin, cin if cout is None else cout[0], 3, padding=1)
+    return g
+
+
+def _transformer_layer(d):
+    """parameter names of model/trans_block.py:127-211"""
+    lay = _Group()
+    lay.self_attn = _Group()
+    lay.self_attn.linears = nn.ModuleList([nn.Linear(d, d) for _ in range(4)])
+    lay.linear1 = nn.Linear(d, 2 * d)
+    lay.linear2 = nn.Linear(2 * d, d)
+    lay.layer_norm1 = nn.LayerNorm(d, eps=1e-6)
+    lay.layer_norm2 = nn.LayerNorm(d, eps=1e-6)
+    return lay
+
+
+def _pos_encoder(d):
+    pe = _Group()
+    pe.proj = nn.Conv3d(d, d, 3, padding=1, groups=d)
+    return pe
+
+
+class _SeedStream:
+    """Distinct dropout stream ids inside one forward pass."""
+
+    def __init__(self, base):
+        self.base = int(base) & 0xFFFFFFFFFF
+        self.n = 0
+
+    def next(self):
+        self.n += 1
+        return (self.base << 20) + self.n
+
+
+class MaskTransUnet(nn.Module):
+    def __init__(self, num_layers, roi_size_list, is_roi_list, dim_input, dim_output, kernel_size=3, dropout=0.3,
+                 act_dtype=torch.float32):
+        super().__init__()
+        if kernel_size != 3:
+            raise ValueError('only the reference default kernel_size=3 is supported')
+        if dim_input != 1:
+            raise ValueError('window embedding of the reference assumes dim_input=1 (Unet_3Dblock.py:131-132)')
+        L = list(num_layers)
+        nl = len(L)
+        self.num_layers, self.roi_size_list, self.is_roi_list = L, list(roi_size_list), list(is_roi_list)
+        self.dim_input, self.dim_output, self.kernel_size, self.dropout = dim_input, dim_output, kernel_size, dropout
+        self.act_dtype = act_dtype
+        self._step = 0
+
+        enc = self.encode = _Group()
+        enc.block_list = nn.ModuleList()
+        for i in range(1, nl):
+            blk = _Group()
+            blk.conv1 = nn.Conv3d(L[i - 1], L[i - 1], 3, padding=1)
+            blk.conv2 = nn.Conv3d(L[i - 1], L[i], 3, stride=(2, 2, (i - 1) % 2 + 1), padding=1)
+            enc.block_list.append(blk)
+        enc.input_block = nn.Conv3d(dim_input * 4, L[0], 3, padding=1)
+
+        dec = self.decode = _Group()
+        dec.bridge_list = nn.ModuleList()
+        for i in range(nl - 1):
+            br = _Group()
+            if self.is_roi_list[i]:
+                d = min(4 * L[i], 256)
+                tr = br.transformer = _Group()
+                tr.down_embed = _Group()
+                tr.down_embed.module_list = nn.Sequential(nn.Sequential(nn.Conv3d(L[i], d, 3, stride=2, padding=1)))
+                tr.up_embed = _Group()
+                tr.up_embed.module_list = nn.Sequential(nn.Sequential(nn.Identity(), nn.Conv3d(d, L[i], 3, padding=1)))
+                tr.pos_encoder = _pos_encoder(d)
+                tr.layers = nn.ModuleList([_transformer_layer(d) for _ in range(N_LAYERS)])
+            dec.bridge_list.append(br)
+        bott = _Group()
+        bott.transformer = _Group()
+        bott.transformer.pos_encoders = nn.ModuleList([_pos_encoder(L[-1]) for _ in range(N_LAYERS)])
+        bott.transformer.layers = nn.ModuleList([_transformer_layer(L[-1]) for _ in range(N_LAYERS)])
+        dec.bridge_list.append(bott)
+        dec.mask_conv_list = nn.ModuleList([nn.Conv3d(L[i], dim_output, 3, padding=1) for i in range(1, nl)])
+        dec.att_conv_list = nn.ModuleList()
+        for i in range(1, nl):
+            g = _Group()
+            g.W_x = nn.Sequential(nn.Conv3d(L[i - 1], L[i - 1], 1))
+            g.W_g = nn.Sequential(nn.Conv3d(L[i], L[i - 1], 1))
+            g.psi = nn.Sequential(nn.Conv3d(L[i - 1], 1, 1))
+            dec.att_conv_list.append(g)
+        dec.block_list = nn.ModuleList()
+        for i in range(1, nl):
+            blk = _Group()
+            blk.conv1 = nn.Conv3d(L[-i], L[-i - 1], 3, padding=1)
+            blk.conv2 = nn.Conv3d(2 * L[-i - 1], L[-i - 1], 3, padding=1)
+            dec.block_list.append(blk)
+        dec.final_block = nn.Conv3d(L[0], dim_output * 4, 3, padding=1)
+        self.last_boxes = []
+
+    # ------------------------------------------------------------------ pieces
+    def _conv_in_act(self, x, conv, stride=(1, 1, 1), res=None, p=0.0, seeds=None, x1=None, ups=False):
+        y = ops.conv3d(x, conv.weight, conv.bias, stride=stride, x1=x1, ups=ups)
+        return ops.instnorm_act(y, res=res, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0)
+
+    def _layer(self, lay, t, B, N, d, p, seeds):
+        """post-norm transformer layer on tokens t [B*N, d] (model/trans_block.py:148-166, 203-211)"""
+        lin = lay.self_attn.linears
+        qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias])
+        a = ops.linear_attention(qkv, B, N, d)
+        a = ops.linear(a, [lin[3].weight], [lin[3].bias])
+        t = ops.res_layernorm(t, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0)
+        f = ops.linear(t, [lay.linear1.weight], [lay.linear1.bias])
+        f = ops.gelu_dropout(f, p, seeds.next() if p > 0 else 0)
+        f = ops.linear(f, [lay.linear2.weight], [lay.linear2.bias])
+        return ops.res_layernorm(t, f, lay.layer_norm2.weight, lay.layer_norm2.bias, 1e-6, p, seeds.next() if p > 0 else 0)
+
+    def _token_transformer(self, layers, pos, x, p, seeds):
+        """8 layers over the voxels of x [B,H,W,D,d]; positional conv after layer 0.  Token order does not
+        matter to the layers (per-token ops + a set reduction over tokens), so voxels stay in place."""
+        B, H, W, D, d = x.shape
+        N = H * W * D
+        t = x.reshape(B * N, d)
+        for n, lay in enumerate(layers):
+            t = self._layer(lay, t, B, N, d, p, seeds)
+            if n == 0:
+                g = ops.pos_conv(t.view(B, H, W, D, d), pos.proj.weight, pos.proj.bias, p, seeds.next() if p > 0 else 0)
+                t = g.view(B * N, d)
+        return t.view(B, H, W, D, d)
+
+    def _roi_bridge(self, br, skip, mask, roi_size, p, seeds):
+        """model/Unet_3Dblock.py:717-755"""
+        plan = ops.RoiPlan(mask, roi_size, 0.5)
+        self.last_boxes.append(plan.box)
+        tr = br.transformer
+        g = ops.roi_warp(skip, plan)
+        e = self._conv_in_act(g, tr.down_embed.module_list[0][0], stride=(2, 2, 2), p=p, seeds=seeds)
+        e = self._token_transformer(tr.layers, tr.pos_encoder, e, p, seeds)
+        e = self._conv_in_act(e, tr.up_embed.module_list[0][1], p=p, seeds=seeds, ups=True)
+        # the nearest x2 grid is 2*ceil(n/2) wide: crop back when the ROI grid is odd (F.interpolate gives 2*n_down)
+        return ops.roi_unwarp(e, plan)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('lintransunet_amd.MaskTransUnet runs on MI355X only (no CPU fallback); move the input to cuda')
+        L, nl, C = self.num_layers, len(self.num_layers), self.dim_output
+        p = float(self.dropout) if self.training else 0.0
+        self._step += 1
+        seeds = _SeedStream(torch.initial_seed() * 1000003 + self._step)
+        self.last_boxes = []
+        B, _, H, W, D = x.shape
+        if H % 2 or W % 2:
+            raise ValueError('H and W must be even')
+        enc, dec = self.encode, self.decode
+
+        t = ops.window_embed(x.contiguous().float(), self.act_dtype)
+        t = self._conv_in_act(t, enc.input_block, seeds=seeds)
+        skips = []
+        for i, blk in enumerate(enc.block_list):
+            s = self._conv_in_act(t, blk.conv1, res=t, seeds=seeds)
+            t = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds)
+            skips.append(s)
+
+        bt = dec.bridge_list[nl - 1].transformer
+        t = self._token_transformer(bt.layers, bt.pos_encoders[0], t, p, seeds)
+        masks = []
+        for i in range(1, nl):
+            lvl = nl - 1 - i
+            t = ops.trilinear_up(t, 2 if (nl - i) % 2 == 0 else 1)
+            mc = dec.mask_conv_list[lvl]
+            m = ops.head_softmax(ops.conv3d(t, mc.weight, mc.bias, cop=4), C)
+            masks.append(m)
+            ag = dec.att_conv_list[lvl]
+            skip = ops.attention_gate(skips[-i], t, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,
+                                      ag.psi[0].weight, ag.psi[0].bias)
+            if self.is_roi_list[lvl]:
+                skip = self._roi_bridge(dec.bridge_list[lvl], skip, m.detach(), self.roi_size_list[lvl], p, seeds)
+            blk = dec.block_list[i - 1]
+            t = self._conv_in_act(t, blk.conv1, seeds=seeds)
+            t = self._conv_in_act(t, blk.conv2, x1=skip, p=p, seeds=seeds)
+        z = ops.conv3d(t, dec.final_block.weight, dec.final_block.bias)
+        out = ops.final_softmax(z, C)
+        if self.training:
+            return _cl(out), [_cl(m) for m in masks]
+        return _cl(ops.onehot_argmax(out.detach()))
+
+
+Model_Dict = {'MaskTransUnet': MaskTransUnet}
+
+
+def get_model_dict(name: str):
+    """Same contract as model/trans_3DUnet.py:215-222.  Only MaskTransUnet exists: the reference's other
+    four registry entries cannot run."""
+    return Model_Dict[name]

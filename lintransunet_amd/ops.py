@@ -1,0 +1,596 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels (include/ltu_hip.h).
+
+Device tensors are channels-last: a reference tensor [B,C,H,W,D] is held as a contiguous
+[B,H,W,D,C] tensor (fp32 or bf16).  PyTorch only provides memory, streams and the autograd
+graph here; every arithmetic op is a HIP kernel from libltu_hip.so and there is no fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU = 0, 1
+LRELU_SLOPE = 0.01
+_c_void_p = ctypes.c_void_p
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f'unsupported activation dtype {t.dtype}')
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name='tensor'):
+    if not t.is_cuda:
+        raise _lib.LtuError(f'{name} must live on the GPU: the HIP path has no CPU fallback')
+    if not t.is_contiguous():
+        raise _lib.LtuError(f'{name} must be contiguous')
+    return t
+
+
+def _ptr_array(tensors):
+    arr = (_c_void_p * 3)()
+    for i, t in enumerate(tensors):
+        arr[i] = _p(t)
+    return arr
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+# ---------------------------------------------------------------------------------------------- no-grad helpers
+
+def window_embed(x, dtype):
+    """[B,1,H,W,D] fp32 (reference layout) -> [B,H/2,W/2,D,8] channels-last, channels 4..7 zero."""
+    _chk(x, 'x')
+    B, _, H, W, D = x.shape
+    y = torch.empty((B, H // 2, W // 2, D, 8), device=x.device, dtype=dtype)
+    _lib.call('ltu_window_embed', _p(x), _p(y), _dt(y), B, H, W, D, _s())
+    return y
+
+
+def label_maxpool(lab, kd):
+    """uint8 [B,H,W,D] -> max-pool (2,2,kd)."""
+    B, H, W, D = lab.shape
+    y = torch.empty((B, H // 2, W // 2, D // kd), device=lab.device, dtype=torch.uint8)
+    _lib.call('ltu_label_maxpool', _p(lab), _p(y), B, H, W, D, kd, _s())
+    return y
+
+
+def onehot_argmax(p):
+    """probabilities [..., C] fp32 -> one-hot of the arg-max class."""
+    o = torch.empty_like(p)
+    C = p.shape[-1]
+    _lib.call('ltu_onehot_argmax', _p(p), _p(o), p.numel() // C, C, _s())
+    return o
+
+
+class RoiPlan:
+    """Per-sample boxes and the separable sampling plans of one ROI bridge (device resident)."""
+
+    def __init__(self, prob, roi_size, thr=0.5):
+        _chk(prob, 'prob')
+        B, H, W, D, C = prob.shape
+        ni, nf = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        _lib.call('ltu_roi_plan_size', B, H, W, roi_size, ctypes.byref(ni), ctypes.byref(nf))
+        self.B, self.H, self.W, self.D, self.roi_size = B, H, W, D, roi_size
+        self.eval_h = int(1.2 * roi_size)
+        self.eval_w = int(self.eval_h * 0.6)
+        self.up_h, self.up_w = 2 * ((self.eval_h + 1) // 2), 2 * ((self.eval_w + 1) // 2)
+        self.ibuf = torch.zeros(ni.value, device=prob.device, dtype=torch.int32)
+        self.fbuf = torch.zeros(nf.value, device=prob.device, dtype=torch.float32)
+        self.box = torch.empty((B, 6), device=prob.device, dtype=torch.float32)
+        _lib.call('ltu_roi_plan', _p(prob), B, H, W, D, C, roi_size, float(thr), _p(self.box), _p(self.ibuf), _p(self.fbuf), _s())
+
+
+# ---------------------------------------------------------------------------------------------- conv / linear
+
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, stride, ups, cop):
+        _chk(x0, 'x0')
+        B, Hi, Wi, Di, C0 = x0.shape
+        C1 = 0 if x1 is None else _chk(x1, 'x1').shape[-1]
+        Co, Ci = weight.shape[0], weight.shape[1]
+        CiP = C0 + C1
+        assert CiP >= Ci and cop >= Co
+        dev = x0.device
+        wf = torch.empty((cop, 27, CiP), device=dev, dtype=torch.float32)
+        _lib.call('ltu_pack_conv_weight', _p(weight), _p(wf), 0, Co, Ci, cop, CiP, _s())
+        bias_p = bias
+        if cop != Co:
+            bias_p = torch.zeros(cop, device=dev, dtype=torch.float32)
+            bias_p[:Co] = bias
+        sh, sw, sd = stride
+        Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
+        Ho, Wo, Do = (Hl - 1) // sh + 1, (Wl - 1) // sw + 1, (Dl - 1) // sd + 1
+        y = torch.empty((B, Ho, Wo, Do, cop), device=dev, dtype=x0.dtype)
+        _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias_p), _p(y), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
+                  int(ups), _dt(x0), _s())
+        ctx.save_for_backward(x0, x1, weight)
+        ctx.cfg = (stride, ups, cop, C0, C1)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, x1, weight = ctx.saved_tensors
+        stride, ups, cop, C0, C1 = ctx.cfg
+        g = g.contiguous()
+        B, Hi, Wi, Di, _ = x0.shape
+        Co, Ci = weight.shape[0], weight.shape[1]
+        CiP = C0 + C1
+        sh, sw, sd = stride
+        dev = x0.device
+        dt = _dt(x0)
+        dx0 = dx1 = None
+        need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
+        if need_dx:
+            wd = torch.empty((CiP, 27, cop), device=dev, dtype=torch.float32)
+            _lib.call('ltu_pack_conv_weight', _p(weight), 0, _p(wd), Co, Ci, cop, CiP, _s())
+            Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
+            d0 = torch.empty((B, Hl, Wl, Dl, C0), device=dev, dtype=x0.dtype)
+            d1 = torch.empty((B, Hl, Wl, Dl, C1), device=dev, dtype=x0.dtype) if C1 else None
+            _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(d0), _p(d1), B, Hl, Wl, Dl, C0, C1, cop, sh, sw, sd, dt, _s())
+            if ups:
+                dx0 = torch.empty_like(x0)
+                _lib.call('ltu_sumpool2', _p(d0), _p(dx0), B, Hi, Wi, Di, C0, dt, _s())
+            else:
+                dx0 = d0
+            dx1 = d1
+        dwf = torch.zeros((cop, 27, CiP), device=dev, dtype=torch.float32)
+        dbp = torch.zeros(cop, device=dev, dtype=torch.float32)
+        _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dwf), _p(dbp), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
+                  int(ups), dt, _s())
+        dw = torch.empty_like(weight)
+        _lib.call('ltu_unpack_conv_wgrad', _p(dwf), _p(dw), Co, Ci, CiP, _s())
+        db = dbp[:Co].clone() if cop != Co else dbp
+        return dx0, dx1, dw, db, None, None, None
+
+
+def conv3d(x0, weight, bias, stride=(1, 1, 1), x1=None, ups=False, cop=None):
+    """3x3x3 conv, padding 1, on channels-last x0 (+ virtual concat x1).  Output has `cop` (>= Co, padded) channels."""
+    return _Conv3d.apply(x0, x1, weight, bias, tuple(stride), bool(ups), cop or weight.shape[0])
+
+
+class _Linear(torch.autograd.Function):
+    """y[M, sum N_i] = x[M,K] . cat(W_i)^T + cat(b_i);  W_i all [N/nw, K]."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        nw = len(wb) // 2
+        ws, bs = wb[:nw], wb[nw:]
+        _chk(x, 'x')
+        M, K = x.shape
+        Ns = ws[0].shape[0]
+        N = Ns * nw
+        y = torch.empty((M, N), device=x.device, dtype=x.dtype)
+        _lib.call('ltu_linear_fwd', _p(x), K, _ptr_array([w.reshape(Ns, K) for w in ws]), nw, _ptr_array(bs), _p(y), N, M, N,
+                  K, 0, _dt(x), _s())
+        ctx.save_for_backward(x, *ws)
+        ctx.nw = nw
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *ws = ctx.saved_tensors
+        nw = ctx.nw
+        g = g.contiguous()
+        M, K = x.shape
+        Ns = ws[0].shape[0]
+        N = Ns * nw
+        dev, dt = x.device, _dt(x)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((K, N), device=dev, dtype=torch.float32)     # cat(W)^T
+            for i, w in enumerate(ws):
+                _lib.call('ltu_transpose_f32', _p(w), _p(wt), Ns, K, N, i * Ns, _s())
+            dx = torch.empty((M, K), device=dev, dtype=x.dtype)
+            _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
+        dws, dbs = [], []
+        esz = g.element_size()
+        for i, w in enumerate(ws):
+            dw = torch.zeros((Ns, K), device=dev, dtype=torch.float32)
+            db = torch.zeros(Ns, device=dev, dtype=torch.float32)
+            _lib.call('ltu_linear_wgrad', g.data_ptr() + i * Ns * esz, N, _p(x), K, _p(dw), _p(db), M, Ns, K, dt, _s())
+            dws.append(dw.view_as(w))
+            dbs.append(db)
+        return (dx, *dws, *dbs)
+
+
+def linear(x, weights, biases):
+    """x [M,K] (any leading dims flattened by the caller); weights: list of [N_i,K] (or [N_i,K,1,1,1])."""
+    return _Linear.apply(x, *weights, *biases)
+
+
+# ---------------------------------------------------------------------------------------------- norms
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, act, p, seed):
+        _chk(x, 'x')
+        B, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * C)
+        sums = torch.zeros((B, C, 3), device=x.device, dtype=torch.float32)
+        dt = _dt(x)
+        _lib.call('ltu_instnorm_stats', _p(x), _p(sums), B, S, C, dt, _s())
+        y = torch.empty_like(x)
+        _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, dt, _s())
+        ctx.save_for_backward(x, sums)
+        ctx.cfg = (act, p, seed, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, sums = ctx.saved_tensors
+        act, p, seed, has_res = ctx.cfg
+        g = g.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * C)
+        bsums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
+                  _dt(x), _s())
+        return dx, (g if has_res else None), None, None, None
+
+
+def instnorm_act(x, res=None, act=ACT_LRELU, p=0.0, seed=0):
+    """y = dropout(act(InstanceNorm(x))) + res over channels-last x [B,...,C]."""
+    return _InstNormAct.apply(x, res, act, p, seed)
+
+
+class _ResLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, p, seed):
+        _chk(x, 'x'); _chk(r, 'r')
+        M, d = x.shape
+        y = torch.empty_like(x)
+        stat = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+        # r is overwritten with z = x + dropout(r): it is the producer's private output buffer
+        _lib.call('ltu_layernorm_fwd', _p(x), _p(r), _p(gamma), _p(beta), _p(y), _p(stat), M, d, float(eps), float(p), seed,
+                  _dt(x), _s())
+        ctx.save_for_backward(r, stat, gamma)
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        z, stat, gamma = ctx.saved_tensors
+        p, seed = ctx.cfg
+        g = g.contiguous()
+        M, d = z.shape
+        dz = torch.empty_like(z)
+        dr = torch.empty_like(z) if p > 0 else dz
+        dgamma = torch.zeros(d, device=z.device, dtype=torch.float32)
+        dbeta = torch.zeros(d, device=z.device, dtype=torch.float32)
+        _lib.call('ltu_layernorm_bwd', _p(g), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta), M, d,
+                  float(p), seed, _dt(z), _s())
+        return dz, dr, dgamma, dbeta, None, None, None
+
+
+def res_layernorm(x, r, gamma, beta, eps=1e-6, p=0.0, seed=0):
+    """LayerNorm(x + dropout(r)) * gamma + beta over the last dim of [M,d]; consumes (overwrites) r."""
+    return _ResLayerNorm.apply(x, r.detach() if not r.requires_grad else r, gamma, beta, eps, p, seed)
+
+
+class _GeluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, p, seed):
+        _chk(u, 'u')
+        h = torch.empty_like(u)
+        _lib.call('ltu_gelu_dropout_fwd', _p(u), _p(h), u.numel(), float(p), seed, _dt(u), _s())
+        ctx.save_for_backward(u)
+        ctx.cfg = (p, seed)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        p, seed = ctx.cfg
+        g = g.contiguous()
+        du = torch.empty_like(u)
+        _lib.call('ltu_gelu_dropout_bwd', _p(g), _p(u), _p(du), u.numel(), float(p), seed, _dt(u), _s())
+        return du, None, None
+
+
+def gelu_dropout(u, p=0.0, seed=0):
+    return _GeluDropout.apply(u, p, seed)
+
+
+# ---------------------------------------------------------------------------------------------- linear attention
+
+class _LinAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, B, N, d):
+        _chk(qkv, 'qkv')
+        H = d // 32
+        dev = qkv.device
+        nsplit = _lib.load().ltu_linattn_splits(B, N)
+        out = torch.empty((B * N, d), device=dev, dtype=qkv.dtype)
+        cx = torch.empty((B * H, 32, 32), device=dev, dtype=torch.float32)
+        colstats = torch.empty((B * H, 64), device=dev, dtype=torch.float32)
+        qstat = torch.empty((B * N, H, 2), device=dev, dtype=torch.float32)
+        ws = torch.empty(B * nsplit * H * 1088, device=dev, dtype=torch.float32)
+        _lib.call('ltu_linattn_fwd', _p(qkv), _p(out), _p(cx), _p(colstats), _p(qstat), _p(ws), B, N, d, _dt(qkv), _s())
+        ctx.save_for_backward(qkv, cx, colstats, qstat)
+        ctx.cfg = (B, N, d, nsplit)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, cx, colstats, qstat = ctx.saved_tensors
+        B, N, d, nsplit = ctx.cfg
+        H = d // 32
+        g = g.contiguous()
+        dev = qkv.device
+        dqkv = torch.empty_like(qkv)
+        dctx = torch.empty_like(cx)
+        tvec = torch.empty((B * H, 32), device=dev, dtype=torch.float32)
+        ws = torch.empty(B * nsplit * H * 1088, device=dev, dtype=torch.float32)
+        _lib.call('ltu_linattn_bwd', _p(qkv), _p(g), _p(cx), _p(colstats), _p(qstat), _p(dqkv), _p(dctx), _p(tvec), _p(ws),
+                  B, N, d, _dt(qkv), _s())
+        return dqkv, None, None, None
+
+
+def linear_attention(qkv, B, N, d):
+    """qkv [B*N, 3d] (q|k|v, 32-wide heads) -> attention output [B*N, d]."""
+    return _LinAttn.apply(qkv, B, N, d)
+
+
+# ---------------------------------------------------------------------------------------------- stencils / resampling
+
+class _PosConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, p, seed):
+        _chk(x, 'x')
+        B, H, W, D, C = x.shape
+        y = torch.empty_like(x)
+        _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, float(p), seed, _dt(x), _s())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        p, seed = ctx.cfg
+        g = g.contiguous()
+        B, H, W, D, C = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(C, device=x.device, dtype=torch.float32)
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, _dt(x), _s())
+        return dx, dw, db, None, None
+
+
+def pos_conv(x, w, b, p=0.0, seed=0):
+    """chan_dropout(x + depthwise3x3x3(x) + b) on channels-last x; w [C,1,3,3,3] in the reference's (D,H,W) kernel order."""
+    return _PosConv.apply(x, w, b, p, seed)
+
+
+class _Trilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sd):
+        _chk(x, 'x')
+        B, H, W, D, C = x.shape
+        y = torch.empty((B, 2 * H, 2 * W, sd * D, C), device=x.device, dtype=x.dtype)
+        _lib.call('ltu_trilinear_up', _p(x), _p(y), 0, B, H, W, D, C, sd, _dt(x), _s())
+        ctx.cfg = (B, H, W, D, C, sd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, D, C, sd = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty((B, H, W, D, C), device=g.device, dtype=g.dtype)
+        _lib.call('ltu_trilinear_up', _p(g), _p(dx), 1, B, H, W, D, C, sd, _dt(g), _s())
+        return dx, None
+
+
+def trilinear_up(x, sd):
+    """Trilinear x(2,2,sd) upsampling, align_corners=True."""
+    return _Trilinear.apply(x, sd)
+
+
+class _RoiResample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, which):
+        _chk(x, 'x')
+        B, C = x.shape[0], x.shape[-1]
+        D = x.shape[3]
+        if which == 0:
+            shape = (B, plan.eval_h, plan.eval_w, D, C)
+        else:
+            shape = (B, plan.H, plan.W, D, C)
+        y = torch.empty(shape, device=x.device, dtype=x.dtype)
+        _lib.call('ltu_roi_resample', _p(x), _p(y), _p(plan.ibuf), _p(plan.fbuf), which, 0, B, plan.H, plan.W, D, C,
+                  plan.roi_size, _dt(x), _s())
+        ctx.plan, ctx.which, ctx.in_shape = plan, which, tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, which = ctx.plan, ctx.which
+        g = g.contiguous()
+        B, _, _, D, C = ctx.in_shape
+        dx = torch.empty(ctx.in_shape, device=g.device, dtype=g.dtype)
+        _lib.call('ltu_roi_resample', _p(g), _p(dx), _p(plan.ibuf), _p(plan.fbuf), which, 1, B, plan.H, plan.W, D, C,
+                  plan.roi_size, _dt(g), _s())
+        return dx, None, None
+
+
+def roi_warp(x, plan):
+    """image lattice -> fixed ROI grid (roi_alignment2)."""
+    return _RoiResample.apply(x, plan, 0)
+
+
+def roi_unwarp(x, plan):
+    """ROI grid -> image lattice (post_processing2)."""
+    return _RoiResample.apply(x, plan, 1)
+
+
+# ---------------------------------------------------------------------------------------------- heads
+
+class _HeadSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, C):
+        _chk(z, 'z')
+        CP = z.shape[-1]
+        M = z.numel() // CP
+        p = torch.empty(z.shape[:-1] + (C,), device=z.device, dtype=torch.float32)
+        _lib.call('ltu_head_softmax_fwd', _p(z), _p(p), M, C, CP, _dt(z), _s())
+        ctx.save_for_backward(p)
+        ctx.cfg = (C, CP, z.dtype)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        C, CP, zdt = ctx.cfg
+        g = g.contiguous()
+        dz = torch.empty(p.shape[:-1] + (CP,), device=p.device, dtype=zdt)
+        _lib.call('ltu_head_softmax_bwd', _p(g), _p(p), _p(dz), p.numel() // C, C, CP, _dt(dz), _s())
+        return dz, None
+
+
+def head_softmax(z, C):
+    """class softmax over the first C of the (padded) channels of z -> fp32 probabilities [..., C]."""
+    return _HeadSoftmax.apply(z, C)
+
+
+class _FinalSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, C):
+        _chk(z, 'z')
+        B, h, w, D, _ = z.shape
+        p = torch.empty((B, 2 * h, 2 * w, D, C), device=z.device, dtype=torch.float32)
+        _lib.call('ltu_final_softmax_fwd', _p(z), _p(p), B, h, w, D, C, _dt(z), _s())
+        ctx.save_for_backward(p)
+        ctx.cfg = (B, h, w, D, C, z.dtype)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        B, h, w, D, C, zdt = ctx.cfg
+        g = g.contiguous()
+        dz = torch.empty((B, h, w, D, 4 * C), device=p.device, dtype=zdt)
+        _lib.call('ltu_final_softmax_bwd', _p(g), _p(p), _p(dz), B, h, w, D, C, _dt(dz), _s())
+        return dz, None
+
+
+def final_softmax(z, C):
+    """window un-embedding + class softmax: z [B,h,w,D,4C] -> fp32 probabilities [B,2h,2w,D,C]."""
+    return _FinalSoftmax.apply(z, C)
+
+
+class _Gate(torch.autograd.Function):
+    """skip * sigmoid(psi . relu(IN(Wx skip) + IN(Wg up)) + b)   (model/Unet_3Dblock.py:217-221, 1385)."""
+
+    @staticmethod
+    def forward(ctx, skip, up, wx, bx, wg, bg, pw, pb):
+        _chk(skip, 'skip'); _chk(up, 'up')
+        B, C = skip.shape[0], skip.shape[-1]
+        Cg = up.shape[-1]
+        M = skip.numel() // C
+        S = M // B
+        dev, dt = skip.device, _dt(skip)
+        u1 = torch.empty((M, C), device=dev, dtype=skip.dtype)
+        u2 = torch.empty((M, C), device=dev, dtype=skip.dtype)
+        _lib.call('ltu_linear_fwd', _p(skip), C, _ptr_array([wx]), 1, _ptr_array([bx]), _p(u1), C, M, C, C, 0, dt, _s())
+        _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([wg]), 1, _ptr_array([bg]), _p(u2), C, M, C, Cg, 0, dt, _s())
+        s1 = torch.zeros((B, C, 3), device=dev, dtype=torch.float32)
+        s2 = torch.zeros((B, C, 3), device=dev, dtype=torch.float32)
+        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), B, S, C, dt, _s())
+        a = torch.empty(M, device=dev, dtype=torch.float32)
+        out = torch.empty_like(skip)
+        _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, dt, _s())
+        ctx.save_for_backward(skip, up, wx, wg, pw, u1, u2, s1, s2, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        skip, up, wx, wg, pw, u1, u2, s1, s2, a = ctx.saved_tensors
+        g = g.contiguous()
+        B, C = skip.shape[0], skip.shape[-1]
+        Cg = up.shape[-1]
+        M = skip.numel() // C
+        S = M // B
+        dev, dt = skip.device, _dt(skip)
+        dskip = torch.empty_like(skip)
+        ds = torch.empty(M, device=dev, dtype=torch.float32)
+        dpw = torch.zeros_like(pw)
+        dpb = torch.zeros(1, device=dev, dtype=torch.float32)
+        bs1 = torch.zeros((B, C, 2), device=dev, dtype=torch.float32)
+        bs2 = torch.zeros((B, C, 2), device=dev, dtype=torch.float32)
+        du1 = torch.empty_like(u1)
+        du2 = torch.empty_like(u2)
+        _lib.call('ltu_gate_bwd', _p(g), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
+                  _p(dpb), _p(bs1), _p(bs2), _p(du1), _p(du2), B, S, C, dt, _s())
+        # through the two 1x1x1 convs
+        wxt = torch.empty((C, C), device=dev, dtype=torch.float32)
+        wgt = torch.empty((Cg, C), device=dev, dtype=torch.float32)
+        _lib.call('ltu_transpose_f32', _p(wx), _p(wxt), C, C, C, 0, _s())
+        _lib.call('ltu_transpose_f32', _p(wg), _p(wgt), C, Cg, C, 0, _s())
+        dup = torch.empty_like(up)
+        # dskip += du1 . Wx  (accumulating epilogue), dup = du2 . Wg
+        _lib.call('ltu_linear_fwd', _p(du1), C, _ptr_array([wxt]), 1, _ptr_array([None]), _p(dskip), C, M, C, C, 1, dt, _s())
+        _lib.call('ltu_linear_fwd', _p(du2), C, _ptr_array([wgt]), 1, _ptr_array([None]), _p(dup), Cg, M, Cg, C, 0, dt, _s())
+        dwx = torch.zeros_like(wx); dbx = torch.zeros(C, device=dev, dtype=torch.float32)
+        dwg = torch.zeros_like(wg); dbg = torch.zeros(C, device=dev, dtype=torch.float32)
+        _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _p(dwx), _p(dbx), M, C, C, dt, _s())
+        _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _p(dwg), _p(dbg), M, C, Cg, dt, _s())
+        return dskip, dup, dwx, dbx, dwg, dbg, dpw, dpb
+
+
+def attention_gate(skip, up, wx, bx, wg, bg, pw, pb):
+    return _Gate.apply(skip, up, wx, bx, wg, bg, pw, pb)
+
+
+# ---------------------------------------------------------------------------------------------- loss
+
+class _LevelLoss(torch.autograd.Function):
+    """Weighted sum of the losses of one decoder level; returns (total, values[1+2+C]) with values detached."""
+
+    @staticmethod
+    def forward(ctx, p, label, w_ce, w_bal, w_dice):
+        _chk(p, 'p'); _chk(label, 'label')
+        B, C = p.shape[0], p.shape[-1]
+        S = p.numel() // (B * C)
+        dev = p.device
+        sums = torch.zeros((B, C, 4), device=dev, dtype=torch.float32)
+        values = torch.zeros(8, device=dev, dtype=torch.float32)
+        coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
+        wd = (ctypes.c_float * 4)(*[float(w_dice[c]) if c < len(w_dice) else 0.0 for c in range(4)])
+        _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _s())
+        ctx.save_for_backward(p, label, coef)
+        ctx.mark_non_differentiable(values)
+        return values[0].clone(), values
+
+    @staticmethod
+    def backward(ctx, g, _gv):
+        p, label, coef = ctx.saved_tensors
+        B, C = p.shape[0], p.shape[-1]
+        S = p.numel() // (B * C)
+        g = g.contiguous().to(torch.float32)
+        dp = torch.empty_like(p)
+        _lib.call('ltu_loss_bwd', _p(p), _p(label), _p(coef), _p(g), _p(dp), B, S, C, _s())
+        return dp, None, None, None, None
+
+
+def level_loss(p, label, w_ce=0.0, w_bal=0.0, w_dice=()):
+    """p fp32 [B,...,C] channels-last probabilities, label uint8 [B,...]: weighted CE + balanced Dice + per-class Dice."""
+    return _LevelLoss.apply(p, label, w_ce, w_bal, tuple(w_dice))

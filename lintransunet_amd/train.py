@@ -1,0 +1,168 @@
+"""The inner training step (utils/utils_3D_embed_full.py:55-91) and its data-parallel form.
+
+One process per GPU.  The batch is sharded over ranks; every normalisation, ROI box, softmax-over-tokens
+and loss term of this network is per-sample, so averaging the per-rank gradients reproduces the
+full-batch gradient of the reference's nn.DataParallel step.  The only exchange is
+one bucketed all-reduce of the gradients over RCCL/xGMI (gloo on CPU tests), launched bucket by bucket
+from autograd hooks so that it overlaps the rest of backward.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .losses import LevelCriterion
+
+
+def get_weight(t, T, default_weight=0.2, initial_weight=1.0, final_weight=1.0):
+    """utils/utils_3D_embed_full.py:16-19"""
+    t = max(t, 0)
+    return min(initial_weight + default_weight * math.exp(t / (5 * T)), final_weight)
+
+
+def get_dynamic_weight(epochs, T=12, warmup_step=10, weight_list=(0.05, 0.05, 0.1, 0.1, 1.0),
+                       initial_weight=(0.1, 0.2, 0.3, 0.4, 1.0), final_weight=(2., 1.5, 1.0, 1., 1.0)):
+    """train3D.py:122-137: list over epochs of per-level weight tuples"""
+    cols = [[get_weight(j - warmup_step, T, weight_list[i], initial_weight[i], final_weight[i]) for j in range(epochs)]
+            for i in range(len(weight_list))]
+    return list(zip(*cols))
+
+
+def level_specs(n_levels=5, criterion_list=('CrossEntroLoss', 'DiceClassLoss'), criterion_weight=None):
+    """train3D.py:139-155 (single class: coarse levels CE+BalanceDice, two finest CE+DiceClass);
+    with `criterion_weight` the multi-class weighting of utils/utils_3D_multi_class.py:85-102 applies."""
+    cw = criterion_weight or [1.0] * len(criterion_list)
+    final = {n: w for n, w in zip(criterion_list, cw)}
+    if criterion_weight is not None:      # multi-class script: the same list at every level
+        return [dict(final) for _ in range(n_levels)]
+    specs = []
+    for i in range(n_levels):
+        if i < n_levels - 2:
+            specs.append({'CrossEntroLoss': 1.0, 'BalanceDiceLoss': 1.0})
+        elif i == n_levels - 2:
+            specs.append({'CrossEntroLoss': 1.0, 'DiceClassLoss': 1.0})
+        else:
+            specs.append(final)
+    return specs
+
+
+def label_pyramid(label, n_levels=5):
+    """uint8 [B,1,H,W,D] -> labels of level 0..n-1 (utils/utils_3D_embed_full.py:64,73-76)"""
+    lab = label.reshape(label.shape[0], *label.shape[2:]).to(torch.uint8).contiguous()
+    out = [lab]
+    cur = ops.label_maxpool(lab, 1)
+    for lvl in range(1, n_levels):
+        out.append(cur)
+        if lvl < n_levels - 1:
+            cur = ops.label_maxpool(cur, 2 if lvl % 2 == 0 else 1)
+    return out
+
+
+def deep_supervision_loss(predict, masks, label, weights, specs=None, scale=1.0):
+    """Per-level fused losses (utils/utils_3D_embed_full.py:66-82).  Returns (list of weighted level totals,
+    list of {name: value}); `sum(totals)` is the reference's total_loss * scale."""
+    n = len(weights)
+    specs = specs or level_specs(n)
+    pyr = label_pyramid(label, n)
+    totals, named = [], []
+    for lvl in range(n):
+        pred = predict if lvl == 0 else masks[-lvl]
+        crit = LevelCriterion(specs[-lvl - 1], scale=weights[lvl] * scale)
+        tot, vals = crit(pred, pyr[lvl].unsqueeze(1))
+        totals.append(tot)
+        named.append(vals)
+    return totals, named
+
+
+def train_step(model, images, labels, weights, step_times=1, specs=None, reducer=None):
+    """forward + 5-level loss + backward for one batch of patches (one `j` of utils_3D_embed_full.py:55-86).
+    Returns the list of weighted level losses (device scalars, no host sync)."""
+    predict, masks = model(images)
+    totals, named = deep_supervision_loss(predict, masks, labels, weights, specs, scale=1.0 / step_times)
+    if reducer is not None:
+        reducer.prepare()
+    torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    if reducer is not None:
+        reducer.finish()
+    return totals, named
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce (mean over ranks) overlapped with backward.
+
+    Parameters are bucketed in reverse registration order (decoder tail first = the order in which
+    backward produces gradients).  Each parameter's `.grad` is a view into its bucket's flat buffer; a
+    post-accumulate hook counts arrivals and launches `all_reduce(async_op=True)` when a bucket is full.
+    Parameters that never receive a gradient (the 14 unused pos_encoders tensors) are left out.
+    """
+
+    def __init__(self, model, bucket_mb=16.0, unused=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        unused = set(unused or [])
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and n not in unused]
+        named.reverse()
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets, cur, cur_n = [], [], 0
+        for n, p in named:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.pending, self.handles = [], [], []
+        self.bucket_of = {}
+        for bi, params in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+            off = 0
+            for p in params:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.bucket_of[p] = bi
+                p.register_post_accumulate_grad_hook(self._hook)
+            self.flat.append(flat)
+        self.pending = [0] * len(self.buckets)
+        self.active = False
+
+    def zero_grad(self):
+        for f in self.flat:
+            f.zero_()
+
+    def prepare(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.handles = []
+        self.active = True
+
+    def _hook(self, p):
+        if not self.active:
+            return
+        bi = self.bucket_of[p]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0 and self.world > 1:
+            self.handles.append((bi, dist.all_reduce(self.flat[bi], group=self.group, async_op=True)))
+
+    def finish(self):
+        self.active = False
+        if self.world > 1:
+            launched = {bi for bi, _ in self.handles}
+            for bi in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
+                if bi not in launched:
+                    self.handles.append((bi, dist.all_reduce(self.flat[bi], group=self.group, async_op=True)))
+            for bi, h in self.handles:
+                h.wait()
+                self.flat[bi].div_(self.world)
+        self.handles = []
+
+
+UNUSED_PARAMETERS = tuple(f'decode.bridge_list.4.transformer.pos_encoders.{n}.proj.{k}'
+                          for n in range(1, 8) for k in ('weight', 'bias'))
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """one-time parameter sync from rank `src` (replaces DataParallel's per-step replicate)"""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, src, group=group)

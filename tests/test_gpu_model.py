@@ -1,0 +1,130 @@
+"""GPU parity of the whole MaskTransUnet step against the vectors produced by the reference itself
+(tests/golden/make_golden.py).  Gates: fp32 storage: max|diff|/max|ref| <= 1e-3 on the output
+and every mask, |dDice| <= 1e-4, boxes bit-exact, gradient norms within 1e-2 relative (fp32 atomics / summation order);
+bf16 storage: Dice gate only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import net as O_net          # noqa: E402
+from oracle import seedgen               # noqa: E402
+from oracle import step as O_step        # noqa: E402
+
+DEV = 'cuda'
+SMALL = dict(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def build(cfg, wseed, dtype=torch.float32, dropout=0.0):
+    from lintransunet_amd.model import get_model_dict
+    model = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, cfg.dim_input, cfg.dim_output,
+                                            dropout=dropout, act_dtype=dtype)
+    model.load_state_dict(seedgen.seeded_params(O_net.param_shapes(cfg), wseed), strict=True)
+    return model.to(DEV).train()
+
+
+def run(cfg, size, batch, wseed, dtype=torch.float32):
+    from lintransunet_amd import train
+    model = build(cfg, wseed, dtype)
+    x = seedgen.seeded_volume((batch, 1) + size, wseed + 1).to(DEV)
+    label = seedgen.seeded_label((batch, 1) + size, wseed + 2).to(DEV)
+    predict, masks = model(x)
+    totals, named = train.deep_supervision_loss(predict, masks, label, O_step.dynamic_weights(0))
+    torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    torch.cuda.synchronize()
+    return model, x, label, predict, masks, totals, named
+
+
+def test_model_small_fp32(golden_dir):
+    G = np.load(os.path.join(golden_dir, 'model_small.npz'))
+    cfg = O_net.NetConfig(**SMALL)
+    model, x, label, predict, masks, totals, named = run(cfg, (32, 32, 32), 2, 100)
+    assert predict.shape == (2, 2, 32, 32, 32)
+    for i, b in enumerate(model.last_boxes):
+        assert torch.equal(b.cpu(), torch.from_numpy(G[f'box{i}'])), f'box{i}'
+    assert rel_err(predict, G['out']) <= 1e-3
+    for i, m in enumerate(masks):
+        assert rel_err(m, G[f'mask{i}']) <= 1e-3, f'mask{i}'
+    total = sum(t.item() for t in totals)
+    assert abs(total - float(G['total'])) <= 1e-4 * max(1.0, abs(float(G['total'])))
+    lv = G['level_losses']
+    for lvl, vals in enumerate(named):
+        got = [v.item() for v in vals.values()]
+        assert np.allclose(got, lv[lvl], rtol=1e-4, atol=1e-5), (lvl, got, lv[lvl])
+    from lintransunet_amd import losses as L
+    dice = L.DiceClassLoss()(predict.detach(), label).item()
+    assert abs(dice - float(G['dice'])) <= 1e-4
+    norms = dict(zip(G['grad_keys'], G['grad_norms']))
+    sd = dict(model.named_parameters())
+    worst = 0.0
+    for k, n in norms.items():
+        got = sd[k].grad.double().norm().item()
+        worst = max(worst, abs(got - n) / max(n, 1e-3))
+    assert worst <= 1e-2, worst
+    for k in G['nograd_keys']:
+        assert sd[str(k)].grad is None
+    for k in G.files:
+        if k.startswith('grad::'):
+            assert rel_err(sd[k[6:]].grad, G[k]) <= 5e-3, k
+    model.eval()
+    with torch.no_grad():
+        onehot = model(x)
+    assert onehot.shape == predict.shape
+    assert abs(int(onehot[:, 1].sum().item()) - int(G['onehot_fg_count'])) <= 2
+
+
+@pytest.mark.parametrize('tag,cfgkw,size,wseed', [('small_wide', SMALL, (64, 96, 16), 200), ('full32', {}, (32, 32, 32), 300)])
+def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, wseed):
+    G = np.load(os.path.join(golden_dir, f'model_{tag}.npz'))
+    cfg = O_net.NetConfig(**cfgkw)
+    model, x, label, predict, masks, totals, named = run(cfg, size, 1, wseed)
+    for i, b in enumerate(model.last_boxes):
+        assert torch.equal(b.cpu(), torch.from_numpy(G[f'box{i}'])), f'box{i}'
+    flat = predict.detach().cpu().flatten()
+    assert rel_err(flat[torch.from_numpy(G['out_idx'])], G['out_sample']) <= 1e-3
+    total = sum(t.item() for t in totals)
+    assert abs(total - float(G['total'])) <= 1e-4 * max(1.0, abs(float(G['total'])))
+    from lintransunet_amd import losses as L
+    assert abs(L.DiceClassLoss()(predict.detach(), label).item() - float(G['dice'])) <= 1e-4
+    norms = dict(zip(G['grad_keys'], G['grad_norms']))
+    sd = dict(model.named_parameters())
+    worst = max(abs(sd[k].grad.double().norm().item() - n) / max(n, 1e-3) for k, n in norms.items())
+    assert worst <= 1e-2, worst
+
+
+def test_model_small_bf16_dice(golden_dir):
+    """bf16 activation storage: Dice gate only (the reference's own bf16-vs-fp32 forward differs by 1.4e-2 rel-L2)"""
+    G = np.load(os.path.join(golden_dir, 'model_small.npz'))
+    cfg = O_net.NetConfig(**SMALL)
+    model, x, label, predict, masks, totals, named = run(cfg, (32, 32, 32), 2, 100, torch.bfloat16)
+    from lintransunet_amd import losses as L
+    dice = L.DiceClassLoss()(predict.detach(), label).item()
+    assert abs(dice - float(G['dice'])) <= 2e-3
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_dropout_training_runs():
+    """p = 0.3 (the reference default): finite loss/grads, different masks on consecutive steps"""
+    from lintransunet_amd import train
+    cfg = O_net.NetConfig(**SMALL)
+    model = build(cfg, 100, dropout=0.3)
+    x = seedgen.seeded_volume((1, 1, 32, 32, 32), 1).to(DEV)
+    label = seedgen.seeded_label((1, 1, 32, 32, 32), 2).to(DEV)
+    t1, _ = train.train_step(model, x, label, O_step.dynamic_weights(0))
+    t2, _ = train.train_step(model, x, label, O_step.dynamic_weights(0))
+    a, b = sum(t.item() for t in t1), sum(t.item() for t in t2)
+    assert np.isfinite(a) and np.isfinite(b) and a != b
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()

@@ -1,0 +1,444 @@
+"""GPU parity tests, kernel by kernel: every C-ABI op (through its autograd wrapper) against the CPU oracle /
+plain torch fp32 on the same seeded inputs, forward and backward.  Tolerances are stated per test:
+fp32 storage 1e-4..1e-3 relative to the tensor's max (fp32 accumulation order differs), bf16 storage 2e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as O_loss          # noqa: E402
+from oracle import net as O_net              # noqa: E402
+from oracle import roi as O_roi              # noqa: E402
+from oracle import seedgen                   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from lintransunet_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+DEV = 'cuda'
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def to_cl(t, dtype=torch.float32):
+    """reference layout [B,C,H,W,D] (cpu) -> channels-last cuda tensor [B,H,W,D,C]"""
+    return t.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+
+
+def from_cl(t):
+    return t.detach().float().cpu().permute(0, 4, 1, 2, 3)
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------- linear
+@pytest.mark.parametrize('M,K,N,nw', [(300, 64, 96, 3), (1000, 128, 128, 1), (77, 32, 32, 1), (513, 256, 768, 3), (130, 64, 32, 1)])
+def test_linear(ops, M, K, N, nw):
+    g = G(1)
+    x = torch.randn(M, K, generator=g)
+    ws = [torch.randn(N // nw, K, generator=g) * 0.1 for _ in range(nw)]
+    bs = [torch.randn(N // nw, generator=g) for _ in range(nw)]
+    go = torch.randn(M, N, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    yr = F.linear(xr, torch.cat(wr), torch.cat(br))
+    yr.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    bd = [b.to(DEV).requires_grad_(True) for b in bs]
+    yd = ops.linear(xd, wd, bd)
+    yd.backward(go.to(DEV))
+    assert rel_err(yd, yr) < 1e-4
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    for a, b in zip(wd, wr):
+        assert rel_err(a.grad, b.grad) < 1e-4
+    for a, b in zip(bd, br):
+        assert rel_err(a.grad, b.grad) < 1e-4
+
+
+def test_linear_bf16(ops):
+    g = G(2)
+    x = torch.randn(400, 128, generator=g)
+    w = torch.randn(64, 128, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    yr = F.linear(x.bfloat16().float(), w, b)
+    yd = ops.linear(x.to(DEV, torch.bfloat16), [w.to(DEV)], [b.to(DEV)])
+    assert yd.dtype == torch.bfloat16
+    assert rel_err(yd, yr) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------- conv3d
+CONV_CASES = [
+    # B, Ci, Co, H, W, D, stride, C1, ups, cop
+    (2, 8, 16, 6, 5, 8, (1, 1, 1), 0, False, None),
+    (1, 16, 32, 8, 8, 6, (2, 2, 1), 0, False, None),
+    (2, 8, 8, 7, 6, 5, (2, 2, 2), 0, False, None),
+    (1, 8, 16, 6, 6, 4, (1, 1, 1), 8, False, None),      # virtual concat
+    (1, 16, 8, 3, 4, 2, (1, 1, 1), 0, True, None),       # fused nearest x2 upsampling
+    (1, 32, 2, 5, 4, 6, (1, 1, 1), 0, False, 4),         # padded mask head
+    (1, 64, 128, 4, 4, 4, (1, 1, 1), 0, False, None),    # wide tiles
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv3d(ops, case):
+    B, Ci, Co, H, W, D, stride, C1, ups, cop = case
+    g = G(3)
+    x0 = torch.randn(B, Ci, H, W, D, generator=g)
+    x1 = torch.randn(B, C1, H, W, D, generator=g) if C1 else None
+    w = torch.randn(Co, Ci + C1, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    x0r = x0.clone().requires_grad_(True)
+    x1r = x1.clone().requires_grad_(True) if C1 else None
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = x0r if not C1 else torch.cat((x0r, x1r), 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2)
+    yr = F.conv3d(xin, wr, br, stride=stride, padding=1)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+
+    x0d = to_cl(x0).requires_grad_(True)
+    x1d = to_cl(x1).requires_grad_(True) if C1 else None
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.conv3d(x0d, wd, bd, stride=stride, x1=x1d, ups=ups, cop=cop)
+    god = to_cl(go)
+    if cop:
+        assert yd.shape[-1] == cop
+        pad = torch.zeros(yd.shape, device=DEV)
+        pad[..., :Co] = god
+        god = pad
+        assert yd[..., Co:].abs().max().item() == 0
+    yd.backward(god)
+    assert rel_err(from_cl(yd)[:, :Co], yr) < 1e-4
+    assert rel_err(from_cl(x0d.grad), x0r.grad) < 1e-4
+    if C1:
+        assert rel_err(from_cl(x1d.grad), x1r.grad) < 1e-4
+    assert rel_err(wd.grad, wr.grad) < 1e-4
+    assert rel_err(bd.grad, br.grad) < 1e-4
+
+
+def test_conv3d_stem_padding(ops):
+    """stem: 4 real input channels carried in an 8-channel tensor (window embedding)"""
+    g = G(4)
+    x = torch.randn(2, 1, 12, 8, 6, generator=g)
+    w = torch.randn(16, 4, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(16, generator=g)
+    yr = F.conv3d(O_net.window_embed(x), w, b, padding=1)
+    e = ops.window_embed(x.to(DEV), torch.float32)
+    assert e.shape == (2, 6, 4, 6, 8)
+    assert rel_err(from_cl(e)[:, :4], O_net.window_embed(x)) == 0
+    yd = ops.conv3d(e, w.to(DEV), b.to(DEV))
+    assert rel_err(from_cl(yd), yr) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize('C,with_res', [(8, True), (32, False), (128, True), (256, False)])
+def test_instnorm_act(ops, C, with_res):
+    g = G(5)
+    x = torch.randn(2, C, 5, 6, 7, generator=g) * 3 + 1.5
+    r = torch.randn(2, C, 5, 6, 7, generator=g) if with_res else None
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if with_res else None
+    yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.01)
+    if with_res:
+        yr = yr + rr
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    xd = to_cl(x).requires_grad_(True)
+    rd = to_cl(r).requires_grad_(True) if with_res else None
+    yd = ops.instnorm_act(xd, rd)
+    yd.backward(to_cl(go))
+    assert rel_err(from_cl(yd), yr) < 1e-4
+    assert rel_err(from_cl(xd.grad), xr.grad) < 2e-4
+    if with_res:
+        assert rel_err(from_cl(rd.grad), rr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('d', [32, 64, 128, 256])
+def test_res_layernorm(ops, d):
+    g = G(6)
+    M = 333
+    x, r = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    go = torch.randn(M, d, generator=g)
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr = F.layer_norm(xr + rr, (d,), gr, br, 1e-6)
+    yr.backward(go)
+    xd, rd = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    gd, bd = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+    yd = ops.res_layernorm(xd, rd, gd, bd)
+    yd.backward(go.to(DEV))
+    assert rel_err(yd, yr) < 1e-4
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    assert rel_err(rd.grad, rr.grad) < 1e-4
+    assert rel_err(gd.grad, gr.grad) < 1e-4
+    assert rel_err(bd.grad, br.grad) < 1e-4
+
+
+def test_gelu(ops):
+    g = G(7)
+    u = torch.randn(100, 64, generator=g) * 2
+    go = torch.randn(100, 64, generator=g)
+    ur = u.clone().requires_grad_(True)
+    F.gelu(ur).backward(go)
+    ud = u.to(DEV).requires_grad_(True)
+    hd = ops.gelu_dropout(ud)
+    hd.backward(go.to(DEV))
+    assert rel_err(hd, F.gelu(u)) < 1e-5
+    assert rel_err(ud.grad, ur.grad) < 1e-5
+
+
+def test_dropout_masks(ops):
+    """Philox dropout: keep rate, 1/(1-p) scaling, and the backward regenerates exactly the forward mask"""
+    n = 1 << 18
+    u = torch.ones(n // 64, 64, device=DEV).requires_grad_(True)
+    h = ops.gelu_dropout(u, 0.3, 12345)
+    val = F.gelu(torch.ones(1)).item() / 0.7
+    kept = h.detach() != 0
+    assert abs(kept.float().mean().item() - 0.7) < 5e-3
+    assert torch.allclose(h.detach()[kept], torch.full((1,), val, device=DEV), rtol=1e-5)
+    h.sum().backward()
+    assert torch.equal(u.grad != 0, kept)
+    h2 = ops.gelu_dropout(u.detach(), 0.3, 12346)
+    assert (kept != (h2 != 0)).float().mean().item() > 0.3        # another seed, another mask
+    x = torch.randn(2, 4, 4, 4, 32, device=DEV).requires_grad_(True)
+    y = ops.instnorm_act(x, None, 1, 0.3, 777)
+    keep = (y.detach() != 0)
+    y.backward(torch.ones_like(y))
+    # IN backward mixes voxels, so test the mask through a second call instead
+    y2 = ops.instnorm_act(x.detach(), None, 1, 0.3, 777)
+    assert torch.equal(y2 != 0, keep)
+
+
+# ---------------------------------------------------------------------------------------------- linear attention
+def _qkv_pack(q, k, v):
+    B, h, N, dk = q.shape
+    f = lambda t: t.transpose(1, 2).reshape(B * N, h * dk)
+    return torch.cat((f(q), f(k), f(v)), dim=1).contiguous()
+
+
+@pytest.mark.parametrize('tag', list(seedgen.LINATTN_CASES))
+def test_linattn_golden(ops, golden_dir, tag):
+    Gd = np.load(os.path.join(golden_dir, 'linattn.npz'))
+    q, k, v, go = seedgen.linattn_case(tag)
+    B, h, N, dk = q.shape
+    d = h * dk
+    qkv = _qkv_pack(q, k, v).to(DEV).requires_grad_(True)
+    out = ops.linear_attention(qkv, B, N, d)
+    out.backward(go.transpose(1, 2).reshape(B * N, d).to(DEV))
+    ref = torch.from_numpy(Gd[f'{tag}_out']).transpose(1, 2).reshape(B * N, d)
+    assert rel_err(out, ref) < 1e-4
+    dref = _qkv_pack(*(torch.from_numpy(Gd[f'{tag}_d{n}']) for n in 'qkv'))
+    assert rel_err(qkv.grad[:, :d], dref[:, :d]) < 2e-4
+    assert rel_err(qkv.grad[:, d:2 * d], dref[:, d:2 * d]) < 2e-4
+    assert rel_err(qkv.grad[:, 2 * d:], dref[:, 2 * d:]) < 2e-4
+
+
+@pytest.mark.parametrize('B,h,N', [(2, 1, 40), (1, 2, 1000), (2, 4, 4097), (1, 8, 2500)])
+def test_linattn_sizes(ops, B, h, N):
+    g = G(8)
+    q, k, v, go = (torch.randn(B, h, N, 32, generator=g) for _ in range(4))
+    k[:, :, N // 3] += 8.0             # late dominant token: the running max must rescale the accumulators
+    k[:, :, 0] += 4.0
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = O_net.linear_attention(qr, kr, vr)
+    ref.backward(go)
+    d = h * 32
+    qkv = _qkv_pack(q, k, v).to(DEV).requires_grad_(True)
+    out = ops.linear_attention(qkv, B, N, d)
+    out.backward(go.transpose(1, 2).reshape(B * N, d).to(DEV))
+    assert rel_err(out, ref.transpose(1, 2).reshape(B * N, d)) < 1e-4
+    dref = _qkv_pack(qr.grad, kr.grad, vr.grad)
+    for s in range(3):
+        assert rel_err(qkv.grad[:, s * d:(s + 1) * d], dref[:, s * d:(s + 1) * d]) < 3e-4
+
+
+def test_attn_layer_golden(ops, golden_dir):
+    """one whole post-norm layer (qkv GEMM, attention core, out-proj, LN, FFN, LN) vs the reference's vectors"""
+    Gd = np.load(os.path.join(golden_dir, 'attn_layer.npz'))
+    from lintransunet_amd.model import MaskTransUnet, _transformer_layer, _SeedStream
+    d, B, N = 64, 2, 40
+    lay = _transformer_layer(d)
+    P = seedgen.seeded_params({k: tuple(v.shape) for k, v in lay.state_dict().items()}, seed=21)
+    lay.load_state_dict(P)
+    lay = lay.to(DEV)
+    x = seedgen.seeded_volume((B, N, d), 22).to(DEV).requires_grad_(True)
+    go = seedgen.seeded_volume((B, N, d), 23).to(DEV)
+    y = MaskTransUnet._layer(None, lay, x.view(B * N, d), B, N, d, 0.0, _SeedStream(0))
+    y.backward(go.view(B * N, d))
+    assert rel_err(y.view(B, N, d), torch.from_numpy(Gd['out'])) < 1e-4
+    assert rel_err(x.grad, torch.from_numpy(Gd['dx'])) < 5e-4
+    for k, p in lay.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(Gd['g_' + k])) < 5e-4, k
+
+
+# ---------------------------------------------------------------------------------------------- stencils / resampling
+@pytest.mark.parametrize('C', [32, 128])
+def test_pos_conv(ops, C):
+    g = G(9)
+    B, H, W, D = 2, 5, 4, 6
+    x = torch.randn(B, C, H, W, D, generator=g)
+    w = torch.randn(C, 1, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    grid = xr.permute(0, 1, 4, 2, 3)                       # the reference's [B,C,D,H,W] view
+    yr = (grid + F.conv3d(grid, wr, br, padding=1, groups=C)).permute(0, 1, 3, 4, 2)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    xd, wd, bd = to_cl(x).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.pos_conv(xd, wd, bd)
+    yd.backward(to_cl(go))
+    assert rel_err(from_cl(yd), yr) < 1e-5
+    assert rel_err(from_cl(xd.grad), xr.grad) < 1e-5
+    assert rel_err(wd.grad, wr.grad) < 1e-4
+    assert rel_err(bd.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize('sd,shape', [(2, (2, 8, 3, 4, 5)), (1, (1, 16, 4, 4, 8)), (2, (1, 8, 1, 1, 8)), (1, (1, 8, 2, 2, 16))])
+def test_trilinear(ops, sd, shape):
+    g = G(10)
+    x = torch.randn(shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=(2, 2, sd), mode='trilinear', align_corners=True)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    xd = to_cl(x).requires_grad_(True)
+    yd = ops.trilinear_up(xd, sd)
+    yd.backward(to_cl(go))
+    assert rel_err(from_cl(yd), yr) < 1e-5
+    assert rel_err(from_cl(xd.grad), xr.grad) < 1e-5
+
+
+def test_roi_golden(ops, golden_dir):
+    """box finder (bit-exact), both warps and their adjoints against the reference's vectors, all edge cases"""
+    Gd = np.load(os.path.join(golden_dir, 'roi.npz'))
+    for name in Gd['names']:
+        mask = torch.from_numpy(Gd[f'{name}_mask'])            # bool [1,1,H,W,D]
+        roi_size = int(Gd[f'{name}_roi_size'])
+        fg = mask[:, 0].float()
+        prob = torch.stack((1 - fg, fg), dim=-1).contiguous().to(DEV)      # [1,H,W,D,2]: 1 - p0 = fg
+        plan = ops.RoiPlan(prob, roi_size, 0.5)
+        assert torch.equal(plan.box.cpu(), torch.from_numpy(Gd[f'{name}_box'])), name
+        feat = torch.from_numpy(Gd[f'{name}_feat'])
+        # feature fixtures have 2 channels; the kernels work on 4-channel vectors
+        pad = lambda t: to_cl(torch.cat((t, torch.zeros_like(t)), dim=1))
+        fd = pad(feat).requires_grad_(True)
+        roi = ops.roi_warp(fd, plan)
+        assert rel_err(from_cl(roi)[:, :2], torch.from_numpy(Gd[f'{name}_roi'])) < 1e-5, name
+        roi.backward(pad(torch.from_numpy(Gd[f'{name}_groi'])))
+        assert rel_err(from_cl(fd.grad)[:, :2], torch.from_numpy(Gd[f'{name}_dfeat'])) < 1e-5, name
+        rin = pad(torch.from_numpy(Gd[f'{name}_roi_in'])).requires_grad_(True)
+        back = ops.roi_unwarp(rin, plan)
+        assert rel_err(from_cl(back)[:, :2], torch.from_numpy(Gd[f'{name}_back'])) < 1e-5, name
+        back.backward(pad(torch.from_numpy(Gd[f'{name}_gback'])))
+        assert rel_err(from_cl(rin.grad)[:, :2], torch.from_numpy(Gd[f'{name}_droi_in'])) < 1e-5, name
+
+
+# ---------------------------------------------------------------------------------------------- heads, gate, losses
+def test_softmax_heads(ops):
+    g = G(11)
+    for C in (2, 3):
+        z = torch.randn(2, 4, 3, 5, 6, generator=g) * 2           # [B,CP=4,H,W,D]
+        zr = z.clone().requires_grad_(True)
+        pr = torch.softmax(zr[:, :C], dim=1)
+        go = torch.randn(pr.shape, generator=g)
+        pr.backward(go)
+        zd = to_cl(z).requires_grad_(True)
+        pd = ops.head_softmax(zd, C)
+        pd.backward(to_cl(go))
+        assert rel_err(from_cl(pd), pr) < 1e-6
+        assert rel_err(from_cl(zd.grad), zr.grad) < 1e-5
+        zf = torch.randn(2, 4 * C, 3, 4, 5, generator=g)
+        zfr = zf.clone().requires_grad_(True)
+        pf = torch.softmax(O_net.window_unembed(zfr), dim=1)
+        gf = torch.randn(pf.shape, generator=g)
+        pf.backward(gf)
+        zfd = to_cl(zf).requires_grad_(True)
+        pfd = ops.final_softmax(zfd, C)
+        pfd.backward(to_cl(gf))
+        assert rel_err(from_cl(pfd), pf) < 1e-6
+        assert rel_err(from_cl(zfd.grad), zfr.grad) < 1e-5
+        oh = ops.onehot_argmax(pfd.detach())
+        ref = torch.zeros_like(pf.detach()).scatter_(1, pf.detach().argmax(1, keepdim=True), 1)
+        assert torch.equal(from_cl(oh), ref)
+
+
+@pytest.mark.parametrize('C,Cg', [(8, 8), (16, 32), (128, 256)])
+def test_attention_gate(ops, C, Cg):
+    g = G(12)
+    B, H, W, D = 2, 4, 3, 5
+    skip, up = torch.randn(B, C, H, W, D, generator=g), torch.randn(B, Cg, H, W, D, generator=g)
+    names = {'G.W_x.0': (C, C), 'G.W_g.0': (C, Cg), 'G.psi.0': (1, C)}
+    P = {}
+    for n, (o, i) in names.items():
+        P[n + '.weight'] = (torch.randn(o, i, 1, 1, 1, generator=g) / i ** 0.5).requires_grad_(True)
+        P[n + '.bias'] = (0.1 * torch.randn(o, generator=g)).requires_grad_(True)
+    sr, ur = skip.clone().requires_grad_(True), up.clone().requires_grad_(True)
+    outr = sr * O_net.attention_gate(P, 'G', sr, ur)
+    go = torch.randn(outr.shape, generator=g)
+    outr.backward(go)
+    Pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in P.items()}
+    sd_, ud = to_cl(skip).requires_grad_(True), to_cl(up).requires_grad_(True)
+    outd = ops.attention_gate(sd_, ud, Pd['G.W_x.0.weight'], Pd['G.W_x.0.bias'], Pd['G.W_g.0.weight'], Pd['G.W_g.0.bias'],
+                              Pd['G.psi.0.weight'], Pd['G.psi.0.bias'])
+    outd.backward(to_cl(go))
+    assert rel_err(from_cl(outd), outr) < 1e-4
+    assert rel_err(from_cl(sd_.grad), sr.grad) < 5e-4
+    assert rel_err(from_cl(ud.grad), ur.grad) < 5e-4
+    for k in P:
+        if k.endswith('bias') and 'psi' not in k:
+            continue          # bias of a conv feeding InstanceNorm: gradient is exactly 0 up to rounding
+        assert rel_err(Pd[k].grad, P[k].grad) < 1e-3, k
+
+
+def test_losses_golden(ops, golden_dir):
+    from lintransunet_amd import losses as L
+    Gd = np.load(os.path.join(golden_dir, 'losses.npz'))
+    p = torch.from_numpy(Gd['c2_p'])
+    lab = torch.from_numpy(Gd['c2_lab'])
+    for name in ('CrossEntroLoss', 'DiceClassLoss', 'BalanceDiceLoss'):
+        pd = to_cl(p).requires_grad_(True)
+        v = L.get_criterions([name])[name](pd.permute(0, 4, 1, 2, 3), lab.to(DEV))
+        v.backward()
+        assert abs(v.item() - float(Gd[f'c2_{name}'])) < 1e-5 * max(1, abs(float(Gd[f'c2_{name}']))), name
+        assert rel_err(from_cl(pd.grad), torch.from_numpy(Gd[f'c2_{name}_dp'])) < 1e-4, name
+    p3 = torch.from_numpy(Gd['c3_p'])
+    lab3 = torch.from_numpy(Gd['c3_lab'])
+    for name in ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'):
+        pd = to_cl(p3).requires_grad_(True)
+        v = L.get_criterions([name])[name](pd.permute(0, 4, 1, 2, 3), lab3.to(DEV))
+        v.backward()
+        assert abs(v.item() - float(Gd[f'c3_{name}'])) < 1e-5, name
+        assert rel_err(from_cl(pd.grad), torch.from_numpy(Gd[f'c3_{name}_dp'])) < 1e-4, name
+    # fused level criterion = weighted sum of the single losses
+    pd = to_cl(p).requires_grad_(True)
+    tot, named = L.LevelCriterion({'CrossEntroLoss': 1.0, 'BalanceDiceLoss': 1.0}, scale=0.4)(pd.permute(0, 4, 1, 2, 3), lab.to(DEV))
+    want = 0.4 * (float(Gd['c2_CrossEntroLoss']) + float(Gd['c2_BalanceDiceLoss']))
+    assert abs(tot.item() - want) < 1e-5
+
+
+def test_label_pyramid(ops):
+    from lintransunet_amd import train
+    from oracle import step as O_step
+    lab = seedgen.seeded_label((2, 1, 32, 32, 16), 5)
+    ref = O_step.label_pyramid(lab, 5)
+    got = train.label_pyramid(lab.to(DEV), 5)
+    for a, b in zip(got, ref):
+        assert torch.equal(a.cpu().float(), b[:, 0].float())

@@ -1,0 +1,120 @@
+"""CPU tests of the host side: C-ABI surface, state_dict surface, loud failure without a GPU, and the
+world-size-2 gradient reducer over gloo."""
+import os
+import re
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import net as O_net
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from lintransunet_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'ltu_hip.h')).read()
+    declared = set(re.findall(r'^int\s+(ltu_\w+)\s*\(', header, flags=re.M))
+    assert len(declared) >= 35
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ltu_version() >= 1
+    # argument counts of the binding table match the C prototypes
+    for name, args in re.findall(r'^int\s+(ltu_\w+)\s*\(([^;]*)\);', header, flags=re.M | re.S):
+        n = 0 if args.strip() == 'void' else len(args.split(','))
+        assert n == len(_lib.SIGNATURES[name]), name
+
+
+@pytest.mark.parametrize('dim_output', [2, 3])
+def test_state_dict_surface_matches_reference(dim_output):
+    from lintransunet_amd.model import get_model_dict
+    cfg = O_net.NetConfig(dim_output=dim_output)
+    model = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, dim_output)
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    want = O_net.param_shapes(cfg)
+    assert got == want
+    assert len(got) == 614
+    from oracle import seedgen
+    model.load_state_dict(seedgen.seeded_params(want, 1), strict=True)
+
+
+def test_no_cpu_fallback():
+    from lintransunet_amd.model import get_model_dict
+    from lintransunet_amd import ops, _lib
+    m = get_model_dict('MaskTransUnet')([8, 8, 8, 16, 32], [20, 12, 9, 10, 6], [False, True, True, True, True], 1, 2)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 32, 32, 32))
+    with pytest.raises(_lib.LtuError):
+        ops.linear(torch.zeros(4, 32), [torch.zeros(32, 32)], [torch.zeros(32)])
+
+
+def test_schedule_helpers():
+    from lintransunet_amd import train
+    from oracle import step as O_step
+    dw = train.get_dynamic_weight(30)
+    for e in (0, 9, 10, 29):
+        assert dw[e] == O_step.dynamic_weights(e)
+    specs = train.level_specs(5)
+    assert list(specs[0]) == ['CrossEntroLoss', 'BalanceDiceLoss'] and list(specs[3]) == ['CrossEntroLoss', 'DiceClassLoss']
+    assert len(train.UNUSED_PARAMETERS) == 14
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _reducer_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from lintransunet_amd.train import GradReducer, broadcast_parameters
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.manual_seed(rank)                      # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                              torch.nn.Linear(16, 1))
+    unused = torch.nn.Linear(3, 3)               # registered, never used in forward (like pos_encoders.1..7)
+    net.add_module('unused', unused)
+    broadcast_parameters(net)
+    red = GradReducer(net, bucket_mb=0.0005, unused=['unused.weight', 'unused.bias'])
+    assert len(red.buckets) >= 2
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 1, generator=g)
+    shard = slice(rank * 4, rank * 4 + 4)
+    for _ in range(2):                           # two steps: buffers are reused
+        red.zero_grad()
+        red.prepare()
+        loss = ((net[:5](x[shard]) - y[shard]) ** 2).mean()      # per-sample loss, mean over the shard
+        loss.backward()
+        red.finish()
+    if rank == 0:
+        ref = torch.nn.Sequential(*[m for m in list(net.children())[:5]])
+        grads = [p.grad.clone() for p in list(net.parameters())[:6]]
+        for p in ref.parameters():
+            p.grad = None
+        ((ref(x) - y) ** 2).mean().backward()
+        err = max((a - p.grad).abs().max().item() for a, p in zip(grads, ref.parameters()))
+        out.put((err, unused.weight.grad is None))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    """sharded batch + mean all-reduce == full-batch gradient; unused parameters are skipped"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, unused_none = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-6
+    assert unused_none
