@@ -18,6 +18,16 @@ DEV = 'cuda'
 SMALL = dict(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
 
 
+def exact_zero_grad(key):
+    """Parameters whose gradient is mathematically zero: the bias of a conv feeding InstanceNorm (the norm removes
+    any per-channel constant) and the key-projection bias (softmax over tokens is shift invariant).  Reference and HIP
+    path both produce rounding noise there (1e-3 .. 1e-8), so a relative comparison is meaningless."""
+    if not key.endswith('.bias'):
+        return False
+    return any(t in key for t in ('.conv1.', '.conv2.', 'input_block', 'down_embed', 'up_embed', 'W_x.0', 'W_g.0',
+                                  'self_attn.linears.1.'))
+
+
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
@@ -67,6 +77,9 @@ def test_model_small_fp32(golden_dir):
     worst = 0.0
     for k, n in norms.items():
         got = sd[k].grad.double().norm().item()
+        if exact_zero_grad(k):
+            assert got <= 1e-2, k
+            continue
         worst = max(worst, abs(got - n) / max(n, 1e-3))
     assert worst <= 1e-2, worst
     for k in G['nograd_keys']:
@@ -96,7 +109,8 @@ def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, wseed):
     assert abs(L.DiceClassLoss()(predict.detach(), label).item() - float(G['dice'])) <= 1e-4
     norms = dict(zip(G['grad_keys'], G['grad_norms']))
     sd = dict(model.named_parameters())
-    worst = max(abs(sd[k].grad.double().norm().item() - n) / max(n, 1e-3) for k, n in norms.items())
+    worst = max(abs(sd[k].grad.double().norm().item() - n) / max(n, 1e-3) for k, n in norms.items()
+                if not exact_zero_grad(k))
     assert worst <= 1e-2, worst
 
 
