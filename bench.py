@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Benchmark of the LinTransUNet hot path on MI355X: 128^3 CT patches/s, forward + 5-level loss + backward.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU, weak scaling (2 patches per GPU, BASELINE.json config 3): every rank draws its own
+synthetic patches, gradients are all-reduced (mean) over RCCL in buckets overlapped with backward.  A "step" is
+one inner training step of utils/utils_3D_embed_full.py:55-86 (dropout 0.3 as in training, no optimizer step,
+inputs resident in HBM).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per 128^3 patch, forward: Linear layers of the transformers
+LINEAR_FWD_GFLOP_128 = 251.1
+
+
+def synthetic_batch(batch, size, seed, device):
+    """N(0,1) volume clipped to the dataset's normalised HU range + ellipsoid labels."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((batch, 1) + size, generator=g).clamp_(-4.51, 4.14)
+    from oracle import seedgen       # label generator only (test infrastructure helper, not on the timed path)
+    lab = seedgen.seeded_label((batch, 1) + size, seed + 1, n_blobs=2)
+    return x.to(device), lab.to(device)
+
+
+def cpu_baseline(size=(128, 128, 128), threads=None):
+    """The oracle (CPU restatement of the reference, fp32, dropout on) timed for ONE step at B=1: a bounded sample."""
+    from oracle import net as O_net, seedgen, step as O_step
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    cfg = O_net.NetConfig(dropout=0.3)
+    P = seedgen.seeded_params(O_net.param_shapes(cfg), 7, requires_grad=True)
+    x = seedgen.seeded_volume((1, 1) + size, 8)
+    lab = seedgen.seeded_label((1, 1) + size, 9)
+    t0 = time.perf_counter()
+    O_step.train_step(P, cfg, x, lab, O_step.dynamic_weights(0))
+    dt = time.perf_counter() - t0
+    return {'value': 1.0 / dt, 'unit': 'patches/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 fwd+bwd step, {size[0]}^3 B=1, fp32, dropout 0.3, no warm-up ({dt:.1f} s)'}
+
+
+class KernelTimer:
+    """HIP-event timing of one op family on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = 0.0
+        self.on = False
+
+    def wrap(self, fn, flops_of):
+        def wrapped(*a, **k):
+            if not self.on:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            self.flops += flops_of(*a, **k)
+            return out
+        return wrapped
+
+    def result(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return ms, len(self.pairs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=128)
+    ap.add_argument('--batch', type=int, default=2, help='patches per GPU')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from lintransunet_amd.model import get_model_dict
+    from lintransunet_amd import train, ops
+
+    torch.manual_seed(1234)          # same initial weights on every rank (then broadcast for good measure)
+    act = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = get_model_dict('MaskTransUnet')([16, 32, 64, 128, 256], [100, 65, 40, 25, 10], [False, True, True, True, True],
+                                            1, 2, dropout=0.3, act_dtype=act).to(dev).train()
+    train.broadcast_parameters(model)
+    torch.manual_seed(1234 + rank)   # dropout streams differ per rank
+    reducer = train.GradReducer(model, bucket_mb=16.0, unused=train.UNUSED_PARAMETERS)
+    size = (args.size,) * 3
+    weights = train.get_dynamic_weight(1)[0]
+    batches = [synthetic_batch(args.batch, size, 100 + 10 * rank + i, dev) for i in range(2)]
+
+    # live timing of the dominant kernel family (the dense projections of the transformers)
+    timer = KernelTimer()
+    ops._Linear.forward = staticmethod(timer.wrap(ops._Linear.forward, lambda ctx, x, *wb: 2.0 * x.shape[0] * x.shape[1] *
+                                                  sum(w.shape[0] for w in wb[:len(wb) // 2])))
+
+    def step(i):
+        reducer.zero_grad()
+        x, lab = batches[i % 2]
+        return train.train_step(model, x, lab, weights, reducer=reducer)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        patches = args.batch * world * args.steps
+        ms_lin, n_lin = timer.result()
+        achieved = timer.flops / (ms_lin * 1e-3) / 1e12 if ms_lin > 0 else 0.0
+        peak = 2500.0 if args.dtype == 'bf16' else 157.3
+        out = {
+            'metric': '128^3 CT patches/sec (fwd+bwd)', 'value': patches / dt, 'unit': 'patches/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
+                                   f'{args.batch} per GPU, dropout 0.3, random-init weights', 'global_batch': args.batch * world,
+                       'patch': [args.size] * 3, 'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_nt_kernel (transformer projections, forward launches)',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1), 'traffic': None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

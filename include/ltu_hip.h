@@ -39,19 +39,22 @@ int ltu_version(void);
 int ltu_window_embed(const float* x, void* y, int dtype, int B, int H, int W, int D, ltu_stream_t s);
 
 /* ---- weight repacking (weights are tiny; done per step) ----------------------------------------
+ * GEMM weight operands are consumed in the activation dtype: these produce them from the fp32 masters.
  * conv weight [Co,Ci,3,3,3] -> wf [CoP][27][CiP] (forward / weight-gradient operand) and/or
- * wd [CiP][27][CoP] (data-gradient operand), zero padded; either output may be NULL. */
-int ltu_pack_conv_weight(const float* w, float* wf, float* wd, int Co, int Ci, int CoP, int CiP, ltu_stream_t s);
+ * wd [CiP][27][CoP] (data-gradient operand), zero padded, stored as out_dtype; either output may be NULL. */
+int ltu_pack_conv_weight(const float* w, void* wf, void* wd, int Co, int Ci, int CoP, int CiP, int out_dtype, ltu_stream_t s);
 /* gradient back to the PyTorch layout: dwf [CoP][27][CiP] -> dw [Co,Ci,3,3,3] */
 int ltu_unpack_conv_wgrad(const float* dwf, float* dw, int Co, int Ci, int CiP, ltu_stream_t s);
-/* out[c*ldo + col_off + r] = in[r*C + c]  (Linear weight for the data-gradient GEMM) */
-int ltu_transpose_f32(const float* in, float* out, int R, int C, int ldo, int col_off, ltu_stream_t s);
+/* out[c*ldo + col_off + r] = in[r*C + c], stored as out_dtype (Linear weight for the data-gradient GEMM) */
+int ltu_transpose_f32(const float* in, void* out, int R, int C, int ldo, int col_off, int out_dtype, ltu_stream_t s);
+/* out[i] = (out_dtype) in[i] */
+int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_stream_t s);
 
 /* ---- dense projections: nn.Linear (model/trans_block.py:144,156,166,187,189) and 1x1x1 convs
- *      (model/Unet_3Dblock.py:200-215).  y[M,N] (+)= a[M,K] . w[N,K]^T + bias.
+ *      (model/Unet_3Dblock.py:200-215).  y[M,N] (+)= a[M,K] . w[N,K]^T + bias;  w in the activation dtype, bias fp32.
  * Up to three weight blocks of N/nw rows each may be given (q,k,v fused: nw = 3); bias entries may
  * be NULL.  accumulate != 0 adds to y. */
-int ltu_linear_fwd(const void* a, int lda, const float* const* w, int nw, const float* const* bias, void* y, int ldy,
+int ltu_linear_fwd(const void* a, int lda, const void* const* w, int nw, const float* const* bias, void* y, int ldy,
                    int M, int N, int K, int accumulate, int dtype, ltu_stream_t s);
 /* dw[N,K] += g[M,N]^T . a[M,K];  db[N] += colsum(g).  dw/db fp32, caller zero-fills; db may be NULL. */
 int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* dw, float* db, int M, int N, int K,
@@ -62,11 +65,11 @@ int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* dw, 
  * materialising it), wf [Co][27][C0+C1], stride (sh,sw,sd) in {1,2}; ups != 0: the conv reads the
  * nearest-neighbour x2 upsampling of x0 (nn.Upsample of Unet_3Dblock.py:421), (Hi,Wi,Di) are then
  * the physical dims.  y [B,Ho,Wo,Do,Co]. */
-int ltu_conv3d_fwd(const void* x0, const void* x1, const float* wf, const float* bias, void* y, int B, int Hi, int Wi,
+int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* bias, void* y, int B, int Hi, int Wi,
                    int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype, ltu_stream_t s);
 /* data gradient: g [B,Ho,Wo,Do,Co], wd [C0+C1][27][Co] -> dx0 [B,Hl,Wl,Dl,C0] (+ dx1 [..,C1]); (Hl,Wl,Dl)
  * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
-int ltu_conv3d_dgrad(const void* g, const float* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,
+int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,
                      int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s);
 /* weight gradient into the packed layout dwf [Co][27][C0+C1] (+=, caller zero-fills), db[Co] += */
 int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi, int Wi,

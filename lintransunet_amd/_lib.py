@@ -16,9 +16,10 @@ P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_uint64
 SIGNATURES = {
     'ltu_version': [],
     'ltu_window_embed': [P, P, I, I, I, I, I, P],
-    'ltu_pack_conv_weight': [P, P, P, I, I, I, I, P],
+    'ltu_pack_conv_weight': [P, P, P, I, I, I, I, I, P],
     'ltu_unpack_conv_wgrad': [P, P, I, I, I, P],
-    'ltu_transpose_f32': [P, P, I, I, I, I, P],
+    'ltu_transpose_f32': [P, P, I, I, I, I, I, P],
+    'ltu_cast_f32': [P, P, L, I, P],
     'ltu_linear_fwd': [P, I, P, I, P, P, I, I, I, I, I, I, P],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P],
     'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],

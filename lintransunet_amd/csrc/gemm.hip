@@ -13,51 +13,7 @@
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) on fp32 LDS tiles; T only
 // selects the HBM storage type.  Waves are 64 wide: a wave owns TM x TN tiles of 32x32.
-#include "common.h"
-
-struct Tap {
-  int8_t dh, dw, dd, wt;
-};
-
-struct IGemmArgs {
-  const void* a0;
-  const void* a1;
-  const float* w[3];
-  const float* bias[3];
-  void* o0;
-  void* o1;
-  long long M;
-  int N, K;          // K = ntaps * C
-  int C, c0;         // channels per tap; channels served by a0 (rest by a1)
-  int lda0, lda1;    // voxel strides of a0 / a1 (elements)
-  int nseg;          // weight row segments (N/nseg rows each)
-  int wrow;          // weight row length = wtaps * C
-  int nb, rh, rw, rd;
-  int sh, sw, sd, ups;
-  int mh, mw, md;
-  int ntaps;
-  Tap tap[27];
-  int out_identity;
-  int omh, omw, omd, ooh, oow, ood, oh, ow, od;
-  int n0;            // columns [0,n0) go to o0 (row stride ldo0), the rest to o1 (ldo1)
-  int ldo0, ldo1;
-  int accum;         // != 0: add to the existing output instead of overwriting
-};
-
-struct RowCoord {
-  int b, h, w, d;
-};
-
-__device__ __forceinline__ RowCoord split_row(const IGemmArgs& g, long long m) {
-  RowCoord r;
-  r.d = (int)(m % g.rd);
-  long long t = m / g.rd;
-  r.w = (int)(t % g.rw);
-  t /= g.rw;
-  r.h = (int)(t % g.rh);
-  r.b = (int)(t / g.rh);
-  return r;
-}
+#include "gemm_desc.h"
 
 // 4 consecutive channels of the A operand at (row, k); zero outside the source / beyond K
 template <typename TA>
@@ -85,7 +41,7 @@ __device__ __forceinline__ float4 gather_w(const IGemmArgs& g, int n, int k) {
   const int c = k - slot * g.C;
   const int nper = g.N / g.nseg;
   const int seg = n / nper;
-  const float* base = g.w[seg] + (long long)(n - seg * nper) * g.wrow;
+  const float* base = reinterpret_cast<const float*>(g.w[seg]) + (long long)(n - seg * nper) * g.wrow;
   return *reinterpret_cast<const float4*>(base + (int)g.tap[slot].wt * g.C + c);
 }
 
@@ -227,15 +183,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_kernel(const IGemmArgs g
 
 // ------------------------------------------------------------------------------------------------
 // TN: dW[n][slot->wt][c] += sum_m G[m][n] * A[m][k];  db[n] += sum_m G[m][n]
-struct WGradArgs {
-  IGemmArgs g;        // gather description (a0/a1, taps, row grid); N,K as above
-  const void* grad;   // G [M][ldg]
-  int ldg;
-  float* dw;          // [N][wrow]
-  float* db;          // may be null
-  int rows_per_split; // multiple of 16
-};
-
 template <typename TA, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_kernel(const WGradArgs wa) {
   const IGemmArgs& g = wa.g;
@@ -406,7 +353,7 @@ static void dense_desc(IGemmArgs& g, long long M, int N, int K) {
   g.n0 = N;
 }
 
-extern "C" int ltu_linear_fwd(const void* a, int lda, const float* const* w, int nw, const float* const* bias, void* y,
+extern "C" int ltu_linear_fwd(const void* a, int lda, const void* const* w, int nw, const float* const* bias, void* y,
                               int ldy, int M, int N, int K, int accumulate, int dtype, ltu_stream_t s) {
   if (nw < 1 || nw > 3 || N % nw != 0 || K % 4 != 0 || lda % 4 != 0) return LTU_E_SHAPE;
   IGemmArgs g;
@@ -416,7 +363,9 @@ extern "C" int ltu_linear_fwd(const void* a, int lda, const float* const* w, int
   for (int i = 0; i < nw; ++i) { g.w[i] = w[i]; g.bias[i] = bias ? bias[i] : nullptr; }
   g.o0 = y; g.o1 = y; g.ldo0 = ldy; g.ldo1 = ldy;
   g.accum = accumulate;
-  LTU_DISPATCH_T(dtype, return (launch_nt<T, T>(g, (hipStream_t)s)););
+  if (dtype == LTU_BF16) return launch_nt_bf16(g, (hipStream_t)s);
+  if (dtype != LTU_F32) return LTU_E_DTYPE;
+  return launch_nt<float, float>(g, (hipStream_t)s);
 }
 
 extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* dw, float* db, int M, int N,
@@ -426,7 +375,9 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
   dense_desc(wa.g, M, N, K);
   wa.g.a0 = a; wa.g.a1 = a; wa.g.lda0 = lda; wa.g.lda1 = lda;
   wa.grad = grad; wa.ldg = ldg; wa.dw = dw; wa.db = db;
-  LTU_DISPATCH_T(dtype, return launch_tn<T>(wa, (hipStream_t)s););
+  if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
+  if (dtype != LTU_F32) return LTU_E_DTYPE;
+  return launch_tn<float>(wa, (hipStream_t)s);
 }
 
 // forward-conv gather description (also used by the weight gradient)
@@ -451,7 +402,7 @@ static int conv_fwd_desc(IGemmArgs& g, int B, int Hi, int Wi, int Di, int C0, in
   return LTU_OK;
 }
 
-extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const float* wf, const float* bias, void* y, int B, int Hi,
+extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* bias, void* y, int B, int Hi,
                               int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype,
                               ltu_stream_t s) {
   IGemmArgs g;
@@ -461,7 +412,9 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const float* wf, c
   g.a0 = x0; g.a1 = x1 ? x1 : x0;
   g.w[0] = wf; g.bias[0] = bias;
   g.o0 = y; g.o1 = y; g.ldo0 = Co; g.ldo1 = Co;
-  LTU_DISPATCH_T(dtype, return (launch_nt<T, T>(g, (hipStream_t)s)););
+  if (dtype == LTU_BF16) return launch_nt_bf16(g, (hipStream_t)s);
+  if (dtype != LTU_F32) return LTU_E_DTYPE;
+  return launch_nt<float, float>(g, (hipStream_t)s);
 }
 
 extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi,
@@ -474,13 +427,15 @@ extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1
   if (Co % 4 != 0) return LTU_E_SHAPE;
   wa.g.a0 = x0; wa.g.a1 = x1 ? x1 : x0;
   wa.grad = grad; wa.ldg = Co; wa.dw = dwf; wa.db = db;
-  LTU_DISPATCH_T(dtype, return launch_tn<T>(wa, (hipStream_t)s););
+  if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
+  if (dtype != LTU_F32) return LTU_E_DTYPE;
+  return launch_tn<float>(wa, (hipStream_t)s);
 }
 
 // Data gradient.  Logical input dims (Hl,Wl,Dl); the forward output dims follow from the stride.
 // For a dim of stride 2 the input positions split into parity classes:  even i receives only from
 // tap 1 (at o = i/2), odd i from tap 0 (o = (i+1)/2) and tap 2 (o = (i-1)/2).
-extern "C" int ltu_conv3d_dgrad(const void* grad, const float* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl,
+extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl,
                                 int C0, int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s) {
   if ((sh != 1 && sh != 2) || (sw != 1 && sw != 2) || (sd != 1 && sd != 2)) return LTU_E_ARG;
   if (Co % 4 != 0) return LTU_E_SHAPE;
@@ -532,7 +487,7 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const float* wd, void* dx0, vo
         g.n0 = C0; g.o0 = dx0; g.ldo0 = C0; g.o1 = dx1 ? dx1 : dx0; g.ldo1 = C1 > 0 ? C1 : C0;
         int rc;
         if (dtype == LTU_F32) rc = launch_nt<float, float>(g, (hipStream_t)s);
-        else if (dtype == LTU_BF16) rc = launch_nt<bf16_t, bf16_t>(g, (hipStream_t)s);
+        else if (dtype == LTU_BF16) rc = launch_nt_bf16(g, (hipStream_t)s);
         else return LTU_E_DTYPE;
         if (rc) return rc;
       }

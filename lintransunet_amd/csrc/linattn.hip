@@ -105,7 +105,7 @@ __global__ void linattn_kv_partial(const T* __restrict__ qkv, float* __restrict_
 __global__ void linattn_kv_combine(const float* __restrict__ part, float* __restrict__ stats, float* __restrict__ ctx,
                                    int nsplit, int H) {
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
-  const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
+  const int i = threadIdx.x & 31, j = threadIdx.x >> 5;     // consecutive lanes read consecutive i of accT[j][i]
   const float* p0 = part + ((long long)b * nsplit * H + h) * PART_STRIDE;
   const long long sstride = (long long)H * PART_STRIDE;
   float m = -INFINITY;
@@ -257,11 +257,18 @@ __global__ void linattn_dctx_partial(const T* __restrict__ qkv, const T* __restr
 // grid (B*H), block 1024: dctx[bh][i][j] = sum_s partT[s][j][i];  tvec[bh][i] = sum_j dctx[i][j]*ctx[i][j]
 __global__ void linattn_dctx_combine(const float* __restrict__ part, const float* __restrict__ ctx, float* __restrict__ dctx,
                                      float* __restrict__ tvec, int nsplit, int H) {
+  __shared__ float sm[32][33];
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
-  const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
   const float* p0 = part + ((long long)b * nsplit * H + h) * 1024;
-  float a = 0.f;
-  for (int s = 0; s < nsplit; ++s) a += p0[(long long)s * H * 1024 + j * 32 + i];
+  {
+    const int ii = threadIdx.x & 31, jj = threadIdx.x >> 5;   // coalesced over the split partials partT[jj][ii]
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += p0[(long long)s * H * 1024 + jj * 32 + ii];
+    sm[jj][ii] = a;
+  }
+  __syncthreads();
+  const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
+  const float a = sm[j][i];
   dctx[(long long)bh * 1024 + i * 32 + j] = a;
   float t = a * ctx[(long long)bh * 1024 + i * 32 + j];
   t = group_sum<32>(t);

@@ -40,8 +40,9 @@ extern "C" int ltu_window_embed(const float* x, void* y, int dtype, int B, int H
 }
 
 // ------------------------------------------------------------------------------------------------ weight repacking
-// w [Co][Ci][27] -> wf [CoP][27][CiP], wd [CiP][27][CoP]  (zero padded)
-__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Co, int Ci,
+// w [Co][Ci][27] -> wf [CoP][27][CiP], wd [CiP][27][CoP]  (zero padded), stored as TW (fp32 or bf16)
+template <typename TW>
+__global__ void pack_conv_kernel(const float* __restrict__ w, TW* __restrict__ wf, TW* __restrict__ wd, int Co, int Ci,
                                  int CoP, int CiP) {
   const long long n = (long long)CoP * 27 * CiP;
   GRID_STRIDE(i, n) {
@@ -49,8 +50,8 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
     const int t = (int)((i / CiP) % 27);
     const int co = (int)(i / ((long long)CiP * 27));
     const float v = (co < Co && ci < Ci) ? w[((long long)co * Ci + ci) * 27 + t] : 0.f;
-    if (wf) wf[i] = v;
-    if (wd) wd[((long long)ci * 27 + t) * CoP + co] = v;
+    if (wf) st1<TW>(wf + i, v);
+    if (wd) st1<TW>(wd + ((long long)ci * 27 + t) * CoP + co, v);
   }
 }
 __global__ void unpack_conv_kernel(const float* __restrict__ dwf, float* __restrict__ dw, int Co, int Ci, int CiP) {
@@ -62,7 +63,8 @@ __global__ void unpack_conv_kernel(const float* __restrict__ dwf, float* __restr
     dw[i] = dwf[((long long)co * 27 + t) * CiP + ci];
   }
 }
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, int ldo, int col_off) {
+template <typename TW>
+__global__ void transpose_kernel(const float* __restrict__ in, TW* __restrict__ out, int R, int C, int ldo, int col_off) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
@@ -72,21 +74,36 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int c = c0 + j, r = r0 + threadIdx.x;
-    if (r < R && c < C) out[(long long)c * ldo + col_off + r] = tile[threadIdx.x][j];
+    if (r < R && c < C) st1<TW>(out + (long long)c * ldo + col_off + r, tile[threadIdx.x][j]);
   }
 }
+template <typename TW>
+__global__ void cast_kernel(const float* __restrict__ in, TW* __restrict__ out, long long n) {
+  GRID_STRIDE(i, n) st1<TW>(out + i, in[i]);
+}
 
-extern "C" int ltu_pack_conv_weight(const float* w, float* wf, float* wd, int Co, int Ci, int CoP, int CiP, ltu_stream_t s) {
+extern "C" int ltu_pack_conv_weight(const float* w, void* wf, void* wd, int Co, int Ci, int CoP, int CiP, int out_dtype,
+                                    ltu_stream_t s) {
   if (CoP < Co || CiP < Ci) return LTU_E_SHAPE;
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(sgrid((long long)CoP * 27 * CiP)), dim3(256), 0, (hipStream_t)s, w, wf, wd, Co, Ci, CoP, CiP);
+  LTU_DISPATCH_T(out_dtype, {
+    hipLaunchKernelGGL((pack_conv_kernel<T>), dim3(sgrid((long long)CoP * 27 * CiP)), dim3(256), 0, (hipStream_t)s, w, (T*)wf,
+                       (T*)wd, Co, Ci, CoP, CiP);
+  });
   return ltu_check_launch();
 }
 extern "C" int ltu_unpack_conv_wgrad(const float* dwf, float* dw, int Co, int Ci, int CiP, ltu_stream_t s) {
   hipLaunchKernelGGL(unpack_conv_kernel, dim3(sgrid((long long)Co * Ci * 27)), dim3(256), 0, (hipStream_t)s, dwf, dw, Co, Ci, CiP);
   return ltu_check_launch();
 }
-extern "C" int ltu_transpose_f32(const float* in, float* out, int R, int C, int ldo, int col_off, ltu_stream_t s) {
-  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)s, in, out, R, C, ldo, col_off);
+extern "C" int ltu_transpose_f32(const float* in, void* out, int R, int C, int ldo, int col_off, int out_dtype, ltu_stream_t s) {
+  LTU_DISPATCH_T(out_dtype, {
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)s, in, (T*)out, R, C,
+                       ldo, col_off);
+  });
+  return ltu_check_launch();
+}
+extern "C" int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_stream_t s) {
+  LTU_DISPATCH_T(out_dtype, { hipLaunchKernelGGL((cast_kernel<T>), dim3(sgrid(n)), dim3(256), 0, (hipStream_t)s, in, (T*)out, n); });
   return ltu_check_launch();
 }
 

@@ -198,7 +198,7 @@ class MaskTransUnet(nn.Module):
             lvl = nl - 1 - i
             t = ops.trilinear_up(t, 2 if (nl - i) % 2 == 0 else 1)
             mc = dec.mask_conv_list[lvl]
-            m = ops.head_softmax(ops.conv3d(t, mc.weight, mc.bias, cop=4), C)
+            m = ops.head_softmax(ops.conv3d(t, mc.weight, mc.bias, cop=4 if self.act_dtype == torch.float32 else 8), C)
             masks.append(m)
             ag = dec.att_conv_list[lvl]
             skip = ops.attention_gate(skips[-i], t, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,

@@ -47,8 +47,23 @@ def _ptr_array(tensors):
     return arr
 
 
-def _pad4(n):
-    return (n + 3) // 4 * 4
+def _w_operand(w, dtype):
+    """fp32 master weight -> GEMM operand in the activation dtype (same layout)"""
+    if dtype == torch.float32:
+        return w
+    out = torch.empty(w.shape, device=w.device, dtype=dtype)
+    _lib.call('ltu_cast_f32', _p(w), _p(out), w.numel(), BF16, _s())
+    return out
+
+
+def _w_transposed(ws, rows, cols, dtype):
+    """cat(ws)^T as a GEMM operand: ws are [rows, cols] fp32 blocks -> [cols, len(ws)*rows] in the activation dtype"""
+    n = rows * len(ws)
+    wt = torch.empty((cols, n), device=ws[0].device, dtype=dtype)
+    odt = F32 if dtype == torch.float32 else BF16
+    for i, w in enumerate(ws):
+        _lib.call('ltu_transpose_f32', _p(w), _p(wt), rows, cols, n, i * rows, odt, _s())
+    return wt
 
 
 # ---------------------------------------------------------------------------------------------- no-grad helpers
@@ -108,8 +123,8 @@ class _Conv3d(torch.autograd.Function):
         CiP = C0 + C1
         assert CiP >= Ci and cop >= Co
         dev = x0.device
-        wf = torch.empty((cop, 27, CiP), device=dev, dtype=torch.float32)
-        _lib.call('ltu_pack_conv_weight', _p(weight), _p(wf), 0, Co, Ci, cop, CiP, _s())
+        wf = torch.empty((cop, 27, CiP), device=dev, dtype=x0.dtype)
+        _lib.call('ltu_pack_conv_weight', _p(weight), _p(wf), 0, Co, Ci, cop, CiP, _dt(x0), _s())
         bias_p = bias
         if cop != Co:
             bias_p = torch.zeros(cop, device=dev, dtype=torch.float32)
@@ -138,8 +153,8 @@ class _Conv3d(torch.autograd.Function):
         dx0 = dx1 = None
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
         if need_dx:
-            wd = torch.empty((CiP, 27, cop), device=dev, dtype=torch.float32)
-            _lib.call('ltu_pack_conv_weight', _p(weight), 0, _p(wd), Co, Ci, cop, CiP, _s())
+            wd = torch.empty((CiP, 27, cop), device=dev, dtype=x0.dtype)
+            _lib.call('ltu_pack_conv_weight', _p(weight), 0, _p(wd), Co, Ci, cop, CiP, dt, _s())
             Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
             d0 = torch.empty((B, Hl, Wl, Dl, C0), device=dev, dtype=x0.dtype)
             d1 = torch.empty((B, Hl, Wl, Dl, C1), device=dev, dtype=x0.dtype) if C1 else None
@@ -177,8 +192,8 @@ class _Linear(torch.autograd.Function):
         Ns = ws[0].shape[0]
         N = Ns * nw
         y = torch.empty((M, N), device=x.device, dtype=x.dtype)
-        _lib.call('ltu_linear_fwd', _p(x), K, _ptr_array([w.reshape(Ns, K) for w in ws]), nw, _ptr_array(bs), _p(y), N, M, N,
-                  K, 0, _dt(x), _s())
+        wop = [_w_operand(w, x.dtype) for w in ws]
+        _lib.call('ltu_linear_fwd', _p(x), K, _ptr_array(wop), nw, _ptr_array(bs), _p(y), N, M, N, K, 0, _dt(x), _s())
         ctx.save_for_backward(x, *ws)
         ctx.nw = nw
         return y
@@ -194,9 +209,7 @@ class _Linear(torch.autograd.Function):
         dev, dt = x.device, _dt(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty((K, N), device=dev, dtype=torch.float32)     # cat(W)^T
-            for i, w in enumerate(ws):
-                _lib.call('ltu_transpose_f32', _p(w), _p(wt), Ns, K, N, i * Ns, _s())
+            wt = _w_transposed(ws, Ns, K, x.dtype)                         # cat(W)^T
             dx = torch.empty((M, K), device=dev, dtype=x.dtype)
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         dws, dbs = [], []
@@ -509,8 +522,10 @@ class _Gate(torch.autograd.Function):
         dev, dt = skip.device, _dt(skip)
         u1 = torch.empty((M, C), device=dev, dtype=skip.dtype)
         u2 = torch.empty((M, C), device=dev, dtype=skip.dtype)
-        _lib.call('ltu_linear_fwd', _p(skip), C, _ptr_array([wx]), 1, _ptr_array([bx]), _p(u1), C, M, C, C, 0, dt, _s())
-        _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([wg]), 1, _ptr_array([bg]), _p(u2), C, M, C, Cg, 0, dt, _s())
+        _lib.call('ltu_linear_fwd', _p(skip), C, _ptr_array([_w_operand(wx, skip.dtype)]), 1, _ptr_array([bx]), _p(u1), C, M, C,
+                  C, 0, dt, _s())
+        _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([_w_operand(wg, skip.dtype)]), 1, _ptr_array([bg]), _p(u2), C, M, C,
+                  Cg, 0, dt, _s())
         s1 = torch.zeros((B, C, 3), device=dev, dtype=torch.float32)
         s2 = torch.zeros((B, C, 3), device=dev, dtype=torch.float32)
         _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), B, S, C, dt, _s())
@@ -541,10 +556,8 @@ class _Gate(torch.autograd.Function):
         _lib.call('ltu_gate_bwd', _p(g), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
                   _p(dpb), _p(bs1), _p(bs2), _p(du1), _p(du2), B, S, C, dt, _s())
         # through the two 1x1x1 convs
-        wxt = torch.empty((C, C), device=dev, dtype=torch.float32)
-        wgt = torch.empty((Cg, C), device=dev, dtype=torch.float32)
-        _lib.call('ltu_transpose_f32', _p(wx), _p(wxt), C, C, C, 0, _s())
-        _lib.call('ltu_transpose_f32', _p(wg), _p(wgt), C, Cg, C, 0, _s())
+        wxt = _w_transposed([wx], C, C, skip.dtype)
+        wgt = _w_transposed([wg], C, Cg, skip.dtype)
         dup = torch.empty_like(up)
         # dskip += du1 . Wx  (accumulating epilogue), dup = du2 . Wg
         _lib.call('ltu_linear_fwd', _p(du1), C, _ptr_array([wxt]), 1, _ptr_array([None]), _p(dskip), C, M, C, C, 1, dt, _s())

@@ -71,15 +71,77 @@ def test_linear(ops, M, K, N, nw):
         assert rel_err(a.grad, b.grad) < 1e-4
 
 
-def test_linear_bf16(ops):
+@pytest.mark.parametrize('M,K,N,nw', [(400, 128, 64, 1), (1000, 64, 96, 3), (257, 256, 768, 3), (4100, 32, 32, 1), (300, 128, 8, 1)])
+def test_linear_bf16(ops, M, K, N, nw):
+    """bf16 matrix-core path (NT forward / data gradient, transposing-read TN weight gradient); bf16 rounding of
+    inputs and outputs bounds the error at ~1e-2 of the tensor's max"""
     g = G(2)
-    x = torch.randn(400, 128, generator=g)
-    w = torch.randn(64, 128, generator=g) * 0.1
-    b = torch.randn(64, generator=g)
-    yr = F.linear(x.bfloat16().float(), w, b)
-    yd = ops.linear(x.to(DEV, torch.bfloat16), [w.to(DEV)], [b.to(DEV)])
+    bf = lambda t: t.bfloat16().float()
+    x = bf(torch.randn(M, K, generator=g))
+    ws = [bf(torch.randn(N // nw, K, generator=g) * 0.1) for _ in range(nw)]
+    bs = [torch.randn(N // nw, generator=g) for _ in range(nw)]
+    go = bf(torch.randn(M, N, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    yr = F.linear(xr, torch.cat(wr), torch.cat(br))
+    yr.backward(go)
+    xd = x.to(DEV, torch.bfloat16).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    bd = [b.to(DEV).requires_grad_(True) for b in bs]
+    yd = ops.linear(xd, wd, bd)
     assert yd.dtype == torch.bfloat16
-    assert rel_err(yd, yr) < 2e-2
+    yd.backward(go.to(DEV, torch.bfloat16))
+    assert rel_err(yd, yr) < 1e-2
+    assert rel_err(xd.grad, xr.grad) < 1e-2
+    for a, b in zip(wd, wr):
+        assert rel_err(a.grad, b.grad) < 2e-3       # fp32 accumulation of exact bf16 products
+    for a, b in zip(bd, br):
+        assert rel_err(a.grad, b.grad) < 2e-3
+
+
+@pytest.mark.parametrize('case', [
+    (2, 8, 16, 6, 5, 8, (1, 1, 1), 0, False, None),
+    (1, 16, 32, 8, 8, 6, (2, 2, 1), 0, False, None),
+    (2, 8, 8, 7, 6, 5, (2, 2, 2), 0, False, None),
+    (1, 8, 16, 6, 6, 4, (1, 1, 1), 8, False, None),
+    (1, 16, 8, 3, 4, 2, (1, 1, 1), 0, True, None),
+    (1, 32, 2, 5, 4, 6, (1, 1, 1), 0, False, 8),
+    (1, 64, 128, 4, 4, 4, (1, 1, 1), 0, False, None),
+])
+def test_conv3d_bf16(ops, case):
+    B, Ci, Co, H, W, D, stride, C1, ups, cop = case
+    g = G(3)
+    bf = lambda t: t.bfloat16().float()
+    x0 = bf(torch.randn(B, Ci, H, W, D, generator=g))
+    x1 = bf(torch.randn(B, C1, H, W, D, generator=g)) if C1 else None
+    w = bf(torch.randn(Co, Ci + C1, 3, 3, 3, generator=g) * 0.1)
+    b = torch.randn(Co, generator=g)
+    x0r = x0.clone().requires_grad_(True)
+    x1r = x1.clone().requires_grad_(True) if C1 else None
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = x0r if not C1 else torch.cat((x0r, x1r), 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2)
+    yr = F.conv3d(xin, wr, br, stride=stride, padding=1)
+    go = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(go)
+    x0d = to_cl(x0, torch.bfloat16).requires_grad_(True)
+    x1d = to_cl(x1, torch.bfloat16).requires_grad_(True) if C1 else None
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.conv3d(x0d, wd, bd, stride=stride, x1=x1d, ups=ups, cop=cop)
+    god = to_cl(go, torch.bfloat16)
+    if cop:
+        pad = torch.zeros(yd.shape, device=DEV, dtype=torch.bfloat16)
+        pad[..., :Co] = god
+        god = pad
+    yd.backward(god)
+    assert rel_err(from_cl(yd)[:, :Co], yr) < 1e-2
+    assert rel_err(from_cl(x0d.grad), x0r.grad) < 1e-2
+    if C1:
+        assert rel_err(from_cl(x1d.grad), x1r.grad) < 1e-2
+    assert rel_err(wd.grad, wr.grad) < 2e-3
+    assert rel_err(bd.grad, br.grad) < 2e-3
 
 
 # ---------------------------------------------------------------------------------------------- conv3d
