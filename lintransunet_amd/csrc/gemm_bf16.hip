@@ -7,21 +7,67 @@
 //                                 ([m][n] / [m][k]) and the MFMA fragments are fetched with the transposing
 //                                 LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group).
 // Activations and weight operands are bf16, accumulation fp32, bias / weight gradients fp32.
+#include <stdlib.h>
+
 #include "gemm_desc.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// M < 2^31 is enforced by the launchers: 32-bit divisions only
 __device__ __forceinline__ RowCoord split_row_b(const IGemmArgs& g, long long m) {
   RowCoord r;
-  r.d = (int)(m % g.rd);
-  long long t = m / g.rd;
-  r.w = (int)(t % g.rw);
-  t /= g.rw;
-  r.h = (int)(t % g.rh);
-  r.b = (int)(t / g.rh);
+  unsigned t = (unsigned)m;
+  const unsigned q0 = t / (unsigned)g.rd;
+  r.d = (int)(t - q0 * (unsigned)g.rd);
+  const unsigned q1 = q0 / (unsigned)g.rw;
+  r.w = (int)(q0 - q1 * (unsigned)g.rw);
+  const unsigned q2 = q1 / (unsigned)g.rh;
+  r.h = (int)(q1 - q2 * (unsigned)g.rh);
+  r.b = (int)q2;
   return r;
+}
+__device__ __forceinline__ void advance_row(const IGemmArgs& g, RowCoord& r, int delta) {
+  r.d += delta;
+  while (r.d >= g.rd) {
+    r.d -= g.rd;
+    if (++r.w == g.rw) {
+      r.w = 0;
+      if (++r.h == g.rh) { r.h = 0; ++r.b; }
+    }
+  }
+}
+// position inside the K axis as (tap slot, channel); advanced without divisions
+struct KCur {
+  int slot, c;
+};
+__device__ __forceinline__ KCur kcur_init(const IGemmArgs& g, int k) {
+  KCur q;
+  q.slot = k / g.C;          // k >= K gives slot >= ntaps, i.e. "past the end"
+  q.c = k - q.slot * g.C;
+  return q;
+}
+__device__ __forceinline__ void kcur_advance(const IGemmArgs& g, KCur& q, int delta) {
+  q.c += delta;
+  while (q.c >= g.C && q.slot < g.ntaps) { q.c -= g.C; ++q.slot; }
+}
+// 8 consecutive bf16 channels of the A operand at (row, cursor); zero outside the source / beyond K
+__device__ __forceinline__ uint4 gather_a8c(const IGemmArgs& g, bool row_ok, const RowCoord& rc, const KCur& q) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  if (!row_ok || q.slot >= g.ntaps) return z;
+  const Tap tp = g.tap[q.slot];
+  int h = rc.h * g.mh + tp.dh, w = rc.w * g.mw + tp.dw, d = rc.d * g.md + tp.dd;
+  if ((unsigned)h >= (unsigned)g.sh || (unsigned)w >= (unsigned)g.sw || (unsigned)d >= (unsigned)g.sd) return z;
+  int ph = g.sh, pw = g.sw, pd = g.sd;
+  if (g.ups) {
+    h >>= 1; w >>= 1; d >>= 1;
+    ph >>= 1; pw >>= 1; pd >>= 1;
+  }
+  const long long vox = (((long long)rc.b * ph + h) * pw + w) * pd + d;
+  const uint16_t* p = q.c < g.c0 ? reinterpret_cast<const uint16_t*>(g.a0) + vox * g.lda0 + q.c
+                                 : reinterpret_cast<const uint16_t*>(g.a1) + vox * g.lda1 + (q.c - g.c0);
+  return *reinterpret_cast<const uint4*>(p);
 }
 
 // 8 consecutive bf16 channels of the A operand at (row, k); zero outside the source / beyond K
@@ -62,17 +108,21 @@ __device__ __forceinline__ long long out_voxel_b(const IGemmArgs& g, long long m
 }
 
 // ------------------------------------------------------------------------------------------------ NT
-template <int WM, int WN, int TM, int TN>
+// BK = K-extent of one LDS tile (32 / 64 / 128 bf16), NBUF = LDS tile buffers.  One tile costs one global
+// round trip, so BK is chosen so that a tile carries enough matrix work to cover it (dense projections with
+// K <= 128 take the whole K in ONE tile; convolutions use 64).  LDS rows are BK+8 elements: a lane group of a
+// ds_read_b128 fragment read (16 rows, same 16-byte column) then covers 16 distinct 4-bank slots.
+template <int WM, int WN, int TM, int TN, int BK, int NBUF>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmArgs g) {
-  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, LDK = 40;
-  constexpr int LA = (BM * 4 + NT - 1) / NT, LB = (BN * 4 + NT - 1) / NT;
+  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = BK + 8, CPRK = BK / 8;
+  constexpr int LA = (BM * CPRK + NT - 1) / NT, LB = (BN * CPRK + NT - 1) / NT;
   constexpr int LDC = BN + 8;                                   // staging row stride (bf16 elements)
-  constexpr int TILE_ELEMS = 2 * (BM + BN) * LDK;
+  constexpr int TILE_ELEMS = NBUF * (BM + BN) * LDK;
   constexpr int STAGE_ELEMS = BM * LDC;
   constexpr int SMEM_ELEMS = TILE_ELEMS > STAGE_ELEMS ? TILE_ELEMS : STAGE_ELEMS;
   __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
-  uint16_t* As = smem;                       // [2][BM][LDK]
-  uint16_t* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
+  uint16_t* As = smem;                          // [NBUF][BM][LDK]
+  uint16_t* Bs = smem + NBUF * BM * LDK;        // [NBUF][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -84,8 +134,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
 #pragma unroll
   for (int p = 0; p < LA; ++p) {
     const int idx = tid + p * NT;
-    const long long m = m_blk + (idx >> 2);
-    rok[p] = (idx < BM * 4) && (m < g.M);
+    const long long m = m_blk + idx / CPRK;
+    rok[p] = (idx < BM * CPRK) && (m < g.M);
     rc[p] = split_row_b(g, rok[p] ? m : 0);
   }
 
@@ -97,44 +147,50 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[LA], rb[LB];
   const int nkt = (g.K + BK - 1) / BK;
+  // every load of this thread sits at the same k offset inside a tile (NT % CPRK == 0): one cursor
+  KCur cur = kcur_init(g, (tid % CPRK) * 8);
+  const uint16_t* wrow[LB];
+#pragma unroll
+  for (int p = 0; p < LB; ++p) {
+    const int idx = tid + p * NT;
+    const int n = n_blk + idx / CPRK;
+    wrow[p] = nullptr;
+    if (idx < BN * CPRK && n < g.N) {
+      const int nper = g.N / g.nseg;
+      const int seg = n / nper;
+      wrow[p] = reinterpret_cast<const uint16_t*>(g.w[seg]) + (long long)(n - seg * nper) * g.wrow;
+    }
+  }
 
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
+  // loads the NEXT tile of the K sequence into a register set
+  auto load_tile = [&](uint4 (&ra)[LA], uint4 (&rb)[LB]) {
+#pragma unroll
+    for (int p = 0; p < LA; ++p) ra[p] = (g.dbg & 4) ? make_uint4(1u, 2u, 3u, 4u) : gather_a8c(g, rok[p], rc[p], cur);
+    const bool kin = cur.slot < g.ntaps;
+    const int woff = kin ? (int)g.tap[cur.slot].wt * g.C + cur.c : 0;
+#pragma unroll
+    for (int p = 0; p < LB; ++p)
+      rb[p] = (kin && wrow[p]) ? *reinterpret_cast<const uint4*>(wrow[p] + woff) : make_uint4(0u, 0u, 0u, 0u);
+    kcur_advance(g, cur, BK);
+  };
+  auto store_tile = [&](const uint4 (&ra)[LA], const uint4 (&rb)[LB], int buf) {
 #pragma unroll
     for (int p = 0; p < LA; ++p) {
       const int idx = tid + p * NT;
-      ra[p] = gather_a8(g, rok[p], rc[p], k0 + (idx & 3) * 8);
+      if (idx < BM * CPRK) *reinterpret_cast<uint4*>(&As[(buf * BM + idx / CPRK) * LDK + (idx % CPRK) * 8]) = ra[p];
     }
 #pragma unroll
     for (int p = 0; p < LB; ++p) {
       const int idx = tid + p * NT;
-      rb[p] = (idx < BN * 4) ? gather_w8(g, n_blk + (idx >> 2), k0 + (idx & 3) * 8) : make_uint4(0u, 0u, 0u, 0u);
+      if (idx < BN * CPRK) *reinterpret_cast<uint4*>(&Bs[(buf * BN + idx / CPRK) * LDK + (idx % CPRK) * 8]) = rb[p];
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < LA; ++p) {
-      const int idx = tid + p * NT;
-      if (idx < BM * 4) *reinterpret_cast<uint4*>(&As[(buf * BM + (idx >> 2)) * LDK + (idx & 3) * 8]) = ra[p];
-    }
-#pragma unroll
-    for (int p = 0; p < LB; ++p) {
-      const int idx = tid + p * NT;
-      if (idx < BN * 4) *reinterpret_cast<uint4*>(&Bs[(buf * BN + (idx >> 2)) * LDK + (idx & 3) * 8]) = rb[p];
-    }
-  };
-
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int li = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  auto compute = [&](int buf) {
+    if (g.dbg & 2) return;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -147,8 +203,45 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+  };
+
+  uint4 ra0[LA], rb0[LB];
+  if (NBUF == 2) {
+    // 3-stage pipeline: tile t in LDS being consumed, tile t+1 arrived in registers, tile t+2 in flight.
+    uint4 ra1[LA], rb1[LB];
+    load_tile(ra0, rb0);                          // tile 0
+    store_tile(ra0, rb0, 0);
+    if (nkt > 1) load_tile(ra0, rb0);             // tile 1
+    if (nkt > 2) load_tile(ra1, rb1);             // tile 2
     __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+      compute(0);                                 // tile kt
+      if (kt + 1 < nkt) {
+        store_tile(ra0, rb0, 1);                  // tile kt+1 (buffer 1 was released by the previous barrier)
+        if (kt + 3 < nkt) load_tile(ra0, rb0);    // tile kt+3
+      }
+      __syncthreads();
+      if (kt + 1 >= nkt) break;
+      compute(1);                                 // tile kt+1
+      if (kt + 2 < nkt) {
+        store_tile(ra1, rb1, 0);                  // tile kt+2
+        if (kt + 4 < nkt) load_tile(ra1, rb1);    // tile kt+4
+      }
+      __syncthreads();
+    }
+  } else {
+    load_tile(ra0, rb0);
+    store_tile(ra0, rb0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) load_tile(ra0, rb0);
+      compute(0);
+      if (kt + 1 < nkt) {
+        __syncthreads();                          // single buffer: everyone is done reading before it is refilled
+        store_tile(ra0, rb0, 0);
+      }
+      __syncthreads();
+    }
   }
 
   // epilogue: bias, convert, stage the BM x BN tile in LDS, then whole-vector stores
@@ -172,6 +265,23 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
       }
   }
   __syncthreads();
+  if (g.dbg & 1) return;
+  const bool wide = !g.accum && (g.N % 8 == 0) && (g.n0 % 8 == 0) && (g.ldo0 % 8 == 0) && (g.ldo1 % 8 == 0);
+  if (wide) {
+    constexpr int CPR = BN / 8;               // 16-byte chunks per row
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
+      const int ml = idx / CPR, nl = (idx % CPR) * 8;
+      const long long m = m_blk + ml;
+      const int n = n_blk + nl;
+      if (m >= g.M || n >= g.N) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(&Cs[ml * LDC + nl]);
+      uint16_t* dst;
+      if (n < g.n0) dst = reinterpret_cast<uint16_t*>(g.o0) + out_voxel_b(g, m) * g.ldo0 + n;
+      else dst = reinterpret_cast<uint16_t*>(g.o1) + out_voxel_b(g, m) * g.ldo1 + (n - g.n0);
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
+    return;
+  }
   constexpr int CPR = BN / 4;                 // 8-byte chunks per row
   for (int idx = tid; idx < BM * CPR; idx += NT) {
     const int ml = idx / CPR, nl = (idx % CPR) * 4;
@@ -195,30 +305,56 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
   }
 }
 
-int launch_nt_bf16(const IGemmArgs& g, hipStream_t st) {
+// tuning override for experiments: LTU_NT_VARIANT = 0 (auto) | 1 (BK 32, 2 buffers) | 2 (BK 64, 2 buffers) | 3 (BK 128, 1 buffer)
+static int nt_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LTU_NT_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_nt_cfg(const IGemmArgs& g, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN));
+  int v = nt_variant();
+  if (v == 0) v = 1;      // measured on MI355X: BK 32 (3 workgroups per CU) beats BK 64/128 on every shape of this network
+  if (v == 3 && g.K > 128) v = 2;
+  if (v == 3)
+    hipLaunchKernelGGL((igemm_nt_bf16_kernel<WM, WN, TM, TN, 128, 1>), grid, dim3(WM * WN * 64), 0, st, g);
+  else if (v == 1)
+    hipLaunchKernelGGL((igemm_nt_bf16_kernel<WM, WN, TM, TN, 32, 2>), grid, dim3(WM * WN * 64), 0, st, g);
+  else
+    hipLaunchKernelGGL((igemm_nt_bf16_kernel<WM, WN, TM, TN, 64, 2>), grid, dim3(WM * WN * 64), 0, st, g);
+}
+
+int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
+  IGemmArgs g = g_in;
+  { const char* e = getenv("LTU_NT_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (g.M <= 0 || g.N <= 0) return LTU_OK;
+  if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.wrow % 8 || g.N % 4 || g.n0 % 4 || g.ldo0 % 4 || g.ldo1 % 4)
     return LTU_E_SHAPE;
   if (g.N > 64) {
-    dim3 grid(cdiv(g.M, 128), cdiv(g.N, 128));
-    hipLaunchKernelGGL((igemm_nt_bf16_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, g);
+    if (g.M <= 8192) launch_nt_cfg<2, 2, 1, 2>(g, st);      // few rows: 64-row tiles keep more CUs busy
+    else launch_nt_cfg<2, 2, 2, 2>(g, st);
   } else if (g.N > 32) {
-    dim3 grid(cdiv(g.M, 128), 1);
-    hipLaunchKernelGGL((igemm_nt_bf16_kernel<4, 1, 1, 2>), grid, dim3(256), 0, st, g);
+    launch_nt_cfg<4, 1, 1, 2>(g, st);
   } else {
-    dim3 grid(cdiv(g.M, 128), 1);
-    hipLaunchKernelGGL((igemm_nt_bf16_kernel<4, 1, 1, 1>), grid, dim3(256), 0, st, g);
+    launch_nt_cfg<4, 1, 1, 1>(g, st);
   }
   return ltu_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ TN
-// tile: BNn (n) x BKk (k) of dW, BR = 32 reduction rows per iteration.  Gs[BR][BNn+32], Xs[BR][BKk+32] bf16
+// tile: BNn (n) x BKk (k) of dW, BR = 64 reduction rows per iteration.  Gs[BR][BNn+32], Xs[BR][BKk+32] bf16
 // (the 64-byte pad makes the 4-row transposing reads of a 32-lane half hit 4 disjoint bank ranges).
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradArgs wa) {
   const IGemmArgs& g = wa.g;
-  constexpr int NT = WM * WN * 64, BNn = WM * TM * 32, BKk = WN * TN * 32, BR = 32;
+  constexpr int NT = WM * WN * 64, BNn = WM * TM * 32, BKk = WN * TN * 32, BR = 64;
   constexpr int LDG = BNn + 32, LDX = BKk + 32;
   constexpr int LG = (BR * BNn / 8 + NT - 1) / NT, LX = (BR * BKk / 8 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) uint16_t Gs[2][BR][LDG];
@@ -243,6 +379,17 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
   uint4 rg[LG], rx[LX];
   float bsum = 0.f;
   const int niter = (int)((m_end - m_begin + BR - 1) / BR);
+  // the k position of each gather of this thread never changes; its row advances by BR per iteration
+  KCur xcur[LX];
+  RowCoord xrc[LX];
+#pragma unroll
+  for (int p = 0; p < LX; ++p) {
+    const int idx = tid + p * NT;
+    xcur[p] = kcur_init(g, k_blk + (idx % (BKk / 8)) * 8);
+    if (k_blk + (idx % (BKk / 8)) * 8 >= g.K) xcur[p].slot = g.ntaps;
+    long long m = m_begin + idx / (BKk / 8);
+    xrc[p] = split_row_b(g, m < g.M ? m : 0);
+  }
 
   auto load_tile = [&](int it) {
     const long long m0 = m_begin + (long long)it * BR;
@@ -259,11 +406,11 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
 #pragma unroll
     for (int p = 0; p < LX; ++p) {
       const int idx = tid + p * NT;
-      const int row = idx / (BKk / 8), kq = (idx % (BKk / 8)) * 8;
+      const int row = idx / (BKk / 8);
       const long long m = m0 + row;
       const bool ok = idx < BR * BKk / 8 && m < m_end;
-      const RowCoord rc = split_row_b(g, ok ? m : 0);
-      rx[p] = gather_a8(g, ok, rc, k_blk + kq);
+      rx[p] = gather_a8c(g, ok, xrc[p], xcur[p]);
+      advance_row(g, xrc[p], BR);
     }
   };
   auto store_tile = [&](int buf) {
@@ -346,17 +493,18 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
 int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   const IGemmArgs& g = wa.g;
   if (g.M <= 0 || g.N <= 0) return LTU_OK;
+  if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.N % 8 || wa.ldg % 8) return LTU_E_SHAPE;
   int bn, bk = 128;
   if (g.N > 64) bn = 128;
   else if (g.N > 32) bn = 64;
   else bn = 32;
   const unsigned nk = cdiv(g.K, bk), nn = cdiv(g.N, bn);
-  long long want = 1024 / ((long long)nk * nn);
+  long long want = 512 / ((long long)nk * nn);
   if (want < 1) want = 1;
   long long rows = (g.M + want - 1) / want;
-  if (rows < 256) rows = 256;
-  rows = (rows + 31) / 32 * 32;
+  if (rows < 512) rows = 512;
+  rows = (rows + 63) / 64 * 64;
   wa.rows_per_split = (int)rows;
   dim3 grid(nk, nn, cdiv(g.M, rows));
   if (g.N > 64) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, wa);

@@ -29,6 +29,7 @@ struct IGemmArgs {
   int n0;            // columns [0,n0) go to o0 (row stride ldo0), the rest to o1 (ldo1)
   int ldo0, ldo1;
   int accum;         // != 0: add to the existing output instead of overwriting
+  int dbg;           // experiments only: 1 = skip output stores, 2 = skip matrix work, 4 = skip A loads
 };
 
 struct RowCoord {

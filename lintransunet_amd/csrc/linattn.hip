@@ -21,53 +21,117 @@
 //                                  sum_n P[n][i] dP[n][i] collapses to this, so no second pass over N).
 //          pass 2   (bwd_apply):   per token: dq, dk, dv (three 32x32 products).
 //
-// The matrix products use v_mfma_f32_32x32x2_f32 (exact fp32): the core is HBM-bound (AI = 16 FLOP/B),
-// fp32 MFMA time stays below the streaming time for both storage types.
+// All four streaming kernels share one structure: 32-token tiles staged in LDS as fp32, the NEXT tile's
+// 16-byte global loads issued (fully unrolled, compile-time counts) before the current tile is consumed,
+// so HBM latency overlaps the matrix work inside a workgroup.  The products use v_mfma_f32_32x32x2_f32
+// (exact fp32): the core is HBM-bound (AI = 16 FLOP/B) and fp32 MFMA time stays below the streaming time.
 #include "common.h"
 
 #define DK 32
+#define TOK 32
+#define PART_STRIDE (64 + 1024)
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
-// ------------------------------------------------------------------------------------------------ phase A
-// grid (nsplit, B), block H*64.  part layout: [B][nsplit][H][32 (m) + 32 (s) + 1024 (accT[j][i])]
-#define PART_STRIDE (64 + 1024)
+// ---- 16-byte global vector <-> fp32 LDS --------------------------------------------------------------------
+template <typename T>
+struct GVec;
+template <>
+struct GVec<float> {
+  static constexpr int W = 4;
+  typedef float4 reg;
+  static __device__ __forceinline__ reg load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ reg zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ void to_lds(float* dst, reg v) { *reinterpret_cast<float4*>(dst) = v; }
+  static __device__ __forceinline__ void from_lds(float* gdst, const float* src) {
+    *reinterpret_cast<float4*>(gdst) = *reinterpret_cast<const float4*>(src);
+  }
+};
+template <>
+struct GVec<bf16_t> {
+  static constexpr int W = 8;
+  typedef uint4 reg;
+  static __device__ __forceinline__ reg load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ reg zero() { return make_uint4(0u, 0u, 0u, 0u); }
+  static __device__ __forceinline__ void to_lds(float* dst, reg v) {
+    float4 a, b;
+    a.x = __uint_as_float(v.x << 16); a.y = __uint_as_float(v.x & 0xffff0000u);
+    a.z = __uint_as_float(v.y << 16); a.w = __uint_as_float(v.y & 0xffff0000u);
+    b.x = __uint_as_float(v.z << 16); b.y = __uint_as_float(v.z & 0xffff0000u);
+    b.z = __uint_as_float(v.w << 16); b.w = __uint_as_float(v.w & 0xffff0000u);
+    *reinterpret_cast<float4*>(dst) = a;
+    *reinterpret_cast<float4*>(dst + 4) = b;
+  }
+  static __device__ __forceinline__ void from_lds(bf16_t* gdst, const float* src) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    uint4 v;
+    v.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+    v.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+    v.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+    v.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+    *reinterpret_cast<uint4*>(gdst) = v;
+  }
+};
 
-template <typename T, int TOK>
-__global__ void linattn_kv_partial(const T* __restrict__ qkv, float* __restrict__ part, int N, int d, int tokens_per_split) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [TOK][2d] : k | v rows
-  const int H = d / DK;
+// Stages TOK rows of ROWE elements (row r at gbase + (n0 + r)*gstride + goff) into LDS rows of stride LDSROW floats.
+template <typename T, int D, int ROWE, int LDSROW>
+struct RowTile {
+  static constexpr int NTHR = 2 * D;
+  static constexpr int W = GVec<T>::W;
+  static constexpr int VPR = ROWE / W;                 // vectors per row
+  static constexpr int NV = (TOK * VPR + NTHR - 1) / NTHR;
+  typename GVec<T>::reg r[NV];
+  __device__ __forceinline__ void load(const T* gbase, long long gstride, int goff, int n0, int n_end, int tid) {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int idx = tid + p * NTHR;
+      const int t = idx / VPR, c = (idx % VPR) * W;
+      r[p] = (idx < TOK * VPR && n0 + t < n_end) ? GVec<T>::load(gbase + (long long)(n0 + t) * gstride + goff + c) : GVec<T>::zero();
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int idx = tid + p * NTHR;
+      const int t = idx / VPR, c = (idx % VPR) * W;
+      if (idx < TOK * VPR) GVec<T>::to_lds(lds + t * LDSROW + c, r[p]);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ phase A
+// grid (nsplit, B), block 2D.  part layout: [B][nsplit][H][32 (m) + 32 (s) + 1024 (accT[j][i])]
+template <typename T, int D>
+__global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict__ qkv, float* __restrict__ part, int N,
+                                                           int tokens_per_split) {
+  constexpr int H = D / DK, ROW = 2 * D;
+  __shared__ __attribute__((aligned(16))) float smem[TOK * ROW];   // k | v rows of one tile
   const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int n_begin = sp * tokens_per_split;
-  int n_end = n_begin + tokens_per_split;
-  if (n_end > N) n_end = N;
-  const int row = 2 * d;                       // floats per staged token
-  const T* base = qkv + (long long)b * N * 3 * d + d;   // start of k|v part of token 0
+  const int n_end = min(N, n_begin + tokens_per_split);
+  const T* base = qkv + (long long)b * N * 3 * D;
 
-  float m_run = -INFINITY, s_run = 0.f;        // column i = li (both halves hold a copy; s is per-half partial)
+  float m_run = -INFINITY, s_run = 0.f;        // column i = li (both halves hold a copy; s is a per-half partial)
   f32x16 acc;                                  // accT[j][i]: row j by register, column i = li
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  RowTile<T, D, ROW, ROW> tile;
+  tile.load(base, 3 * D, D, n_begin, n_end, tid);
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
+    __syncthreads();                            // previous tile fully consumed
+    tile.store(smem, tid);
     __syncthreads();
-    // stage TOK token rows (k|v) as fp32; rows past n_end are left unread (masked below)
-    const int nvec = TOK * row / 4;
-    for (int i = tid; i < nvec; i += blockDim.x) {
-      const int t = i / (row / 4), c = (i % (row / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + t < n_end) v = Vec4<T>::load(base + (long long)(n0 + t) * 3 * d + c);
-      *reinterpret_cast<float4*>(&smem[t * row + c]) = v;
-    }
-    __syncthreads();
+    if (n0 + TOK < n_end) tile.load(base, 3 * D, D, n0 + TOK, n_end, tid);
     const int ntok = min(TOK, n_end - n0);
-    const float* ks = smem + wave * DK;        // k of this head: ks[t*row + i]
-    const float* vs = smem + d + wave * DK;
-    // column max over this tile: lane (i, half) scans tokens half, half+2, ...
+    const float* ks = smem + wave * DK;        // k of this head: ks[t*ROW + i]
+    const float* vs = smem + D + wave * DK;
     float mt = -INFINITY;
-    for (int t = lh; t < ntok; t += 2) mt = fmaxf(mt, ks[t * row + li]);
+#pragma unroll 4
+    for (int t = lh; t < TOK; t += 2)
+      if (t < ntok) mt = fmaxf(mt, ks[t * ROW + li]);
     mt = fmaxf(mt, xhalf(mt));
     const float m_new = fmaxf(m_run, mt);
     const float alpha = __expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
@@ -76,13 +140,13 @@ __global__ void linattn_kv_partial(const T* __restrict__ qkv, float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= alpha;
     // accT[j][i] += sum_t v[t][j] * p[t][i];  MFMA k-step = 2 tokens (lane half picks the token)
-#pragma unroll 4
+#pragma unroll
     for (int t0 = 0; t0 < TOK; t0 += 2) {
       const int t = t0 + lh;
       float p = 0.f, vv = 0.f;
       if (t < ntok) {
-        p = __expf(ks[t * row + li] - m_new);
-        vv = vs[t * row + li];
+        p = __expf(ks[t * ROW + li] - m_new);
+        vv = vs[t * ROW + li];
       }
       s_run += p;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p, acc, 0, 0, 0);
@@ -101,68 +165,87 @@ __global__ void linattn_kv_partial(const T* __restrict__ qkv, float* __restrict_
   }
 }
 
-// grid (B*H), block 1024: thread (i = tid>>5, j = tid&31).  stats [B*H][64] = colmax | colsum; ctx [B*H][32][32]
-__global__ void linattn_kv_combine(const float* __restrict__ part, float* __restrict__ stats, float* __restrict__ ctx,
-                                   int nsplit, int H) {
-  const int bh = blockIdx.x, b = bh / H, h = bh % H;
-  const int i = threadIdx.x & 31, j = threadIdx.x >> 5;     // consecutive lanes read consecutive i of accT[j][i]
+// Merge of (m, s, accT) partials, two levels so that more than B*H workgroups share the work:
+//   level 1: grid (ngroups, B*H): partials [g*group, (g+1)*group) of `part` -> one partial in `part2`
+//   level 2: grid (1, B*H) with final != 0: the ngroups partials -> colmax, colsum, ctx (normalised)
+// block 1024: thread (i = tid&31, j = tid>>5) (coalesced over accT[j][i]).
+__global__ void __launch_bounds__(1024) linattn_kv_combine(const float* __restrict__ part, int nsplit, int group,
+                                                           float* __restrict__ part2, float* __restrict__ stats,
+                                                           float* __restrict__ ctx, int H, int final) {
+  const int bh = blockIdx.y, b = bh / H, h = bh % H, g = blockIdx.x;
+  const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   const float* p0 = part + ((long long)b * nsplit * H + h) * PART_STRIDE;
   const long long sstride = (long long)H * PART_STRIDE;
+  const int s0 = g * group, s1 = min(nsplit, s0 + group);
   float m = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, p0[s * sstride + i]);
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) m = fmaxf(m, p0[s * sstride + i]);
   float ssum = 0.f, a = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) {
     const float* p = p0 + s * sstride;
     const float f = __expf(p[i] - m);
     ssum += p[32 + i] * f;
     a += p[64 + j * 32 + i] * f;
   }
-  ctx[(long long)bh * 1024 + i * 32 + j] = a / ssum;
-  if (j == 0) {
-    stats[bh * 64 + i] = m;
-    stats[bh * 64 + 32 + i] = ssum;
+  if (final) {
+    ctx[(long long)bh * 1024 + i * 32 + j] = a / ssum;
+    if (j == 0) {
+      stats[bh * 64 + i] = m;
+      stats[bh * 64 + 32 + i] = ssum;
+    }
+  } else {
+    float* o = part2 + (((long long)b * gridDim.x + g) * H + h) * PART_STRIDE;
+    o[64 + j * 32 + i] = a;
+    if (j == 0) {
+      o[i] = m;
+      o[32 + i] = ssum;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ phase B
-// grid (ceil(N/TOKB), B), block H*64; each block handles TOKB tokens in tiles of 32.
+// grid (ceil(N/tokb), B), block 2D; each block handles tokb tokens in tiles of 32.
 // out [B*N][d];  qstat [B*N][H][2] = (row max, 1/(rowsum*sqrt(32)))
-template <typename T>
-__global__ void linattn_apply(const T* __restrict__ qkv, const float* __restrict__ ctx, T* __restrict__ out,
-                              float* __restrict__ qstat, int N, int d, int tokb) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [32][d+1] q tile, reused for the out tile
-  const int H = d / DK;
+//
+// MFMA k-index convention of the per-token kernels: in k-step s the lane half `lh` supplies channel
+// ch(s, lh) = 16*lh + s (any bijection works as long as both operands use it).  A lane therefore needs 16
+// CONTIGUOUS channels of its token row, fetched with four 128-bit LDS reads from 16-byte aligned rows of
+// stride d+4 floats (lane l starts at bank 4*l mod 64: conflict-free for ds_read_b128).
+template <typename T, int D>
+__global__ void __launch_bounds__(2 * D) linattn_apply(const T* __restrict__ qkv, const float* __restrict__ ctx, T* __restrict__ out,
+                                                      float* __restrict__ qstat, int N, int tokb) {
+  constexpr int H = D / DK, LDQ = D + 4, NTHR = 2 * D, W = GVec<T>::W;
+  __shared__ __attribute__((aligned(16))) float smem[TOK * LDQ];   // q tile, reused for the out tile
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int ldq = d + 1;
-  // B operand: ctx[i = 2s+half][j = li]
-  float cb[16];
+  float cb[16];                                  // B operand: ctx[i = ch(s,lh)][j = li]
   const float* cx = ctx + ((long long)b * H + wave) * 1024;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) cb[s] = cx[(2 * s + lh) * 32 + li];
-  const float rs = 0.17677669529663688110f;   // 1/sqrt(32)
+  for (int s = 0; s < 16; ++s) cb[s] = cx[(16 * lh + s) * 32 + li];
+  const float rs = 0.17677669529663688110f;      // 1/sqrt(32)
+  const T* base = qkv + (long long)b * N * 3 * D;
 
   const int n_begin = blockIdx.x * tokb;
   const int n_end = min(N, n_begin + tokb);
-  for (int n0 = n_begin; n0 < n_end; n0 += 32) {
+  RowTile<T, D, D, LDQ> tile;
+  tile.load(base, 3 * D, 0, n_begin, n_end, tid);
+  for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
     __syncthreads();
-    for (int i = tid; i < 32 * d / 4; i += blockDim.x) {
-      const int t = i / (d / 4), c = (i % (d / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + t < n_end) v = Vec4<T>::load(qkv + ((long long)b * N + n0 + t) * 3 * d + c);
-      float* dst = &smem[t * ldq + c];
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
+    tile.store(smem, tid);
     __syncthreads();
-    // lane (tok = li, half): elements i = 2s+half of its token's head row
+    if (n0 + TOK < n_end) tile.load(base, 3 * D, 0, n0 + TOK, n_end, tid);
     float a[16];
+    const float* qrow = &smem[li * LDQ + wave * DK + 16 * lh];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 v = *reinterpret_cast<const float4*>(qrow + 4 * q4);
+      a[4 * q4] = v.x; a[4 * q4 + 1] = v.y; a[4 * q4 + 2] = v.z; a[4 * q4 + 3] = v.w;
+    }
     float mx = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      a[s] = smem[li * ldq + wave * DK + 2 * s + lh];
-      mx = fmaxf(mx, a[s]);
-    }
+    for (int s = 0; s < 16; ++s) mx = fmaxf(mx, a[s]);
     mx = fmaxf(mx, xhalf(mx));
     float sum = 0.f;
 #pragma unroll
@@ -186,15 +269,15 @@ __global__ void linattn_apply(const T* __restrict__ qkv, const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      smem[t * ldq + wave * DK + li] = acc[r];
+      smem[t * LDQ + wave * DK + li] = acc[r];
     }
     __syncthreads();
-    for (int i = tid; i < 32 * d / 4; i += blockDim.x) {
-      const int t = i / (d / 4), c = (i % (d / 4)) * 4;
-      if (n0 + t < n_end) {
-        const float* src = &smem[t * ldq + c];
-        Vec4<T>::store(out + ((long long)b * N + n0 + t) * d + c, make_float4(src[0], src[1], src[2], src[3]));
-      }
+    constexpr int VPR = D / W;
+#pragma unroll
+    for (int p = 0; p < (TOK * VPR + NTHR - 1) / NTHR; ++p) {
+      const int idx = tid + p * NTHR;
+      const int t = idx / VPR, c = (idx % VPR) * W;
+      if (idx < TOK * VPR && n0 + t < n_end) GVec<T>::from_lds(out + ((long long)b * N + n0 + t) * D + c, &smem[t * LDQ + c]);
     }
   }
 }
@@ -202,46 +285,46 @@ __global__ void linattn_apply(const T* __restrict__ qkv, const float* __restrict
 // ------------------------------------------------------------------------------------------------ backward pass 1
 // dctxT[j][i] = sum_n dO[n][j] * qs[n][i];  same split structure as phase A.
 // part layout: [B][nsplit][H][1024 (accT[j][i])]
-template <typename T, int TOK>
-__global__ void linattn_dctx_partial(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ qstat,
-                                     float* __restrict__ part, int N, int d, int tokens_per_split) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [TOK][2d]: q | dO rows, then [TOK][H][2] stats
-  const int H = d / DK;
+template <typename T, int D>
+__global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                             const float* __restrict__ qstat, float* __restrict__ part, int N,
+                                                             int tokens_per_split) {
+  constexpr int H = D / DK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // q tile | dO tile | row stats
+  float* sq = smem;
+  float* sg = smem + TOK * D;
+  float* st = smem + 2 * TOK * D;
   const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int n_begin = sp * tokens_per_split;
   const int n_end = min(N, n_begin + tokens_per_split);
-  const int row = 2 * d;
-  float* st = smem + TOK * row;
+  const T* qb = qkv + (long long)b * N * 3 * D;
+  const T* gb = dout + (long long)b * N * D;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  RowTile<T, D, D, D> tq, tg;
+  tq.load(qb, 3 * D, 0, n_begin, n_end, tid);
+  tg.load(gb, D, 0, n_begin, n_end, tid);
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
     __syncthreads();
-    for (int i = tid; i < TOK * d / 4; i += blockDim.x) {
-      const int t = i / (d / 4), c = (i % (d / 4)) * 4;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f), g = q;
-      if (n0 + t < n_end) {
-        q = Vec4<T>::load(qkv + ((long long)b * N + n0 + t) * 3 * d + c);
-        g = Vec4<T>::load(dout + ((long long)b * N + n0 + t) * d + c);
-      }
-      *reinterpret_cast<float4*>(&smem[t * row + c]) = q;
-      *reinterpret_cast<float4*>(&smem[t * row + d + c]) = g;
-    }
-    for (int i = tid; i < TOK * H * 2; i += blockDim.x) {
-      const int t = i / (H * 2);
-      st[i] = (n0 + t < n_end) ? qstat[((long long)b * N + n0) * H * 2 + i] : 0.f;
-    }
+    tq.store(sq, tid);
+    tg.store(sg, tid);
+    if (tid < TOK * H * 2) st[tid] = (n0 + tid / (H * 2) < n_end) ? qstat[((long long)b * N + n0) * H * 2 + tid] : 0.f;
     __syncthreads();
+    if (n0 + TOK < n_end) {
+      tq.load(qb, 3 * D, 0, n0 + TOK, n_end, tid);
+      tg.load(gb, D, 0, n0 + TOK, n_end, tid);
+    }
     const int ntok = min(TOK, n_end - n0);
-#pragma unroll 4
+#pragma unroll
     for (int t0 = 0; t0 < TOK; t0 += 2) {
       const int t = t0 + lh;
       float qv = 0.f, gv = 0.f;
       if (t < ntok) {
-        qv = __expf(smem[t * row + wave * DK + li] - st[(t * H + wave) * 2]) * st[(t * H + wave) * 2 + 1];
-        gv = smem[t * row + d + wave * DK + li];
+        qv = __expf(sq[t * D + wave * DK + li] - st[(t * H + wave) * 2]) * st[(t * H + wave) * 2 + 1];
+        gv = sg[t * D + wave * DK + li];
       }
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, qv, acc, 0, 0, 0);
     }
@@ -255,14 +338,15 @@ __global__ void linattn_dctx_partial(const T* __restrict__ qkv, const T* __restr
 }
 
 // grid (B*H), block 1024: dctx[bh][i][j] = sum_s partT[s][j][i];  tvec[bh][i] = sum_j dctx[i][j]*ctx[i][j]
-__global__ void linattn_dctx_combine(const float* __restrict__ part, const float* __restrict__ ctx, float* __restrict__ dctx,
-                                     float* __restrict__ tvec, int nsplit, int H) {
+__global__ void __launch_bounds__(1024) linattn_dctx_combine(const float* __restrict__ part, const float* __restrict__ ctx,
+                                                             float* __restrict__ dctx, float* __restrict__ tvec, int nsplit, int H) {
   __shared__ float sm[32][33];
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const float* p0 = part + ((long long)b * nsplit * H + h) * 1024;
   {
     const int ii = threadIdx.x & 31, jj = threadIdx.x >> 5;   // coalesced over the split partials partT[jj][ii]
     float a = 0.f;
+#pragma unroll 8
     for (int s = 0; s < nsplit; ++s) a += p0[(long long)s * H * 1024 + jj * 32 + ii];
     sm[jj][ii] = a;
   }
@@ -280,52 +364,52 @@ __global__ void linattn_dctx_combine(const float* __restrict__ part, const float
 //   dqsT[i][t] = sum_j ctx[i][j] dO[t][j]      dq[t][i] = qs[t][i] (dqsT[i][t] - sum_i' p[t][i'] dqsT[i'][t])
 //   dvT[j][t]  = sum_i dctx[i][j] P[t][i]
 //   dPT[i][t]  = sum_j dctx[i][j] v[t][j]      dk[t][i] = P[t][i] (dPT[i][t] - tvec[i])
-// writes dqkv [B*N][3d] (dq | dk | dv)
-template <typename T>
-__global__ void linattn_bwd_apply(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ ctx,
-                                  const float* __restrict__ dctx, const float* __restrict__ stats,
-                                  const float* __restrict__ tvec, const float* __restrict__ qstat, T* __restrict__ dqkv,
-                                  int N, int d, int tokb) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [32][3d+1] qkv tile (reused for dqkv), [32][d+1] dO tile
-  const int H = d / DK;
+// writes dqkv [B*N][3d] (dq | dk | dv).  Same k-index convention and LDS row format as linattn_apply.
+template <typename T, int D>
+__global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                          const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                          const float* __restrict__ stats, const float* __restrict__ tvec,
+                                                          const float* __restrict__ qstat, T* __restrict__ dqkv, int N, int tokb) {
+  constexpr int H = D / DK, LD3 = 3 * D + 4, LD1 = D + 4, NTHR = 2 * D, W = GVec<T>::W;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [32][LD3] qkv tile (reused for dqkv), [32][LD1] dO, [H][96] stats
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int ld3 = 3 * d + 1, ld1 = d + 1;
-  float* gt = smem + 32 * ld3;
+  float* gt = smem + TOK * LD3;
+  float* cs = gt + TOK * LD1 + wave * 96;      // this head's column max | 1/colsum | tvec
   const long long bh = (long long)b * H + wave;
-  // A operands (rows on lanes):  ctxA[s] = ctx[i=li][j=2s+half];  dcA[s] = dctx[i=li][j=2s+half];
-  //                              dcT[s]  = dctx[i=2s+half][j=li]
+  if (lane < 32) {
+    cs[lane] = stats[bh * 64 + lane];
+    cs[32 + lane] = 1.f / stats[bh * 64 + 32 + lane];
+    cs[64 + lane] = tvec[bh * 32 + lane];
+  }
+  // A operands (rows on lanes), k-index ch(s,lh) = 16*lh + s:
+  //   ctxA[s] = ctx[i=li][j=ch];  dcA[s] = dctx[i=li][j=ch];  dcT[s] = dctx[i=ch][j=li]
   float ctxA[16], dcA[16], dcT[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    ctxA[s] = ctx[bh * 1024 + li * 32 + 2 * s + lh];
-    dcA[s] = dctx[bh * 1024 + li * 32 + 2 * s + lh];
-    dcT[s] = dctx[bh * 1024 + (2 * s + lh) * 32 + li];
+    ctxA[s] = ctx[bh * 1024 + li * 32 + 16 * lh + s];
+    dcA[s] = dctx[bh * 1024 + li * 32 + 16 * lh + s];
+    dcT[s] = dctx[bh * 1024 + (16 * lh + s) * 32 + li];
   }
-  const float* cst = stats + bh * 64;
-  const float* tv = tvec + bh * 32;
+  const T* qb = qkv + (long long)b * N * 3 * D;
+  const T* gb = dout + (long long)b * N * D;
 
   const int n_begin = blockIdx.x * tokb;
   const int n_end = min(N, n_begin + tokb);
-  for (int n0 = n_begin; n0 < n_end; n0 += 32) {
+  RowTile<T, D, 3 * D, LD3> tq;
+  RowTile<T, D, D, LD1> tg;
+  tq.load(qb, 3 * D, 0, n_begin, n_end, tid);
+  tg.load(gb, D, 0, n_begin, n_end, tid);
+  for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
     __syncthreads();
-    for (int i = tid; i < 32 * d; i += blockDim.x) {      // i over (t, 4-vector); 3d/4 + d/4 = d vectors per token
-      const int t = i / d, v4 = i % d;
-      const bool ok = n0 + t < n_end;
-      if (v4 < 3 * d / 4) {
-        const int c = v4 * 4;
-        float4 v = ok ? Vec4<T>::load(qkv + ((long long)b * N + n0 + t) * 3 * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float* dst = &smem[t * ld3 + c];
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-      } else {
-        const int c = (v4 - 3 * d / 4) * 4;
-        float4 v = ok ? Vec4<T>::load(dout + ((long long)b * N + n0 + t) * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float* dst = &gt[t * ld1 + c];
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-      }
+    tq.store(smem, tid);
+    tg.store(gt, tid);
+    __syncthreads();
+    if (n0 + TOK < n_end) {
+      tq.load(qb, 3 * D, 0, n0 + TOK, n_end, tid);
+      tg.load(gb, D, 0, n0 + TOK, n_end, tid);
     }
-    __syncthreads();
     const bool tok_ok = n0 + li < n_end;
     float rmax = 0.f, rinv = 0.f;
     if (tok_ok) {
@@ -333,72 +417,97 @@ __global__ void linattn_bwd_apply(const T* __restrict__ qkv, const T* __restrict
       rmax = qs[0];
       rinv = qs[1];
     }
-    const float* qrow = &smem[li * ld3 + wave * DK];
-    const float* krow = qrow + d;
-    const float* vrow = qrow + 2 * d;
-    const float* grow = &gt[li * ld1 + wave * DK];
+    const float* qrow = &smem[li * LD3 + wave * DK];
+    const float* krow = qrow + D;
+    const float* vrow = qrow + 2 * D;
+    const float* grow = &gt[li * LD1 + wave * DK];
 
-    // B operands with the token on the lane: element index kk = 2s+half
+    // B operands with the token on the lane: channels 16*lh + s
+    float gj[16], kk[16], vj[16];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 a = *reinterpret_cast<const float4*>(grow + 16 * lh + 4 * q4);
+      const float4 c = *reinterpret_cast<const float4*>(krow + 16 * lh + 4 * q4);
+      const float4 e = *reinterpret_cast<const float4*>(vrow + 16 * lh + 4 * q4);
+      gj[4 * q4] = a.x; gj[4 * q4 + 1] = a.y; gj[4 * q4 + 2] = a.z; gj[4 * q4 + 3] = a.w;
+      kk[4 * q4] = c.x; kk[4 * q4 + 1] = c.y; kk[4 * q4 + 2] = c.z; kk[4 * q4 + 3] = c.w;
+      vj[4 * q4] = e.x; vj[4 * q4 + 1] = e.y; vj[4 * q4 + 2] = e.z; vj[4 * q4 + 3] = e.w;
+    }
     f32x16 aq, av, ak;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { aq[r] = 0.f; av[r] = 0.f; ak[r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int kk = 2 * s + lh;
-      const float gj = grow[kk];                                           // dO[t][j=kk]
-      const float pk = __expf(krow[kk] - cst[kk]) / cst[32 + kk];          // P[t][i=kk]
-      const float vj = vrow[kk];                                           // v[t][j=kk]
-      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(ctxA[s], gj, aq, 0, 0, 0);  // dqsT[i][t]
-      av = __builtin_amdgcn_mfma_f32_32x32x2f32(dcT[s], pk, av, 0, 0, 0);   // dvT[j][t]   (A[row=j][kk=i] = dctx[i][j])
-      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(dcA[s], vj, ak, 0, 0, 0);   // dPT[i][t]
+      const int ch = 16 * lh + s;
+      const float pk = __expf(kk[s] - cs[ch]) * cs[32 + ch];                  // P[t][i=ch]
+      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(ctxA[s], gj[s], aq, 0, 0, 0);  // dqsT[i][t]
+      av = __builtin_amdgcn_mfma_f32_32x32x2f32(dcT[s], pk, av, 0, 0, 0);      // dvT[j][t]   (A[row=j][kk=i] = dctx[i][j])
+      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(dcA[s], vj[s], ak, 0, 0, 0);   // dPT[i][t]
     }
-    // registers now hold rows idx(r) = (r&3) + 8*(r>>2) + 4*half for token li
+    // registers hold rows idx(r) = (r&3) + 8*(r>>2) + 4*half of token li: 4 groups of 4 contiguous channels
     float dot = 0.f;
-    float qsv[16];
+    float qsv[16], pkv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      qsv[r] = __expf(qrow[i] - rmax) * rinv;                 // qs[t][i] = p/sqrt(32)
-      dot += qsv[r] * aq[r];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int i0 = 8 * g4 + 4 * lh;
+      const float4 qv = *reinterpret_cast<const float4*>(qrow + i0);
+      const float4 kv = *reinterpret_cast<const float4*>(krow + i0);
+      const float qa[4] = {qv.x, qv.y, qv.z, qv.w}, ka[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        qsv[r] = __expf(qa[e] - rmax) * rinv;                 // qs[t][i] = p/sqrt(32)
+        pkv[r] = __expf(ka[e] - cs[i0 + e]) * cs[32 + i0 + e];
+        dot += qsv[r] * aq[r];
+      }
     }
     dot += xhalf(dot);
     dot *= 5.65685424949238019521f;                           // sum_i p_i dqs_i = sqrt(32) * sum_i qs_i dqs_i
-    float dqv[16], dkv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      dqv[r] = qsv[r] * (aq[r] - dot);
-      const float pk = __expf(krow[i] - cst[i]) / cst[32 + i];
-      dkv[r] = pk * (ak[r] - tv[i]);
-    }
     __syncthreads();   // all waves finished reading the staged tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      smem[li * ld3 + wave * DK + i] = dqv[r];
-      smem[li * ld3 + d + wave * DK + i] = dkv[r];
-      smem[li * ld3 + 2 * d + wave * DK + i] = av[r];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int i0 = 8 * g4 + 4 * lh;
+      float4 oq, ok4, ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        f4at(oq, e) = qsv[r] * (aq[r] - dot);
+        f4at(ok4, e) = pkv[r] * (ak[r] - cs[64 + i0 + e]);
+        f4at(ov, e) = av[r];
+      }
+      *reinterpret_cast<float4*>(&smem[li * LD3 + wave * DK + i0]) = oq;
+      *reinterpret_cast<float4*>(&smem[li * LD3 + D + wave * DK + i0]) = ok4;
+      *reinterpret_cast<float4*>(&smem[li * LD3 + 2 * D + wave * DK + i0]) = ov;
     }
     __syncthreads();
-    for (int i = tid; i < 32 * 3 * d / 4; i += blockDim.x) {
-      const int t = i / (3 * d / 4), c = (i % (3 * d / 4)) * 4;
-      if (n0 + t < n_end) {
-        const float* src = &smem[t * ld3 + c];
-        Vec4<T>::store(dqkv + ((long long)b * N + n0 + t) * 3 * d + c, make_float4(src[0], src[1], src[2], src[3]));
-      }
+    constexpr int VPR = 3 * D / W;
+#pragma unroll
+    for (int p = 0; p < (TOK * VPR + NTHR - 1) / NTHR; ++p) {
+      const int idx = tid + p * NTHR;
+      const int t = idx / VPR, c = (idx % VPR) * W;
+      if (idx < TOK * VPR && n0 + t < n_end) GVec<T>::from_lds(dqkv + ((long long)b * N + n0 + t) * 3 * D + c, &smem[t * LD3 + c]);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 static int pick_splits(int B, int N, int* tokens_per_split) {
-  int want = 1024 / (B > 0 ? B : 1);
+  // ~256..512 streaming workgroups in total, whole 32-token tiles each
+  int want = 512 / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   int tps = (N + want - 1) / want;
-  if (tps < 64) tps = 64;
   tps = (tps + 31) / 32 * 32;
+  if (tps < 32) tps = 32;
   *tokens_per_split = tps;
   return (N + tps - 1) / tps;
+}
+// tokens per workgroup of the per-token kernels: ~512 workgroups, whole tiles
+static int pick_tokb(int B, int N) {
+  long long per = ((long long)B * N + 511) / 512;
+  int tokb = (int)((per + 31) / 32 * 32);
+  if (tokb < 32) tokb = 32;
+  if (tokb > 512) tokb = 512;
+  return tokb;
 }
 
 extern "C" int ltu_linattn_splits(int B, int N) {
@@ -406,21 +515,36 @@ extern "C" int ltu_linattn_splits(int B, int N) {
   return pick_splits(B, N, &tps);
 }
 
+#define LA_DISPATCH_D(d, ...)                                   \
+  do {                                                          \
+    if ((d) == 32) { constexpr int D = 32; __VA_ARGS__ }        \
+    else if ((d) == 64) { constexpr int D = 64; __VA_ARGS__ }   \
+    else if ((d) == 128) { constexpr int D = 128; __VA_ARGS__ } \
+    else if ((d) == 256) { constexpr int D = 256; __VA_ARGS__ } \
+    else return LTU_E_SHAPE;                                    \
+  } while (0)
+
 extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws,
                                int B, int N, int d, int dtype, ltu_stream_t s) {
-  if (d % 32 != 0 || d < 32 || d > 512) return LTU_E_SHAPE;
   const int H = d / 32;
   int tps;
   const int nsplit = pick_splits(B, N, &tps);
   hipStream_t st = (hipStream_t)s;
-  constexpr int TOK = 32;
-  const size_t lds_a = (size_t)TOK * 2 * d * sizeof(float);
-  const size_t lds_b = (size_t)32 * (d + 1) * sizeof(float);
-  const int tokb = 128;
+  const int tokb = pick_tokb(B, N);
   LTU_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((linattn_kv_partial<T, TOK>), dim3(nsplit, B), dim3(H * 64), lds_a, st, (const T*)qkv, part_ws, N, d, tps);
-    hipLaunchKernelGGL(linattn_kv_combine, dim3(B * H), dim3(1024), 0, st, part_ws, colstats, ctx, nsplit, H);
-    hipLaunchKernelGGL((linattn_apply<T>), dim3(cdiv(N, tokb), B), dim3(H * 64), lds_b, st, (const T*)qkv, ctx, (T*)out, qstat, N, d, tokb);
+    LA_DISPATCH_D(d, {
+      hipLaunchKernelGGL((linattn_kv_partial<T, D>), dim3(nsplit, B), dim3(2 * D), 0, st, (const T*)qkv, part_ws, N, tps);
+      // two-level merge of the split partials (level-1 results live behind the level-0 partials in part_ws)
+      const int group = 16, ngroups = (nsplit + group - 1) / group;
+      float* part2 = part_ws + (size_t)B * nsplit * H * PART_STRIDE;
+      if (ngroups > 1) {
+        hipLaunchKernelGGL(linattn_kv_combine, dim3(ngroups, B * H), dim3(1024), 0, st, part_ws, nsplit, group, part2, colstats, ctx, H, 0);
+        hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part2, ngroups, ngroups, nullptr, colstats, ctx, H, 1);
+      } else {
+        hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part_ws, nsplit, nsplit, nullptr, colstats, ctx, H, 1);
+      }
+      hipLaunchKernelGGL((linattn_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), 0, st, (const T*)qkv, ctx, (T*)out, qstat, N, tokb);
+    });
   });
   return ltu_check_launch();
 }
@@ -428,19 +552,18 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
 extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const float* colstats,
                                const float* qstat, void* dqkv, float* dctx, float* tvec, float* part_ws, int B, int N,
                                int d, int dtype, ltu_stream_t s) {
-  if (d % 32 != 0 || d < 32 || d > 256) return LTU_E_SHAPE;
   const int H = d / 32;
   int tps;
   const int nsplit = pick_splits(B, N, &tps);
   hipStream_t st = (hipStream_t)s;
-  constexpr int TOK = 32;
-  const size_t lds_a = (size_t)(TOK * 2 * d + TOK * H * 2) * sizeof(float);
-  const size_t lds_b = (size_t)(32 * (3 * d + 1) + 32 * (d + 1)) * sizeof(float);
-  const int tokb = 64;
+  const size_t lds_b = (size_t)(32 * (3 * d + 4) + 32 * (d + 4) + H * 96) * sizeof(float);
+  const int tokb = pick_tokb(B, N);
   LTU_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((linattn_dctx_partial<T, TOK>), dim3(nsplit, B), dim3(H * 64), lds_a, st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, d, tps);
-    hipLaunchKernelGGL(linattn_dctx_combine, dim3(B * H), dim3(1024), 0, st, part_ws, ctx, dctx, tvec, nsplit, H);
-    hipLaunchKernelGGL((linattn_bwd_apply<T>), dim3(cdiv(N, tokb), B), dim3(H * 64), lds_b, st, (const T*)qkv, (const T*)dout, ctx, dctx, colstats, tvec, qstat, (T*)dqkv, N, d, tokb);
+    LA_DISPATCH_D(d, {
+      hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float), st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);
+      hipLaunchKernelGGL(linattn_dctx_combine, dim3(B * H), dim3(1024), 0, st, part_ws, ctx, dctx, tvec, nsplit, H);
+      hipLaunchKernelGGL((linattn_bwd_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), lds_b, st, (const T*)qkv, (const T*)dout, ctx, dctx, colstats, tvec, qstat, (T*)dqkv, N, tokb);
+    });
   });
   return ltu_check_launch();
 }

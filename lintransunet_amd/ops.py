@@ -335,7 +335,7 @@ class _LinAttn(torch.autograd.Function):
         cx = torch.empty((B * H, 32, 32), device=dev, dtype=torch.float32)
         colstats = torch.empty((B * H, 64), device=dev, dtype=torch.float32)
         qstat = torch.empty((B * N, H, 2), device=dev, dtype=torch.float32)
-        ws = torch.empty(B * nsplit * H * 1088, device=dev, dtype=torch.float32)
+        ws = torch.empty(B * (nsplit + nsplit // 16 + 2) * H * 1088, device=dev, dtype=torch.float32)
         _lib.call('ltu_linattn_fwd', _p(qkv), _p(out), _p(cx), _p(colstats), _p(qstat), _p(ws), B, N, d, _dt(qkv), _s())
         ctx.save_for_backward(qkv, cx, colstats, qstat)
         ctx.cfg = (B, N, d, nsplit)
