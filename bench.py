@@ -113,7 +113,7 @@ def main():
 
     # live timing of the dominant kernel family (the dense projections of the transformers)
     timer = KernelTimer()
-    ops._Linear.forward = staticmethod(timer.wrap(ops._Linear.forward, lambda ctx, x, *wb: 2.0 * x.shape[0] * x.shape[1] *
+    ops._Linear.forward = staticmethod(timer.wrap(ops._Linear.forward, lambda ctx, x, prep, *wb: 2.0 * x.shape[0] * x.shape[1] *
                                                   sum(w.shape[0] for w in wb[:len(wb) // 2])))
 
     def step(i):

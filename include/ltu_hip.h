@@ -49,6 +49,11 @@ int ltu_unpack_conv_wgrad(const float* dwf, float* dw, int Co, int Ci, int CiP, 
 int ltu_transpose_f32(const float* in, void* out, int R, int C, int ldo, int col_off, int out_dtype, ltu_stream_t s);
 /* out[i] = (out_dtype) in[i] */
 int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_stream_t s);
+/* All of the above for a whole model in ONE launch.  table: n device-resident 40-byte records
+ * { const float* src; void* dst; int kind, R, C, p0, p1, pad; } with kind 0 = cast (R*C elements),
+ * 1 = transpose ([R][C] -> dst[c*p0 + p1 + r]), 2 = pack wf ([R=Co][C=Ci][27] -> [p0=CoP][27][p1=CiP]),
+ * 3 = pack wd (-> [p1=CiP][27][p0=CoP]), 4 = fp32 copy of R*C elements (padded biases). */
+int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
 
 /* ---- dense projections: nn.Linear (model/trans_block.py:144,156,166,187,189) and 1x1x1 convs
  *      (model/Unet_3Dblock.py:200-215).  y[M,N] (+)= a[M,K] . w[N,K]^T + bias;  w in the activation dtype, bias fp32.
@@ -71,9 +76,12 @@ int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* 
  * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
 int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,
                      int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s);
-/* weight gradient into the packed layout dwf [Co][27][C0+C1] (+=, caller zero-fills), db[Co] += */
+/* weight gradient (+=, the caller zero-fills): torch_co == 0: into the packed layout dwf [Co][27][C0+C1];
+ * torch_co != 0: straight into a PyTorch-layout gradient [torch_co][torch_ci][3][3][3] (padded rows/channels dropped).
+ * db[Co] += column sums of g. */
 int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi, int Wi,
-                     int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype, ltu_stream_t s);
+                     int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co, int torch_ci, int dtype,
+                     ltu_stream_t s);
 /* y[b,h,w,d,c] = sum of the 2x2x2 children of x [B,2H,2W,2D,C] (adjoint of nearest x2 upsampling) */
 int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int dtype, ltu_stream_t s);
 

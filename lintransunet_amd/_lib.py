@@ -24,7 +24,8 @@ SIGNATURES = {
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P],
     'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
-    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_weight_prep': [P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],
     'ltu_linattn_splits': [I, I],
     'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],

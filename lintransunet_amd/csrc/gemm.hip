@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_kernel(const WGradArgs w
     __syncthreads();
   }
 
-  if (do_bias && tid < BNn && n_blk + tid < g.N) atomicAdd(wa.db + n_blk + tid, bsum);
+  if (do_bias && tid < BNn && n_blk + tid < (wa.t_co ? wa.t_co : g.N)) atomicAdd(wa.db + n_blk + tid, bsum);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int k = k_blk + (wn * TN + j) * 32 + li;
@@ -289,12 +289,17 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_kernel(const WGradArgs w
     const int slot = k / g.C;
     const int c = k - slot * g.C;
     const long long wk = (long long)g.tap[slot].wt * g.C + c;
+    const int wt = g.tap[slot].wt;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < g.N) atomicAdd(wa.dw + (long long)n * g.wrow + wk, acc[i][j][r]);
+        if (wa.t_co) {
+          if (n < wa.t_co && c < wa.t_ci) atomicAdd(wa.dw + ((long long)n * wa.t_ci + c) * 27 + wt, acc[i][j][r]);
+        } else if (n < g.N) {
+          atomicAdd(wa.dw + (long long)n * g.wrow + wk, acc[i][j][r]);
+        }
       }
     }
   }
@@ -374,7 +379,7 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
   WGradArgs wa;
   dense_desc(wa.g, M, N, K);
   wa.g.a0 = a; wa.g.a1 = a; wa.g.lda0 = lda; wa.g.lda1 = lda;
-  wa.grad = grad; wa.ldg = ldg; wa.dw = dw; wa.db = db;
+  wa.grad = grad; wa.ldg = ldg; wa.dw = dw; wa.db = db; wa.t_co = 0; wa.t_ci = 0;
   if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_tn<float>(wa, (hipStream_t)s);
@@ -418,15 +423,15 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
 }
 
 extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi,
-                                int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype,
-                                ltu_stream_t s) {
+                                int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co,
+                                int torch_ci, int dtype, ltu_stream_t s) {
   WGradArgs wa;
   int Ho, Wo, Do;
   int rc = conv_fwd_desc(wa.g, B, Hi, Wi, Di, C0, C1, Co, sh, sw, sd, ups, &Ho, &Wo, &Do);
   if (rc) return rc;
   if (Co % 4 != 0) return LTU_E_SHAPE;
   wa.g.a0 = x0; wa.g.a1 = x1 ? x1 : x0;
-  wa.grad = grad; wa.ldg = Co; wa.dw = dwf; wa.db = db;
+  wa.grad = grad; wa.ldg = Co; wa.dw = dwf; wa.db = db; wa.t_co = torch_co; wa.t_ci = torch_ci;
   if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_tn<float>(wa, (hipStream_t)s);

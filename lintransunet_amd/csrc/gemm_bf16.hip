@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
     __syncthreads();
   }
 
-  if (do_bias && tid < BNn && n_blk + tid < g.N) atomicAdd(wa.db + n_blk + tid, bsum);
+  if (do_bias && tid < BNn && n_blk + tid < (wa.t_co ? wa.t_co : g.N)) atomicAdd(wa.db + n_blk + tid, bsum);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int k = k_blk + (wn * TN + j) * 32 + li;
@@ -480,12 +480,17 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
     const int slot = k / g.C;
     const int c = k - slot * g.C;
     const long long wk = (long long)g.tap[slot].wt * g.C + c;
+    const int wt = g.tap[slot].wt;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < g.N) atomicAdd(wa.dw + (long long)n * g.wrow + wk, acc[i][j][r]);
+        if (wa.t_co) {
+          if (n < wa.t_co && c < wa.t_ci) atomicAdd(wa.dw + ((long long)n * wa.t_ci + c) * 27 + wt, acc[i][j][r]);
+        } else if (n < g.N) {
+          atomicAdd(wa.dw + (long long)n * g.wrow + wk, acc[i][j][r]);
+        }
       }
   }
 }

@@ -53,7 +53,8 @@ struct WGradArgs {
   int ldg;
   float* dw;          // [N][wrow]
   float* db;          // may be null
-  int rows_per_split; // multiple of 16
+  int rows_per_split; // multiple of the tile's row count
+  int t_co, t_ci;     // != 0: dw is a PyTorch conv weight gradient [t_co][t_ci][27] (padded rows/channels are dropped)
 };
 
 

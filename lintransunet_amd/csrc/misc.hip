@@ -1,3 +1,55 @@
+// Library version + the batched weight-operand preparation (one launch per step for the whole model).
 #include "common.h"
 
-extern "C" int ltu_version(void) { return 1; }
+extern "C" int ltu_version(void) { return 2; }
+
+// One descriptor per prepared operand.  kinds:
+//   0  cast        dst[i] = src[i]                                  R*C elements
+//   1  transpose   dst[c*p0 + p1 + r] = src[r*C + c]                src [R][C]  (p0 = ld of dst, p1 = column offset)
+//   2  pack_f      conv [R=Co][C=Ci][27] -> dst [p0=CoP][27][p1=CiP] zero padded
+//   3  pack_d      conv [R=Co][C=Ci][27] -> dst [p1=CiP][27][p0=CoP] zero padded
+//   4  copy_f32    dst[i] = src[i] as fp32 whatever the operand dtype (padded biases)      R*C elements
+struct WPrep {
+  const float* src;
+  void* dst;
+  int kind, R, C, p0, p1, pad;
+};
+
+template <typename TW>
+__global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
+  const WPrep d = table[blockIdx.y];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  TW* dst = reinterpret_cast<TW*>(d.dst);
+  if (d.kind == 0) {
+    const long long n = (long long)d.R * d.C;
+    for (long long i = t0; i < n; i += stride) st1<TW>(dst + i, d.src[i]);
+  } else if (d.kind == 4) {
+    const long long n = (long long)d.R * d.C;
+    for (long long i = t0; i < n; i += stride) reinterpret_cast<float*>(d.dst)[i] = d.src[i];
+  } else if (d.kind == 1) {
+    const long long n = (long long)d.R * d.C;
+    for (long long i = t0; i < n; i += stride) {       // i enumerates the DESTINATION (coalesced writes; sources are L2-resident)
+      const int r = (int)(i % d.R), c = (int)(i / d.R);
+      st1<TW>(dst + (long long)c * d.p0 + d.p1 + r, d.src[(long long)r * d.C + c]);
+    }
+  } else {
+    const int CoP = d.p0, CiP = d.p1;
+    const long long n = (long long)CoP * 27 * CiP;
+    for (long long i = t0; i < n; i += stride) {
+      int co, ci, t;
+      if (d.kind == 2) { ci = (int)(i % CiP); t = (int)((i / CiP) % 27); co = (int)(i / ((long long)CiP * 27)); }
+      else { co = (int)(i % CoP); t = (int)((i / CoP) % 27); ci = (int)(i / ((long long)CoP * 27)); }
+      const float v = (co < d.R && ci < d.C) ? d.src[((long long)co * d.C + ci) * 27 + t] : 0.f;
+      st1<TW>(dst + i, v);
+    }
+  }
+}
+
+extern "C" int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s) {
+  if (n <= 0) return LTU_OK;
+  LTU_DISPATCH_T(out_dtype, {
+    hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(16, n), dim3(256), 0, (hipStream_t)s, (const WPrep*)table);
+  });
+  return ltu_check_launch();
+}

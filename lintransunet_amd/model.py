@@ -31,12 +31,6 @@ class _Group(nn.Module):
     """anonymous parameter container"""
 
 
-def _conv_pair(cin, cout):
-    g = _Group()
-    g.conv1 = nn.Conv3d(cin, cin if cout is None else cout[0], 3, padding=1)
-    return g
-
-
 def _transformer_layer(d):
     """parameter names of model/trans_block.py:127-211"""
     lay = _Group()
@@ -65,6 +59,67 @@ class _SeedStream:
     def next(self):
         self.n += 1
         return (self.base << 20) + self.n
+
+
+class _WeightStore:
+    """Every GEMM weight operand of the model in the activation dtype, refreshed by ONE kernel launch per step.
+
+    conv: wf [CoP][27][CiP] + wd [CiP][27][CoP] (+ a padded fp32 bias for the mask heads);
+    linear / 1x1x1 conv groups: forward operands (bf16 copies; the fp32 masters themselves in fp32 mode) and cat(W)^T.
+    """
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.recs = []          # (src, dst, kind, R, C, p0, p1)
+        self.conv, self.lin = {}, {}
+        self.table = None
+
+    def add_conv(self, conv, cip=None, cop=None):
+        w = conv.weight
+        Co, Ci = w.shape[0], w.shape[1]
+        cip, cop = cip or Ci, cop or Co
+        wf = torch.empty((cop, 27, cip), device=self.device, dtype=self.dtype)
+        wd = torch.empty((cip, 27, cop), device=self.device, dtype=self.dtype)
+        self.recs.append((w, wf, 2, Co, Ci, cop, cip))
+        self.recs.append((w, wd, 3, Co, Ci, cop, cip))
+        bias = conv.bias
+        if cop != Co:
+            bias = torch.zeros(cop, device=self.device, dtype=torch.float32)
+            self.recs.append((conv.bias, bias, 4, 1, Co, 0, 0))
+        self.conv[id(conv)] = ops.ConvPrep(wf, wd, bias)
+
+    def add_linear(self, key, weights):
+        """weights: list of [N,K(,1,1,1)] parameters sharing K (a fused q,k,v group or a single projection)"""
+        N, K = weights[0].shape[0], weights[0].shape[1]
+        if self.dtype == torch.float32:
+            fw = list(weights)
+        else:
+            fw = []
+            for w in weights:
+                c = torch.empty((N, K), device=self.device, dtype=self.dtype)
+                self.recs.append((w, c, 0, N, K, 0, 0))
+                fw.append(c)
+        wt = torch.empty((K, N * len(weights)), device=self.device, dtype=self.dtype)
+        for i, w in enumerate(weights):
+            self.recs.append((w, wt, 1, N, K, N * len(weights), i * N))
+        self.lin[key] = ops.LinPrep(fw, wt)
+
+    def finalize(self):
+        import numpy as np
+        rec = np.zeros(len(self.recs), dtype=[('src', '<u8'), ('dst', '<u8'), ('kind', '<i4'), ('R', '<i4'), ('C', '<i4'),
+                                              ('p0', '<i4'), ('p1', '<i4'), ('pad', '<i4')])
+        for i, (src, dst, kind, R, C, p0, p1) in enumerate(self.recs):
+            rec[i] = (src.data_ptr(), dst.data_ptr(), kind, R, C, p0, p1, 0)
+        self.ptrs = [(src.data_ptr(), dst.data_ptr()) for src, dst, *_ in self.recs]
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+
+    def stale(self):
+        """parameter storage moved (e.g. .to(), load with assign): the table must be rebuilt"""
+        return any(src.data_ptr() != p0 for (src, *_), (p0, _) in zip(self.recs, self.ptrs))
+
+    def refresh(self):
+        ops._lib.call('ltu_weight_prep', self.table.data_ptr(), len(self.recs), ops.F32 if self.dtype == torch.float32 else ops.BF16,
+                      torch.cuda.current_stream().cuda_stream)
 
 
 class MaskTransUnet(nn.Module):
@@ -126,22 +181,63 @@ class MaskTransUnet(nn.Module):
             dec.block_list.append(blk)
         dec.final_block = nn.Conv3d(L[0], dim_output * 4, 3, padding=1)
         self.last_boxes = []
+        self._store = None
+
+    # ------------------------------------------------------------------ prepared weight operands
+    def _weights(self, device):
+        st = self._store
+        if st is not None and st.device == device and st.dtype == self.act_dtype and not st.stale():
+            return st
+        st = _WeightStore(device, self.act_dtype)
+        enc, dec = self.encode, self.decode
+        st.add_conv(enc.input_block, cip=8)
+        for blk in enc.block_list:
+            st.add_conv(blk.conv1)
+            st.add_conv(blk.conv2)
+        head_pad = 4 if self.act_dtype == torch.float32 else 8
+        for mc in dec.mask_conv_list:
+            st.add_conv(mc, cop=head_pad)
+        for blk in dec.block_list:
+            st.add_conv(blk.conv1)
+            st.add_conv(blk.conv2)
+        st.add_conv(dec.final_block)
+        for ag in dec.att_conv_list:
+            st.add_linear(id(ag.W_x[0]), [ag.W_x[0].weight])
+            st.add_linear(id(ag.W_g[0]), [ag.W_g[0].weight])
+        for br in dec.bridge_list:
+            if not hasattr(br, 'transformer'):
+                continue
+            tr = br.transformer
+            if hasattr(tr, 'down_embed'):
+                st.add_conv(tr.down_embed.module_list[0][0])
+                st.add_conv(tr.up_embed.module_list[0][1])
+            for lay in tr.layers:
+                lin = lay.self_attn.linears
+                st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight])
+                st.add_linear((id(lay), 'o'), [lin[3].weight])
+                st.add_linear((id(lay), 'f1'), [lay.linear1.weight])
+                st.add_linear((id(lay), 'f2'), [lay.linear2.weight])
+        st.finalize()
+        self._store = st
+        return st
 
     # ------------------------------------------------------------------ pieces
     def _conv_in_act(self, x, conv, stride=(1, 1, 1), res=None, p=0.0, seeds=None, x1=None, ups=False):
-        y = ops.conv3d(x, conv.weight, conv.bias, stride=stride, x1=x1, ups=ups)
+        y = ops.conv3d(x, conv.weight, conv.bias, stride=stride, x1=x1, ups=ups, prep=self._store.conv[id(conv)])
         return ops.instnorm_act(y, res=res, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0)
 
     def _layer(self, lay, t, B, N, d, p, seeds):
         """post-norm transformer layer on tokens t [B*N, d] (model/trans_block.py:148-166, 203-211)"""
         lin = lay.self_attn.linears
-        qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias])
+        wl = self._store.lin
+        qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
+                         prep=wl[(id(lay), 'qkv')])
         a = ops.linear_attention(qkv, B, N, d)
-        a = ops.linear(a, [lin[3].weight], [lin[3].bias])
+        a = ops.linear(a, [lin[3].weight], [lin[3].bias], prep=wl[(id(lay), 'o')])
         t = ops.res_layernorm(t, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0)
-        f = ops.linear(t, [lay.linear1.weight], [lay.linear1.bias])
+        f = ops.linear(t, [lay.linear1.weight], [lay.linear1.bias], prep=wl[(id(lay), 'f1')])
         f = ops.gelu_dropout(f, p, seeds.next() if p > 0 else 0)
-        f = ops.linear(f, [lay.linear2.weight], [lay.linear2.bias])
+        f = ops.linear(f, [lay.linear2.weight], [lay.linear2.bias], prep=wl[(id(lay), 'f2')])
         return ops.res_layernorm(t, f, lay.layer_norm2.weight, lay.layer_norm2.bias, 1e-6, p, seeds.next() if p > 0 else 0)
 
     def _token_transformer(self, layers, pos, x, p, seeds):
@@ -182,6 +278,8 @@ class MaskTransUnet(nn.Module):
         if H % 2 or W % 2:
             raise ValueError('H and W must be even')
         enc, dec = self.encode, self.decode
+        store = self._weights(x.device)
+        store.refresh()                      # one launch: every cast / transposed / repacked weight of this step
 
         t = ops.window_embed(x.contiguous().float(), self.act_dtype)
         t = self._conv_in_act(t, enc.input_block, seeds=seeds)
@@ -198,17 +296,18 @@ class MaskTransUnet(nn.Module):
             lvl = nl - 1 - i
             t = ops.trilinear_up(t, 2 if (nl - i) % 2 == 0 else 1)
             mc = dec.mask_conv_list[lvl]
-            m = ops.head_softmax(ops.conv3d(t, mc.weight, mc.bias, cop=4 if self.act_dtype == torch.float32 else 8), C)
+            m = ops.head_softmax(ops.conv3d(t, mc.weight, mc.bias, cop=4 if self.act_dtype == torch.float32 else 8,
+                                            prep=store.conv[id(mc)]), C)
             masks.append(m)
             ag = dec.att_conv_list[lvl]
             skip = ops.attention_gate(skips[-i], t, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,
-                                      ag.psi[0].weight, ag.psi[0].bias)
+                                      ag.psi[0].weight, ag.psi[0].bias, store.lin[id(ag.W_x[0])], store.lin[id(ag.W_g[0])])
             if self.is_roi_list[lvl]:
                 skip = self._roi_bridge(dec.bridge_list[lvl], skip, m.detach(), self.roi_size_list[lvl], p, seeds)
             blk = dec.block_list[i - 1]
             t = self._conv_in_act(t, blk.conv1, seeds=seeds)
             t = self._conv_in_act(t, blk.conv2, x1=skip, p=p, seeds=seeds)
-        z = ops.conv3d(t, dec.final_block.weight, dec.final_block.bias)
+        z = ops.conv3d(t, dec.final_block.weight, dec.final_block.bias, prep=store.conv[id(dec.final_block)])
         out = ops.final_softmax(z, C)
         if self.training:
             return _cl(out), [_cl(m) for m in masks]

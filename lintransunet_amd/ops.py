@@ -3,6 +3,15 @@
 Device tensors are channels-last: a reference tensor [B,C,H,W,D] is held as a contiguous
 [B,H,W,D,C] tensor (fp32 or bf16).  PyTorch only provides memory, streams and the autograd
 graph here; every arithmetic op is a HIP kernel from libltu_hip.so and there is no fallback.
+
+Three host-side mechanisms keep the launch count down:
+  * prepared weight operands (`prep=`): the model produces every cast / transposed / repacked weight of a
+    step with ONE `ltu_weight_prep` launch; without `prep` an op prepares its own operands per call.
+  * fused gradient accumulation: a parameter carrying `_ltu_grad` (an fp32 view into a flat gradient
+    buffer, installed by `train.GradReducer`) receives its gradient straight from the weight-gradient
+    kernels (`+=`), the Function returns None for it and calls `_ltu_hook(param)`.
+  * `scratch_zeros`: small zero-initialised statistics buffers come from one arena that is cleared with
+    a single fill per step instead of one `torch.zeros` launch each.
 """
 import ctypes
 
@@ -47,6 +56,70 @@ def _ptr_array(tensors):
     return arr
 
 
+# ---------------------------------------------------------------------------------------------- scratch arena
+
+class _Arena:
+    """Bump allocator over one fp32 buffer that is zero-filled once per step."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.need = 0
+
+    def begin_step(self, device):
+        if self.need > 0 and (self.buf is None or self.buf.numel() < self.need or self.buf.device != device):
+            self.buf = torch.empty(int(self.need * 1.25) + 1024, device=device, dtype=torch.float32)
+        if self.buf is not None:
+            self.buf.zero_()
+        self.off = 0
+        self.need = 0
+
+    def zeros(self, shape, device):
+        n = 1
+        for s in shape:
+            n *= s
+        n_al = (n + 63) // 64 * 64
+        self.need += n_al
+        if self.buf is not None and self.buf.device == device and self.off + n_al <= self.buf.numel():
+            out = self.buf[self.off:self.off + n].view(shape)
+            self.off += n_al
+            return out
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
+_ARENA = _Arena()
+
+
+def begin_step(device):
+    """Called by the model at the start of a training forward: recycles and clears the scratch arena."""
+    _ARENA.begin_step(device)
+
+
+def scratch_zeros(shape, device):
+    return _ARENA.zeros(tuple(shape), device)
+
+
+# ---------------------------------------------------------------------------------------------- gradients of parameters
+
+def _grad_buf(p):
+    """fp32 buffer the weight-gradient kernels accumulate into, and whether it is the parameter's fused buffer"""
+    tgt = getattr(p, '_ltu_grad', None)
+    if tgt is not None:
+        return tgt, True
+    return torch.zeros(p.shape, device=p.device, dtype=torch.float32), False    # handed to autograd: must own its memory
+
+
+def _grad_done(p, buf, fused):
+    if fused:
+        hook = getattr(p, '_ltu_hook', None)
+        if hook is not None:
+            hook(p)
+        return None
+    return buf
+
+
+# ---------------------------------------------------------------------------------------------- weight operands
+
 def _w_operand(w, dtype):
     """fp32 master weight -> GEMM operand in the activation dtype (same layout)"""
     if dtype == torch.float32:
@@ -64,6 +137,22 @@ def _w_transposed(ws, rows, cols, dtype):
     for i, w in enumerate(ws):
         _lib.call('ltu_transpose_f32', _p(w), _p(wt), rows, cols, n, i * rows, odt, _s())
     return wt
+
+
+class ConvPrep:
+    """prepared operands of one 3x3x3 conv: wf [CoP][27][CiP], wd [CiP][27][CoP] (activation dtype), bias [CoP] fp32"""
+    __slots__ = ('wf', 'wd', 'bias')
+
+    def __init__(self, wf, wd, bias):
+        self.wf, self.wd, self.bias = wf, wd, bias
+
+
+class LinPrep:
+    """prepared operands of a (group of) Linear / 1x1x1 conv weights: forward operands and cat(W)^T"""
+    __slots__ = ('w', 'wt')
+
+    def __init__(self, w, wt):
+        self.w, self.wt = w, wt
 
 
 # ---------------------------------------------------------------------------------------------- no-grad helpers
@@ -105,8 +194,8 @@ class RoiPlan:
         self.eval_h = int(1.2 * roi_size)
         self.eval_w = int(self.eval_h * 0.6)
         self.up_h, self.up_w = 2 * ((self.eval_h + 1) // 2), 2 * ((self.eval_w + 1) // 2)
-        self.ibuf = torch.zeros(ni.value, device=prob.device, dtype=torch.int32)
-        self.fbuf = torch.zeros(nf.value, device=prob.device, dtype=torch.float32)
+        self.ibuf = torch.empty(ni.value, device=prob.device, dtype=torch.int32)
+        self.fbuf = torch.empty(nf.value, device=prob.device, dtype=torch.float32)
         self.box = torch.empty((B, 6), device=prob.device, dtype=torch.float32)
         _lib.call('ltu_roi_plan', _p(prob), B, H, W, D, C, roi_size, float(thr), _p(self.box), _p(self.ibuf), _p(self.fbuf), _s())
 
@@ -115,7 +204,7 @@ class RoiPlan:
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, stride, ups, cop):
+    def forward(ctx, x0, x1, weight, bias, stride, ups, cop, prep):
         _chk(x0, 'x0')
         B, Hi, Wi, Di, C0 = x0.shape
         C1 = 0 if x1 is None else _chk(x1, 'x1').shape[-1]
@@ -123,26 +212,31 @@ class _Conv3d(torch.autograd.Function):
         CiP = C0 + C1
         assert CiP >= Ci and cop >= Co
         dev = x0.device
-        wf = torch.empty((cop, 27, CiP), device=dev, dtype=x0.dtype)
-        _lib.call('ltu_pack_conv_weight', _p(weight), _p(wf), 0, Co, Ci, cop, CiP, _dt(x0), _s())
-        bias_p = bias
-        if cop != Co:
-            bias_p = torch.zeros(cop, device=dev, dtype=torch.float32)
-            bias_p[:Co] = bias
+        if prep is None:
+            wf = torch.empty((cop, 27, CiP), device=dev, dtype=x0.dtype)
+            _lib.call('ltu_pack_conv_weight', _p(weight), _p(wf), 0, Co, Ci, cop, CiP, _dt(x0), _s())
+            bias_p = bias
+            if cop != Co:
+                bias_p = torch.zeros(cop, device=dev, dtype=torch.float32)
+                bias_p[:Co] = bias
+        else:
+            wf, bias_p = prep.wf, prep.bias
         sh, sw, sd = stride
         Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
         Ho, Wo, Do = (Hl - 1) // sh + 1, (Wl - 1) // sw + 1, (Dl - 1) // sd + 1
         y = torch.empty((B, Ho, Wo, Do, cop), device=dev, dtype=x0.dtype)
         _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias_p), _p(y), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
                   int(ups), _dt(x0), _s())
-        ctx.save_for_backward(x0, x1, weight)
-        ctx.cfg = (stride, ups, cop, C0, C1)
+        ctx.save_for_backward(x0, x1)
+        ctx.params = (weight, bias)
+        ctx.cfg = (stride, ups, cop, C0, C1, prep)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x0, x1, weight = ctx.saved_tensors
-        stride, ups, cop, C0, C1 = ctx.cfg
+        x0, x1 = ctx.saved_tensors
+        weight, bias = ctx.params
+        stride, ups, cop, C0, C1, prep = ctx.cfg
         g = g.contiguous()
         B, Hi, Wi, Di, _ = x0.shape
         Co, Ci = weight.shape[0], weight.shape[1]
@@ -153,8 +247,11 @@ class _Conv3d(torch.autograd.Function):
         dx0 = dx1 = None
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
         if need_dx:
-            wd = torch.empty((CiP, 27, cop), device=dev, dtype=x0.dtype)
-            _lib.call('ltu_pack_conv_weight', _p(weight), 0, _p(wd), Co, Ci, cop, CiP, dt, _s())
+            if prep is None:
+                wd = torch.empty((CiP, 27, cop), device=dev, dtype=x0.dtype)
+                _lib.call('ltu_pack_conv_weight', _p(weight), 0, _p(wd), Co, Ci, cop, CiP, dt, _s())
+            else:
+                wd = prep.wd
             Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
             d0 = torch.empty((B, Hl, Wl, Dl, C0), device=dev, dtype=x0.dtype)
             d1 = torch.empty((B, Hl, Wl, Dl, C1), device=dev, dtype=x0.dtype) if C1 else None
@@ -165,26 +262,24 @@ class _Conv3d(torch.autograd.Function):
             else:
                 dx0 = d0
             dx1 = d1
-        dwf = torch.zeros((cop, 27, CiP), device=dev, dtype=torch.float32)
-        dbp = torch.zeros(cop, device=dev, dtype=torch.float32)
-        _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dwf), _p(dbp), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
-                  int(ups), dt, _s())
-        dw = torch.empty_like(weight)
-        _lib.call('ltu_unpack_conv_wgrad', _p(dwf), _p(dw), Co, Ci, CiP, _s())
-        db = dbp[:Co].clone() if cop != Co else dbp
-        return dx0, dx1, dw, db, None, None, None
+        dw, fw = _grad_buf(weight)
+        db, fb = _grad_buf(bias)
+        # the weight gradient lands directly in the PyTorch layout [Co,Ci,3,3,3]; padded rows / channels are dropped
+        _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd, int(ups),
+                  Co, Ci, dt, _s())
+        return dx0, dx1, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None, None, None, None
 
 
-def conv3d(x0, weight, bias, stride=(1, 1, 1), x1=None, ups=False, cop=None):
+def conv3d(x0, weight, bias, stride=(1, 1, 1), x1=None, ups=False, cop=None, prep=None):
     """3x3x3 conv, padding 1, on channels-last x0 (+ virtual concat x1).  Output has `cop` (>= Co, padded) channels."""
-    return _Conv3d.apply(x0, x1, weight, bias, tuple(stride), bool(ups), cop or weight.shape[0])
+    return _Conv3d.apply(x0, x1, weight, bias, tuple(stride), bool(ups), cop or weight.shape[0], prep)
 
 
 class _Linear(torch.autograd.Function):
     """y[M, sum N_i] = x[M,K] . cat(W_i)^T + cat(b_i);  W_i all [N/nw, K]."""
 
     @staticmethod
-    def forward(ctx, x, *wb):
+    def forward(ctx, x, prep, *wb):
         nw = len(wb) // 2
         ws, bs = wb[:nw], wb[nw:]
         _chk(x, 'x')
@@ -192,16 +287,18 @@ class _Linear(torch.autograd.Function):
         Ns = ws[0].shape[0]
         N = Ns * nw
         y = torch.empty((M, N), device=x.device, dtype=x.dtype)
-        wop = [_w_operand(w, x.dtype) for w in ws]
+        wop = prep.w if prep is not None else [_w_operand(w, x.dtype) for w in ws]
         _lib.call('ltu_linear_fwd', _p(x), K, _ptr_array(wop), nw, _ptr_array(bs), _p(y), N, M, N, K, 0, _dt(x), _s())
-        ctx.save_for_backward(x, *ws)
-        ctx.nw = nw
+        ctx.save_for_backward(x)
+        ctx.params = (ws, bs)
+        ctx.prep = prep
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, *ws = ctx.saved_tensors
-        nw = ctx.nw
+        (x,) = ctx.saved_tensors
+        ws, bs = ctx.params
+        nw = len(ws)
         g = g.contiguous()
         M, K = x.shape
         Ns = ws[0].shape[0]
@@ -209,23 +306,23 @@ class _Linear(torch.autograd.Function):
         dev, dt = x.device, _dt(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = _w_transposed(ws, Ns, K, x.dtype)                         # cat(W)^T
+            wt = ctx.prep.wt if ctx.prep is not None else _w_transposed(ws, Ns, K, x.dtype)     # cat(W)^T
             dx = torch.empty((M, K), device=dev, dtype=x.dtype)
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         dws, dbs = [], []
         esz = g.element_size()
-        for i, w in enumerate(ws):
-            dw = torch.zeros((Ns, K), device=dev, dtype=torch.float32)
-            db = torch.zeros(Ns, device=dev, dtype=torch.float32)
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            dw, fw = _grad_buf(w)
+            db, fb = _grad_buf(b)
             _lib.call('ltu_linear_wgrad', g.data_ptr() + i * Ns * esz, N, _p(x), K, _p(dw), _p(db), M, Ns, K, dt, _s())
-            dws.append(dw.view_as(w))
-            dbs.append(db)
-        return (dx, *dws, *dbs)
+            dws.append(_grad_done(w, dw, fw))
+            dbs.append(_grad_done(b, db, fb))
+        return (dx, None, *dws, *dbs)
 
 
-def linear(x, weights, biases):
+def linear(x, weights, biases, prep=None):
     """x [M,K] (any leading dims flattened by the caller); weights: list of [N_i,K] (or [N_i,K,1,1,1])."""
-    return _Linear.apply(x, *weights, *biases)
+    return _Linear.apply(x, prep, *weights, *biases)
 
 
 # ---------------------------------------------------------------------------------------------- norms
@@ -236,7 +333,7 @@ class _InstNormAct(torch.autograd.Function):
         _chk(x, 'x')
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        sums = torch.zeros((B, C, 3), device=x.device, dtype=torch.float32)
+        sums = scratch_zeros((B, C, 3), x.device)
         dt = _dt(x)
         _lib.call('ltu_instnorm_stats', _p(x), _p(sums), B, S, C, dt, _s())
         y = torch.empty_like(x)
@@ -252,7 +349,7 @@ class _InstNormAct(torch.autograd.Function):
         g = g.contiguous()
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        bsums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float32)
+        bsums = scratch_zeros((B, C, 2), x.device)
         dx = torch.empty_like(x)
         _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
                   _dt(x), _s())
@@ -274,28 +371,30 @@ class _ResLayerNorm(torch.autograd.Function):
         # r is overwritten with z = x + dropout(r): it is the producer's private output buffer
         _lib.call('ltu_layernorm_fwd', _p(x), _p(r), _p(gamma), _p(beta), _p(y), _p(stat), M, d, float(eps), float(p), seed,
                   _dt(x), _s())
-        ctx.save_for_backward(r, stat, gamma)
+        ctx.save_for_backward(r, stat)
+        ctx.params = (gamma, beta)
         ctx.cfg = (p, seed)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        z, stat, gamma = ctx.saved_tensors
+        z, stat = ctx.saved_tensors
+        gamma, beta = ctx.params
         p, seed = ctx.cfg
         g = g.contiguous()
         M, d = z.shape
         dz = torch.empty_like(z)
         dr = torch.empty_like(z) if p > 0 else dz
-        dgamma = torch.zeros(d, device=z.device, dtype=torch.float32)
-        dbeta = torch.zeros(d, device=z.device, dtype=torch.float32)
+        dgamma, fg = _grad_buf(gamma)
+        dbeta, fb = _grad_buf(beta)
         _lib.call('ltu_layernorm_bwd', _p(g), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta), M, d,
                   float(p), seed, _dt(z), _s())
-        return dz, dr, dgamma, dbeta, None, None, None
+        return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None
 
 
 def res_layernorm(x, r, gamma, beta, eps=1e-6, p=0.0, seed=0):
     """LayerNorm(x + dropout(r)) * gamma + beta over the last dim of [M,d]; consumes (overwrites) r."""
-    return _ResLayerNorm.apply(x, r.detach() if not r.requires_grad else r, gamma, beta, eps, p, seed)
+    return _ResLayerNorm.apply(x, r, gamma, beta, eps, p, seed)
 
 
 class _GeluDropout(torch.autograd.Function):
@@ -371,21 +470,23 @@ class _PosConv(torch.autograd.Function):
         B, H, W, D, C = x.shape
         y = torch.empty_like(x)
         _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, float(p), seed, _dt(x), _s())
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x)
+        ctx.params = (w, b)
         ctx.cfg = (p, seed)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
+        w, b = ctx.params
         p, seed = ctx.cfg
         g = g.contiguous()
         B, H, W, D, C = x.shape
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros(C, device=x.device, dtype=torch.float32)
+        dw, fw = _grad_buf(w)
+        db, fb = _grad_buf(b)
         _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, _dt(x), _s())
-        return dx, dw, db, None, None
+        return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
 
 
 def pos_conv(x, w, b, p=0.0, seed=0):
@@ -513,7 +614,7 @@ class _Gate(torch.autograd.Function):
     """skip * sigmoid(psi . relu(IN(Wx skip) + IN(Wg up)) + b)   (model/Unet_3Dblock.py:217-221, 1385)."""
 
     @staticmethod
-    def forward(ctx, skip, up, wx, bx, wg, bg, pw, pb):
+    def forward(ctx, skip, up, wx, bx, wg, bg, pw, pb, px, pg):
         _chk(skip, 'skip'); _chk(up, 'up')
         B, C = skip.shape[0], skip.shape[-1]
         Cg = up.shape[-1]
@@ -522,23 +623,27 @@ class _Gate(torch.autograd.Function):
         dev, dt = skip.device, _dt(skip)
         u1 = torch.empty((M, C), device=dev, dtype=skip.dtype)
         u2 = torch.empty((M, C), device=dev, dtype=skip.dtype)
-        _lib.call('ltu_linear_fwd', _p(skip), C, _ptr_array([_w_operand(wx, skip.dtype)]), 1, _ptr_array([bx]), _p(u1), C, M, C,
-                  C, 0, dt, _s())
-        _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([_w_operand(wg, skip.dtype)]), 1, _ptr_array([bg]), _p(u2), C, M, C,
-                  Cg, 0, dt, _s())
-        s1 = torch.zeros((B, C, 3), device=dev, dtype=torch.float32)
-        s2 = torch.zeros((B, C, 3), device=dev, dtype=torch.float32)
+        wxo = px.w[0] if px is not None else _w_operand(wx, skip.dtype)
+        wgo = pg.w[0] if pg is not None else _w_operand(wg, skip.dtype)
+        _lib.call('ltu_linear_fwd', _p(skip), C, _ptr_array([wxo]), 1, _ptr_array([bx]), _p(u1), C, M, C, C, 0, dt, _s())
+        _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([wgo]), 1, _ptr_array([bg]), _p(u2), C, M, C, Cg, 0, dt, _s())
+        s1 = scratch_zeros((B, C, 3), dev)
+        s2 = scratch_zeros((B, C, 3), dev)
         _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), B, S, C, dt, _s())
         _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), B, S, C, dt, _s())
         a = torch.empty(M, device=dev, dtype=torch.float32)
         out = torch.empty_like(skip)
         _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, dt, _s())
-        ctx.save_for_backward(skip, up, wx, wg, pw, u1, u2, s1, s2, a)
+        ctx.save_for_backward(skip, up, u1, u2, s1, s2, a)
+        ctx.params = (wx, bx, wg, bg, pw, pb)
+        ctx.prep = (px, pg)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        skip, up, wx, wg, pw, u1, u2, s1, s2, a = ctx.saved_tensors
+        skip, up, u1, u2, s1, s2, a = ctx.saved_tensors
+        wx, bx, wg, bg, pw, pb = ctx.params
+        px, pg = ctx.prep
         g = g.contiguous()
         B, C = skip.shape[0], skip.shape[-1]
         Cg = up.shape[-1]
@@ -547,30 +652,33 @@ class _Gate(torch.autograd.Function):
         dev, dt = skip.device, _dt(skip)
         dskip = torch.empty_like(skip)
         ds = torch.empty(M, device=dev, dtype=torch.float32)
-        dpw = torch.zeros_like(pw)
-        dpb = torch.zeros(1, device=dev, dtype=torch.float32)
-        bs1 = torch.zeros((B, C, 2), device=dev, dtype=torch.float32)
-        bs2 = torch.zeros((B, C, 2), device=dev, dtype=torch.float32)
+        dpw, fpw = _grad_buf(pw)
+        dpb, fpb = _grad_buf(pb)
+        bs1 = scratch_zeros((B, C, 2), dev)
+        bs2 = scratch_zeros((B, C, 2), dev)
         du1 = torch.empty_like(u1)
         du2 = torch.empty_like(u2)
         _lib.call('ltu_gate_bwd', _p(g), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
                   _p(dpb), _p(bs1), _p(bs2), _p(du1), _p(du2), B, S, C, dt, _s())
         # through the two 1x1x1 convs
-        wxt = _w_transposed([wx], C, C, skip.dtype)
-        wgt = _w_transposed([wg], C, Cg, skip.dtype)
+        wxt = px.wt if px is not None else _w_transposed([wx], C, C, skip.dtype)
+        wgt = pg.wt if pg is not None else _w_transposed([wg], C, Cg, skip.dtype)
         dup = torch.empty_like(up)
         # dskip += du1 . Wx  (accumulating epilogue), dup = du2 . Wg
         _lib.call('ltu_linear_fwd', _p(du1), C, _ptr_array([wxt]), 1, _ptr_array([None]), _p(dskip), C, M, C, C, 1, dt, _s())
         _lib.call('ltu_linear_fwd', _p(du2), C, _ptr_array([wgt]), 1, _ptr_array([None]), _p(dup), Cg, M, Cg, C, 0, dt, _s())
-        dwx = torch.zeros_like(wx); dbx = torch.zeros(C, device=dev, dtype=torch.float32)
-        dwg = torch.zeros_like(wg); dbg = torch.zeros(C, device=dev, dtype=torch.float32)
+        dwx, f1 = _grad_buf(wx)
+        dbx, f2 = _grad_buf(bx)
+        dwg, f3 = _grad_buf(wg)
+        dbg, f4 = _grad_buf(bg)
         _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _p(dwx), _p(dbx), M, C, C, dt, _s())
         _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _p(dwg), _p(dbg), M, C, Cg, dt, _s())
-        return dskip, dup, dwx, dbx, dwg, dbg, dpw, dpb
+        return (dskip, dup, _grad_done(wx, dwx, f1), _grad_done(bx, dbx, f2), _grad_done(wg, dwg, f3), _grad_done(bg, dbg, f4),
+                _grad_done(pw, dpw, fpw), _grad_done(pb, dpb, fpb), None, None)
 
 
-def attention_gate(skip, up, wx, bx, wg, bg, pw, pb):
-    return _Gate.apply(skip, up, wx, bx, wg, bg, pw, pb)
+def attention_gate(skip, up, wx, bx, wg, bg, pw, pb, prep_x=None, prep_g=None):
+    return _Gate.apply(skip, up, wx, bx, wg, bg, pw, pb, prep_x, prep_g)
 
 
 # ---------------------------------------------------------------------------------------------- loss
@@ -584,8 +692,8 @@ class _LevelLoss(torch.autograd.Function):
         B, C = p.shape[0], p.shape[-1]
         S = p.numel() // (B * C)
         dev = p.device
-        sums = torch.zeros((B, C, 4), device=dev, dtype=torch.float32)
-        values = torch.zeros(8, device=dev, dtype=torch.float32)
+        sums = scratch_zeros((B, C, 4), dev)
+        values = torch.empty(8, device=dev, dtype=torch.float32)
         coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
         wd = (ctypes.c_float * 4)(*[float(w_dice[c]) if c < len(w_dice) else 0.0 for c in range(4)])
         _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _s())

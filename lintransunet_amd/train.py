@@ -78,6 +78,7 @@ def deep_supervision_loss(predict, masks, label, weights, specs=None, scale=1.0)
 def train_step(model, images, labels, weights, step_times=1, specs=None, reducer=None):
     """forward + 5-level loss + backward for one batch of patches (one `j` of utils_3D_embed_full.py:55-86).
     Returns the list of weighted level losses (device scalars, no host sync)."""
+    ops.begin_step(images.device)
     predict, masks = model(images)
     totals, named = deep_supervision_loss(predict, masks, labels, weights, specs, scale=1.0 / step_times)
     if reducer is not None:
@@ -97,7 +98,7 @@ class GradReducer:
     Parameters that never receive a gradient (the 14 unused pos_encoders tensors) are left out.
     """
 
-    def __init__(self, model, bucket_mb=16.0, unused=None, group=None):
+    def __init__(self, model, bucket_mb=16.0, unused=None, group=None, fused=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         unused = set(unused or [])
@@ -122,7 +123,10 @@ class GradReducer:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
                 self.bucket_of[p] = bi
-                p.register_post_accumulate_grad_hook(self._hook)
+                p.register_post_accumulate_grad_hook(self._hook)     # gradients that arrive through autograd
+                if fused and p.is_cuda:
+                    p._ltu_grad = p.grad                            # ... and those written by the wgrad kernels directly
+                    p._ltu_hook = self._hook
             self.flat.append(flat)
         self.pending = [0] * len(self.buckets)
         self.active = False

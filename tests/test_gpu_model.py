@@ -139,6 +139,31 @@ def test_dropout_training_runs():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+def test_fused_gradient_path_matches_autograd_path():
+    """GradReducer installs `_ltu_grad` targets: the wgrad kernels then accumulate straight into the flat gradient
+    buffer.  Same step, same weights: both routes must give the same gradients (and the arena must not corrupt them)."""
+    from lintransunet_amd import train
+    cfg = O_net.NetConfig(**SMALL)
+    x = seedgen.seeded_volume((2, 1, 32, 32, 32), 11).to(DEV)
+    label = seedgen.seeded_label((2, 1, 32, 32, 32), 12).to(DEV)
+    w = O_step.dynamic_weights(0)
+    ref = build(cfg, 100)
+    train.train_step(ref, x, label, w)
+    fused = build(cfg, 100)
+    red = train.GradReducer(fused, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
+    for _ in range(2):                       # second step: buffers and arena are recycled
+        red.zero_grad()
+        train.train_step(fused, x, label, w, reducer=red)
+    torch.cuda.synchronize()
+    pr, pf = dict(ref.named_parameters()), dict(fused.named_parameters())
+    for k, p in pr.items():
+        if p.grad is None:
+            continue
+        a, b = pf[k].grad, p.grad
+        tol = 1e-5 if exact_zero_grad(k) else 2e-3 * max(b.abs().max().item(), 1e-3)    # fp32 atomics: run-to-run order
+        assert (a - b).abs().max().item() <= tol, k
+
+
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()

@@ -343,7 +343,11 @@ def test_attn_layer_golden(ops, golden_dir):
     lay = lay.to(DEV)
     x = seedgen.seeded_volume((B, N, d), 22).to(DEV).requires_grad_(True)
     go = seedgen.seeded_volume((B, N, d), 23).to(DEV)
-    y = MaskTransUnet._layer(None, lay, x.view(B * N, d), B, N, d, 0.0, _SeedStream(0))
+    class _NoStore:                      # per-call operand preparation (no weight store)
+        class _S:
+            lin = type('D', (dict,), {'__getitem__': lambda self, k: None})()
+        _store = _S()
+    y = MaskTransUnet._layer(_NoStore(), lay, x.view(B * N, d), B, N, d, 0.0, _SeedStream(0))
     y.backward(go.view(B * N, d))
     assert rel_err(y.view(B, N, d), torch.from_numpy(Gd['out'])) < 1e-4
     assert rel_err(x.grad, torch.from_numpy(Gd['dx'])) < 5e-4
