@@ -22,8 +22,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per 128^3 patch, forward: Linear layers of the transformers
-LINEAR_FWD_GFLOP_128 = 251.1
+# Roofline object: the dense projections of the transformer layers (nn.Linear, model/trans_block.py:144-189) are the
+# largest kernel family by time.  They are HBM-bound (AI ~ 98 flop/B < ridge ~ 310); algorithmic bytes
+# of one launch y[M,N] = x[M,K] W^T: (M*K + M*N + N*K) * sizeof(bf16).
+HBM_PEAK_GBS = 8000.0
 
 
 def synthetic_batch(batch, size, seed, device):
@@ -38,8 +40,14 @@ def synthetic_batch(batch, size, seed, device):
 def cpu_baseline(size=(128, 128, 128), threads=None):
     """The oracle (CPU restatement of the reference, fp32, dropout on) timed for ONE step at B=1: a bounded sample."""
     from oracle import net as O_net, seedgen, step as O_step
-    threads = threads or os.cpu_count()
+    if threads is None:        # the box exposes every host core but grants a 16-core share per GPU
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+        threads = max(1, min(threads, 16))
     torch.set_num_threads(threads)
+    print(f'[bench] cpu_baseline: oracle step on {threads} host threads ...', file=sys.stderr, flush=True)
     cfg = O_net.NetConfig(dropout=0.3)
     P = seedgen.seeded_params(O_net.param_shapes(cfg), 7, requires_grad=True)
     x = seedgen.seeded_volume((1, 1) + size, 8)
@@ -56,7 +64,7 @@ class KernelTimer:
 
     def __init__(self):
         self.pairs = []
-        self.flops = 0.0
+        self.flops = 0.0        # accumulated "work" (bytes here)
         self.on = False
 
     def wrap(self, fn, flops_of):
@@ -113,8 +121,11 @@ def main():
 
     # live timing of the dominant kernel family (the dense projections of the transformers)
     timer = KernelTimer()
-    ops._Linear.forward = staticmethod(timer.wrap(ops._Linear.forward, lambda ctx, x, prep, *wb: 2.0 * x.shape[0] * x.shape[1] *
-                                                  sum(w.shape[0] for w in wb[:len(wb) // 2])))
+    def linear_bytes(ctx, x, prep, *wb):
+        n = sum(w.shape[0] for w in wb[:len(wb) // 2])
+        return float(x.shape[0] * x.shape[1] + x.shape[0] * n + n * x.shape[1]) * x.element_size()
+
+    ops._Linear.forward = staticmethod(timer.wrap(ops._Linear.forward, linear_bytes))
 
     def step(i):
         reducer.zero_grad()
@@ -143,8 +154,11 @@ def main():
     if rank == 0:
         patches = args.batch * world * args.steps
         ms_lin, n_lin = timer.result()
-        achieved = timer.flops / (ms_lin * 1e-3) / 1e12 if ms_lin > 0 else 0.0
-        peak = 2500.0 if args.dtype == 'bf16' else 157.3
+        achieved = timer.flops / (ms_lin * 1e-3) / 1e9 if ms_lin > 0 else 0.0       # GB/s
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_linear.json')                # FETCH/WRITE_SIZE of the same launches
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
         out = {
             'metric': '128^3 CT patches/sec (fwd+bwd)', 'value': patches / dt, 'unit': 'patches/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
@@ -152,9 +166,10 @@ def main():
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights', 'global_batch': args.batch * world,
                        'patch': [args.size] * 3, 'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'igemm_nt_kernel (transformer projections, forward launches)',
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1), 'traffic': None},
+            'roofline': {'bound': 'hbm', 'kernel': 'igemm_nt_bf16_kernel<2,2,2,2,32,2> (transformer projections, forward launches)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),
+                         'algorithmic_bytes_per_launch': timer.flops / max(n_lin, 1), 'traffic': traffic},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(size)
