@@ -13,7 +13,8 @@
  *     library never allocates, frees, retains pointers or synchronises; all work is enqueued on
  *     `stream`.  Functions are stateless and re-entrant.
  *   - Dropout: (p, seed) select a counter-based Philox mask; the backward entry points regenerate
- *     the mask from the same (p, seed) instead of reading a stored one.  p = 0 disables.
+ *     the mask from the same (p, seed) instead of reading a stored one.  p = 0 disables.  `step` (nullable) is a
+ *     device-resident counter mixed into the seed at run time, so a captured HIP graph draws fresh masks per replay.
  *   - Return value: 0 = LTU_OK, negative = LTU_E_* argument error, positive = hipError_t.
  */
 #ifndef LTU_HIP_H
@@ -61,9 +62,12 @@ int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
  * be NULL.  accumulate != 0 adds to y. */
 int ltu_linear_fwd(const void* a, int lda, const void* const* w, int nw, const float* const* bias, void* y, int ldy,
                    int M, int N, int K, int accumulate, int dtype, ltu_stream_t s);
-/* dw[N,K] += g[M,N]^T . a[M,K];  db[N] += colsum(g).  dw/db fp32, caller zero-fills; db may be NULL. */
-int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* dw, float* db, int M, int N, int K,
-                     int dtype, ltu_stream_t s);
+/* dw_i[N/nw,K] += g[:, block i]^T . a[M,K];  db_i += column sums of g (fp32 gradients, accumulated; db may be NULL).
+ * ws: optional workspace of ltu_wgrad_ws_floats(M,N,K) floats - with it (bf16) the row-split partial tiles are stored and
+ * summed by a second kernel (no atomics, one launch for all nw blocks); without it fp32 atomics are used. */
+long long ltu_wgrad_ws_floats(long long M, int N, int K);
+int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw, int M, int N,
+                     int K, float* ws, int dtype, ltu_stream_t s);
 
 /* ---- 3x3x3 convolution, padding 1: model/Unet_3Dblock.py:310,314,375,421,523,528,588,1328,1353 --
  * x0 [B,Hi,Wi,Di,C0] (+ optional x1 [..,C1]: the channel concat of Unet_3Dblock.py:553 without
@@ -78,10 +82,11 @@ int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B,
                      int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s);
 /* weight gradient (+=, the caller zero-fills): torch_co == 0: into the packed layout dwf [Co][27][C0+C1];
  * torch_co != 0: straight into a PyTorch-layout gradient [torch_co][torch_ci][3][3][3] (padded rows/channels dropped).
- * db[Co] += column sums of g. */
+ * db[Co] += column sums of g.
+ * ws: optional workspace of ltu_wgrad_ws_floats(B*Ho*Wo*Do, Co, 27*(C0+C1)) floats (two-stage reduction, see above). */
 int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi, int Wi,
-                     int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co, int torch_ci, int dtype,
-                     ltu_stream_t s);
+                     int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co, int torch_ci, float* ws,
+                     int dtype, ltu_stream_t s);
 /* y[b,h,w,d,c] = sum of the 2x2x2 children of x [B,2H,2W,2D,C] (adjoint of nearest x2 upsampling) */
 int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int dtype, ltu_stream_t s);
 
@@ -102,23 +107,23 @@ int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const f
  * apply: y = dropout(act((x-mean)*rstd)) + res (res may be NULL). */
 int ltu_instnorm_stats(const void* x, float* sums, int B, long long S, int C, int dtype, ltu_stream_t s);
 int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C, int act,
-                       float slope, float p, uint64_t seed, int dtype, ltu_stream_t s);
+                       float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dx from dy; bsums [B][C][2] zero-filled scratch */
 int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, void* dx, int B, long long S, int C,
-                     int act, float slope, float p, uint64_t seed, int dtype, ltu_stream_t s);
+                     int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- residual LayerNorm: model/trans_block.py:205-206,209-210 -----------------------------------
  * y = LN(x + dropout(r)) * gamma + beta over rows of d in {32,64,128,256}; r is OVERWRITTEN with the
  * pre-norm sum z; stat [M][2] = {mean, rstd}. */
 int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat, long long M,
-                      int d, float eps, float p, uint64_t seed, int dtype, ltu_stream_t s);
+                      int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dz (gradient of x) and dr = dz*dropmask (dr may alias dz when p = 0); dgamma/dbeta += (zero-filled) */
 int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                      float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, int dtype, ltu_stream_t s);
+                      float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- GELU(erf) + dropout: model/trans_block.py:208 ---------------------------------------------- */
-int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, int dtype, ltu_stream_t s);
-int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, float p, uint64_t seed, int dtype,
+int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, float p, uint64_t seed, const uint64_t* step, int dtype,
                          ltu_stream_t s);
 
 /* ---- class-probability heads ---------------------------------------------------------------------
@@ -148,10 +153,10 @@ int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* 
  * y = chan_dropout(x + dwconv3x3x3(x) + bias), x [B,H,W,D,C]; w [C,1,3,3,3] with the reference's kernel
  * axes (D,H,W); nn.Dropout3d draws one keep/drop per (sample, channel). */
 int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C, float p,
-                   uint64_t seed, int dtype, ltu_stream_t s);
+                   uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller) */
 int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int B, int H, int W,
-                   int D, int C, float p, uint64_t seed, int dtype, ltu_stream_t s);
+                   int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- dynamic ROI: model/Unet_3Dblock.py:821-873, 37-49 (box), 51-82 (index maps), 985-1117 (warps) ----
  * prob f32 [B,H,W,D,C]: foreground = (1 - prob[...,0]) >= thr.  Writes box [B][6] = (x0,y0,0,x1,y1,D-1)

@@ -21,22 +21,23 @@ SIGNATURES = {
     'ltu_transpose_f32': [P, P, I, I, I, I, I, P],
     'ltu_cast_f32': [P, P, L, I, P],
     'ltu_linear_fwd': [P, I, P, I, P, P, I, I, I, I, I, I, P],
-    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P],
+    'ltu_wgrad_ws_floats': [L, I, I],
+    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, I, P],
     'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
-    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_weight_prep': [P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],
     'ltu_linattn_splits': [I, I],
     'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],
     'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     'ltu_instnorm_stats': [P, P, I, L, I, I, P],
-    'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, I, P],
-    'ltu_instnorm_bwd': [P, P, P, P, P, I, L, I, I, F, F, U, I, P],
-    'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, I, P],
-    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, L, I, F, U, I, P],
-    'ltu_gelu_dropout_fwd': [P, P, L, F, U, I, P],
-    'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, I, P],
+    'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_instnorm_bwd': [P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
+    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
+    'ltu_gelu_dropout_fwd': [P, P, L, F, U, P, I, P],
+    'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, P, I, P],
     'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],
     'ltu_head_softmax_bwd': [P, P, P, L, I, I, I, P],
     'ltu_final_softmax_fwd': [P, P, I, I, I, I, I, I, P],
@@ -44,8 +45,8 @@ SIGNATURES = {
     'ltu_onehot_argmax': [P, P, L, I, P],
     'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
-    'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, I, P],
-    'ltu_dwconv_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, U, I, P],
+    'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, P, I, P],
+    'ltu_dwconv_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
     'ltu_roi_plan_size': [I, I, I, I, P, P],
     'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P],
     'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
@@ -73,7 +74,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
-        fn.restype = c_int
+        fn.restype = c_longlong if name == 'ltu_wgrad_ws_floats' else c_int
     _lib = lib
     return lib
 

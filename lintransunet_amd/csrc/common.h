@@ -114,8 +114,11 @@ struct DropCfg {       // p == 0 disables
   uint32_t seed_lo, seed_hi;
 };
 
-__device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed) {
+// `step` (nullable) points at a device-resident step counter mixed into the seed, so that a HIP-graph replay
+// of a captured step (whose scalar arguments are frozen) still draws fresh masks.
+__device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed, const uint64_t* step) {
   DropCfg d;
+  if (step != nullptr && p > 0.f) seed += *step * 0x9E3779B97F4A7C15ull;
   d.p = p;
   d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
   d.thresh = p > 0.f ? (uint32_t)fminf(p * 4294967296.f, 4294967295.f) : 0u;

@@ -373,16 +373,38 @@ extern "C" int ltu_linear_fwd(const void* a, int lda, const void* const* w, int 
   return launch_nt<float, float>(g, (hipStream_t)s);
 }
 
-extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* dw, float* db, int M, int N,
-                                int K, int dtype, ltu_stream_t s) {
-  if (K % 4 != 0 || lda % 4 != 0 || ldg % 4 != 0 || N % 4 != 0) return LTU_E_SHAPE;
+extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) { return tn_geometry(M, N, K, 32).ws_floats; }
+
+extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw,
+                                int M, int N, int K, float* ws, int dtype, ltu_stream_t s) {
+  if (nw < 1 || nw > 3 || N % nw != 0 || K % 4 != 0 || lda % 4 != 0 || ldg % 4 != 0 || N % 4 != 0) return LTU_E_SHAPE;
   WGradArgs wa;
-  dense_desc(wa.g, M, N, K);
-  wa.g.a0 = a; wa.g.a1 = a; wa.g.lda0 = lda; wa.g.lda1 = lda;
-  wa.grad = grad; wa.ldg = ldg; wa.dw = dw; wa.db = db; wa.t_co = 0; wa.t_ci = 0;
-  if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
-  if (dtype != LTU_F32) return LTU_E_DTYPE;
-  return launch_tn<float>(wa, (hipStream_t)s);
+  memset(&wa, 0, sizeof(wa));
+  if (dtype == LTU_BF16 && ws != nullptr) {
+    // one launch over all weight blocks, two-stage reduction through the workspace
+    dense_desc(wa.g, M, N, K);
+    wa.g.a0 = a; wa.g.a1 = a; wa.g.lda0 = lda; wa.g.lda1 = lda;
+    wa.grad = grad; wa.ldg = ldg; wa.part = ws;
+    wa.nseg_w = nw;
+    for (int i = 0; i < nw; ++i) { wa.dwseg[i] = dw[i]; wa.dbseg[i] = db ? db[i] : nullptr; }
+    wa.dw = dw[0]; wa.db = db ? db[0] : nullptr;
+    return launch_tn_bf16(wa, (hipStream_t)s);
+  }
+  const int Ns = N / nw;
+  const size_t esz = dtype == LTU_BF16 ? 2 : 4;
+  for (int i = 0; i < nw; ++i) {            // atomic path: one launch per weight block
+    memset(&wa, 0, sizeof(wa));
+    dense_desc(wa.g, M, Ns, K);
+    wa.g.a0 = a; wa.g.a1 = a; wa.g.lda0 = lda; wa.g.lda1 = lda;
+    wa.grad = reinterpret_cast<const char*>(grad) + (size_t)i * Ns * esz; wa.ldg = ldg;
+    wa.dw = dw[i]; wa.db = db ? db[i] : nullptr;
+    int rc;
+    if (dtype == LTU_BF16) rc = launch_tn_bf16(wa, (hipStream_t)s);
+    else if (dtype == LTU_F32) rc = launch_tn<float>(wa, (hipStream_t)s);
+    else return LTU_E_DTYPE;
+    if (rc) return rc;
+  }
+  return LTU_OK;
 }
 
 // forward-conv gather description (also used by the weight gradient)
@@ -424,14 +446,16 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
 
 extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi,
                                 int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co,
-                                int torch_ci, int dtype, ltu_stream_t s) {
+                                int torch_ci, float* ws, int dtype, ltu_stream_t s) {
   WGradArgs wa;
+  memset(&wa, 0, sizeof(wa));
   int Ho, Wo, Do;
   int rc = conv_fwd_desc(wa.g, B, Hi, Wi, Di, C0, C1, Co, sh, sw, sd, ups, &Ho, &Wo, &Do);
   if (rc) return rc;
   if (Co % 4 != 0) return LTU_E_SHAPE;
   wa.g.a0 = x0; wa.g.a1 = x1 ? x1 : x0;
   wa.grad = grad; wa.ldg = Co; wa.dw = dwf; wa.db = db; wa.t_co = torch_co; wa.t_ci = torch_ci;
+  wa.part = dtype == LTU_BF16 ? ws : nullptr; wa.nseg_w = 1;
   if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_tn<float>(wa, (hipStream_t)s);

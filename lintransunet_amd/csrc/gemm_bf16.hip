@@ -349,12 +349,12 @@ int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ TN
-// tile: BNn (n) x BKk (k) of dW, BR = 64 reduction rows per iteration.  Gs[BR][BNn+32], Xs[BR][BKk+32] bf16
+// tile: BNn (n) x BKk (k) of dW, BR = 32 reduction rows per iteration (40 KB LDS: 3-4 workgroups per CU; BR = 64 measured slower).  Gs[BR][BNn+32], Xs[BR][BKk+32] bf16
 // (the 64-byte pad makes the 4-row transposing reads of a 32-lane half hit 4 disjoint bank ranges).
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradArgs wa) {
   const IGemmArgs& g = wa.g;
-  constexpr int NT = WM * WN * 64, BNn = WM * TM * 32, BKk = WN * TN * 32, BR = 64;
+  constexpr int NT = WM * WN * 64, BNn = WM * TM * 32, BKk = WN * TN * 32, BR = 32;
   constexpr int LDG = BNn + 32, LDX = BKk + 32;
   constexpr int LG = (BR * BNn / 8 + NT - 1) / NT, LX = (BR * BKk / 8 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) uint16_t Gs[2][BR][LDG];
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
   const int tcol = 16 * (gq & 1) + 4 * tp;
   const int trow = 8 * (gq >> 1) + tq;
   const int lh = lane >> 5, li = lane & 31;
-  const bool do_bias = wa.db != nullptr && blockIdx.x == 0;
+  const bool do_bias = (wa.db != nullptr || wa.part != nullptr) && blockIdx.x == 0;
   for (int it = 0; it < niter; ++it) {
     const int buf = it & 1;
     if (it + 1 < niter) load_tile(it + 1);
@@ -472,6 +472,23 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
     __syncthreads();
   }
 
+  if (wa.part != nullptr) {
+    // two-stage: plain coalesced stores of this split's tile (32 consecutive k per half-wave = 128-byte rows)
+    float* pz = wa.part + (long long)blockIdx.z * wa.npad * wa.kpad;
+    if (do_bias && tid < BNn) wa.bpart[(long long)blockIdx.z * wa.npad + n_blk + tid] = bsum;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int k = k_blk + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          pz[(long long)n * wa.kpad + k] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   if (do_bias && tid < BNn && n_blk + tid < (wa.t_co ? wa.t_co : g.N)) atomicAdd(wa.db + n_blk + tid, bsum);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -495,25 +512,69 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
   }
 }
 
+// second stage: gradient[n][k] += sum over splits of part[z][n][k]; db[n] += sum_z bpart[z][n].
+// grid-stride over the N*K real elements (+ N bias elements), consecutive threads on consecutive k.
+__global__ void wgrad_reduce_kernel(const WGradArgs wa, int nsplit) {
+  const IGemmArgs& g = wa.g;
+  const long long nk = (long long)g.N * g.K;
+  const long long total = nk + g.N;
+  const long long zs = (long long)wa.npad * wa.kpad;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    if (e < nk) {
+      const int n = (int)(e / g.K), k = (int)(e % g.K);
+      const float* p = wa.part + (long long)n * wa.kpad + k;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int z = 0;
+      for (; z + 3 < nsplit; z += 4) {
+        a0 += p[z * zs]; a1 += p[(z + 1) * zs]; a2 += p[(z + 2) * zs]; a3 += p[(z + 3) * zs];
+      }
+      for (; z < nsplit; ++z) a0 += p[z * zs];
+      const float v = (a0 + a1) + (a2 + a3);
+      if (wa.t_co) {
+        const int slot = k / g.C, c = k - slot * g.C;
+        if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
+      } else if (wa.nseg_w > 1) {
+        const int nper = g.N / wa.nseg_w, seg = n / nper;
+        wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
+      } else {
+        const int slot = k / g.C, c = k - slot * g.C;
+        wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
+      }
+    } else {
+      const int n = (int)(e - nk);
+      float v = 0.f;
+      for (int z = 0; z < nsplit; ++z) v += wa.bpart[(long long)z * wa.npad + n];
+      if (wa.nseg_w > 1) {
+        const int nper = g.N / wa.nseg_w, seg = n / nper;
+        if (wa.dbseg[seg]) wa.dbseg[seg][n - seg * nper] += v;
+      } else if (wa.db && n < (wa.t_co ? wa.t_co : g.N)) {
+        wa.db[n] += v;
+      }
+    }
+  }
+}
+
 int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   const IGemmArgs& g = wa.g;
   if (g.M <= 0 || g.N <= 0) return LTU_OK;
   if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.N % 8 || wa.ldg % 8) return LTU_E_SHAPE;
-  int bn, bk = 128;
-  if (g.N > 64) bn = 128;
-  else if (g.N > 32) bn = 64;
-  else bn = 32;
-  const unsigned nk = cdiv(g.K, bk), nn = cdiv(g.N, bn);
-  long long want = 512 / ((long long)nk * nn);
-  if (want < 1) want = 1;
-  long long rows = (g.M + want - 1) / want;
-  if (rows < 512) rows = 512;
-  rows = (rows + 63) / 64 * 64;
-  wa.rows_per_split = (int)rows;
-  dim3 grid(nk, nn, cdiv(g.M, rows));
+  const TnGeom t = tn_geometry(g.M, g.N, g.K, 32);
+  wa.rows_per_split = t.rows;
+  if (wa.part != nullptr) {
+    wa.npad = t.nn * t.bn;
+    wa.kpad = t.nk * t.bk;
+    wa.bpart = wa.part + (long long)t.nsplit * wa.npad * wa.kpad;
+  }
+  dim3 grid(t.nk, t.nn, t.nsplit);
   if (g.N > 64) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, wa);
   else if (g.N > 32) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, 4, 2, 1>), grid, dim3(256), 0, st, wa);
   else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, 4, 1, 1>), grid, dim3(256), 0, st, wa);
+  if (wa.part != nullptr) {
+    const long long total = (long long)g.N * g.K + g.N;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, wa, t.nsplit);
+  }
   return ltu_check_launch();
 }

@@ -55,7 +55,37 @@ struct WGradArgs {
   float* db;          // may be null
   int rows_per_split; // multiple of the tile's row count
   int t_co, t_ci;     // != 0: dw is a PyTorch conv weight gradient [t_co][t_ci][27] (padded rows/channels are dropped)
+  // two-stage mode (part != null): every split stores its fp32 tile to part[split][npad][kpad] (+ bias partials to
+  // bpart[split][npad]) with plain stores; wgrad_reduce_kernel sums the splits into the gradient.  No atomics.
+  float* part;
+  float* bpart;
+  int npad, kpad;
+  float* dwseg[3];    // gradient blocks of N/nseg_w rows each (fused q,k,v projections)
+  float* dbseg[3];
+  int nseg_w;
 };
+
+// split geometry shared by the launcher and the workspace-size query
+struct TnGeom {
+  int bn, bk, nn, nk, rows, nsplit;
+  long long ws_floats;
+};
+static inline TnGeom tn_geometry(long long M, int N, int K, int brows) {
+  TnGeom t;
+  t.bk = 128;
+  t.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  t.nk = (K + t.bk - 1) / t.bk;
+  t.nn = (N + t.bn - 1) / t.bn;
+  long long want = 1024 / ((long long)t.nk * t.nn);
+  if (want < 1) want = 1;
+  long long rows = (M + want - 1) / want;
+  if (rows < 256) rows = 256;
+  rows = (rows + brows - 1) / brows * brows;
+  t.rows = (int)rows;
+  t.nsplit = (int)((M + rows - 1) / rows);
+  t.ws_floats = (long long)t.nsplit * t.nn * t.bn * ((long long)t.nk * t.bk + 1);
+  return t;
+}
 
 
 // bf16-MFMA launchers (gemm_bf16.hip)

@@ -67,10 +67,10 @@ __global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict
 template <typename T>
 __global__ void instnorm_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums, const T* __restrict__ res,
                                       T* __restrict__ y, long long S, int C, int B, int act, float slope, float p,
-                                      uint64_t seed) {
+                                      uint64_t seed, const uint64_t* step) {
   const long long nvec = (long long)B * S * C / 4;
   const float invS = 1.f / (float)S;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   const long long per_b = S * C / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i / per_b);
@@ -97,14 +97,14 @@ __global__ void instnorm_apply_kernel(const T* __restrict__ x, const float* __re
 template <typename T>
 __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
                                           float* __restrict__ bsums, long long S, int C, int rows_per_block, int act,
-                                          float slope, float p, uint64_t seed) {
+                                          float slope, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];
   const int b = blockIdx.y;
   const int cv = C / 4;
   const int tid = threadIdx.x;
   const int v = tid % cv, rg = tid / cv, nrg = blockDim.x / cv;
   const float invS = 1.f / (float)S;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
   if (rg < nrg) {
     InStat st[4];
@@ -141,10 +141,10 @@ __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __r
 template <typename T>
 __global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
                                           const float* __restrict__ bsums, T* __restrict__ dx, long long S, int C, int B,
-                                          int act, float slope, float p, uint64_t seed) {
+                                          int act, float slope, float p, uint64_t seed, const uint64_t* step) {
   const long long nvec = (long long)B * S * C / 4;
   const float invS = 1.f / (float)S;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   const long long per_b = S * C / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i / per_b);
@@ -172,12 +172,12 @@ __global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __r
 template <typename T, int G>
 __global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ stat,
-                                     long long M, float eps, float p, uint64_t seed) {
+                                     long long M, float eps, float p, uint64_t seed, const uint64_t* step) {
   const int d = G * 4;
   const int gl = threadIdx.x % G;
   const long long rows_per_block = blockDim.x / G;
   const long long row = (long long)blockIdx.x * rows_per_block + threadIdx.x / G;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   const bool ok = row < M;
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ok) {
@@ -210,11 +210,11 @@ template <typename T, int G>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ stat,
                                      const float* __restrict__ gamma, T* __restrict__ dz, T* __restrict__ dr,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int rows_per_block,
-                                     float p, uint64_t seed) {
+                                     float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];   // [rowgroups][d][2]
   const int d = G * 4;
   const int gl = threadIdx.x % G, rg = threadIdx.x / G, nrg = blockDim.x / G;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -288,18 +288,18 @@ static unsigned stream_grid(long long nvec) {
 }
 
 extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C,
-                                  int act, float slope, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+                                  int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 != 0) return LTU_E_SHAPE;
   const long long nvec = (long long)B * S * C / 4;
   LTU_DISPATCH_T(dtype, {
     hipLaunchKernelGGL((instnorm_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)x, sums,
-                       (const T*)res, (T*)y, S, C, B, act, slope, p, seed);
+                       (const T*)res, (T*)y, S, C, B, act, slope, p, seed, step);
   });
   return ltu_check_launch();
 }
 
 extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, void* dx, int B, long long S,
-                                int C, int act, float slope, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+                                int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
   int nchunks;
   const int rows = stats_rows(S, B, &nchunks);
@@ -310,9 +310,9 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
   const long long nvec = (long long)B * S * C / 4;
   LTU_DISPATCH_T(dtype, {
     hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)dy,
-                       (const T*)x, sums, bsums, S, C, rows, act, slope, p, seed);
+                       (const T*)x, sums, bsums, S, C, rows, act, slope, p, seed, step);
     hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
-                       (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed);
+                       (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
   });
   return ltu_check_launch();
 }
@@ -327,19 +327,19 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
   } while (0)
 
 extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat,
-                                 long long M, int d, float eps, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+                                 long long M, int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   LTU_DISPATCH_T(dtype, {
     LN_DISPATCH_G(d, {
       const int rows = 256 / G;
       hipLaunchKernelGGL((layernorm_fwd_kernel<T, G>), dim3(cdiv(M, rows)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)r,
-                         gamma, beta, (T*)y, stat, M, eps, p, seed);
+                         gamma, beta, (T*)y, stat, M, eps, p, seed, step);
     });
   });
   return ltu_check_launch();
 }
 
 extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                                 float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, int dtype,
+                                 float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype,
                                  ltu_stream_t s) {
   LTU_DISPATCH_T(dtype, {
     LN_DISPATCH_G(d, {
@@ -349,7 +349,7 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* sta
       rows = (rows + nrg - 1) / nrg * nrg;
       const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(cdiv(M, rows)), dim3(256), lds, (hipStream_t)s, (const T*)dy,
-                         (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, M, (int)rows, p, seed);
+                         (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, M, (int)rows, p, seed, step);
     });
   });
   return ltu_check_launch();

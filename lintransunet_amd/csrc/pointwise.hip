@@ -139,8 +139,8 @@ extern "C" int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, 
 // ------------------------------------------------------------------------------------------------ GELU + dropout
 // h = drop(gelu(u))  (model/trans_block.py:208);  du = dh * mask * gelu'(u)
 template <typename T>
-__global__ void gelu_drop_fwd_kernel(const T* __restrict__ u, T* __restrict__ h, long long nvec, float p, uint64_t seed) {
-  const DropCfg dc = make_drop(p, seed);
+__global__ void gelu_drop_fwd_kernel(const T* __restrict__ u, T* __restrict__ h, long long nvec, float p, uint64_t seed, const uint64_t* step) {
+  const DropCfg dc = make_drop(p, seed, step);
   GRID_STRIDE(i, nvec) {
     float4 v = Vec4<T>::load(u + i * 4);
     v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
@@ -149,8 +149,8 @@ __global__ void gelu_drop_fwd_kernel(const T* __restrict__ u, T* __restrict__ h,
 }
 template <typename T>
 __global__ void gelu_drop_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, long long nvec,
-                                     float p, uint64_t seed) {
-  const DropCfg dc = make_drop(p, seed);
+                                     float p, uint64_t seed, const uint64_t* step) {
+  const DropCfg dc = make_drop(p, seed, step);
   GRID_STRIDE(i, nvec) {
     const float4 v = Vec4<T>::load(u + i * 4);
     const float4 g = Vec4<T>::load(dh + i * 4);
@@ -159,15 +159,15 @@ __global__ void gelu_drop_bwd_kernel(const T* __restrict__ dh, const T* __restri
                                            g.z * m.z * gelu_erf_grad(v.z), g.w * m.w * gelu_erf_grad(v.w)));
   }
 }
-extern "C" int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+extern "C" int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (n % 4) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((gelu_drop_fwd_kernel<T>), dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)s, (const T*)u, (T*)h, n / 4, p, seed); });
+  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((gelu_drop_fwd_kernel<T>), dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)s, (const T*)u, (T*)h, n / 4, p, seed, step); });
   return ltu_check_launch();
 }
-extern "C" int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, float p, uint64_t seed, int dtype,
+extern "C" int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, float p, uint64_t seed, const uint64_t* step, int dtype,
                                     ltu_stream_t s) {
   if (n % 4) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((gelu_drop_bwd_kernel<T>), dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)s, (const T*)dh, (const T*)u, (T*)du, n / 4, p, seed); });
+  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((gelu_drop_bwd_kernel<T>), dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)s, (const T*)dh, (const T*)u, (T*)du, n / 4, p, seed, step); });
   return ltu_check_launch();
 }
 
@@ -503,13 +503,13 @@ __device__ __forceinline__ void dw_tap(int t, int& dh, int& dw, int& dd) {
 
 template <typename T>
 __global__ void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                  T* __restrict__ y, int B, int H, int W, int D, int C, float p, uint64_t seed) {
+                                  T* __restrict__ y, int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float wl[];   // [27][C]
   for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wl[(i % 27) * C + i / 27] = w[i];
   __syncthreads();
   const int cv = C / 4;
   const long long n = (long long)B * H * W * D * cv;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   GRID_STRIDE(i, n) {
     const int v = (int)(i % cv);
     long long t = i / cv;
@@ -536,13 +536,13 @@ __global__ void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restri
 // dx = g' + sum_t w[t] g'(vox - off_t),  g' = dy * chanmask
 template <typename T>
 __global__ void dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B, int H,
-                                       int W, int D, int C, float p, uint64_t seed) {
+                                       int W, int D, int C, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float wl[];
   for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wl[(i % 27) * C + i / 27] = w[i];
   __syncthreads();
   const int cv = C / 4;
   const long long n = (long long)B * H * W * D * cv;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   GRID_STRIDE(i, n) {
     const int v = (int)(i % cv);
     long long t = i / cv;
@@ -569,14 +569,14 @@ __global__ void dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __
 template <typename T>
 __global__ void dwconv_bwd_weight_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dwt,
                                          float* __restrict__ db, int B, int H, int W, int D, int C, int rows_per_block, float p,
-                                         uint64_t seed) {
+                                         uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];   // [C][28]
   for (int i = threadIdx.x; i < C * 28; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   const int cv = C / 4;
   const int v = threadIdx.x % cv, rg = threadIdx.x / cv, nrg = blockDim.x / cv;
   const int b = blockIdx.y;
-  const DropCfg dc = make_drop(p, seed);
+  const DropCfg dc = make_drop(p, seed, step);
   const float4 m = dropmask4(dc, (uint64_t)(((long long)b * C + v * 4) >> 2));
   float acc[28][4];
 #pragma unroll
@@ -619,14 +619,14 @@ __global__ void dwconv_bwd_weight_kernel(const T* __restrict__ dy, const T* __re
 }
 
 extern "C" int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C,
-                              float p, uint64_t seed, int dtype, ltu_stream_t s) {
+                              float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4) return LTU_E_SHAPE;
   const long long n = (long long)B * H * W * D * (C / 4);
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((dwconv_fwd_kernel<T>), dim3(sgrid(n)), dim3(256), 27 * C * sizeof(float), (hipStream_t)s, (const T*)x, w, bias, (T*)y, B, H, W, D, C, p, seed); });
+  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((dwconv_fwd_kernel<T>), dim3(sgrid(n)), dim3(256), 27 * C * sizeof(float), (hipStream_t)s, (const T*)x, w, bias, (T*)y, B, H, W, D, C, p, seed, step); });
   return ltu_check_launch();
 }
 extern "C" int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dwt, float* db, int B, int H,
-                              int W, int D, int C, float p, uint64_t seed, int dtype, ltu_stream_t s) {
+                              int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 || 256 % (C / 4)) return LTU_E_SHAPE;
   const long long n = (long long)B * H * W * D * (C / 4);
   const long long S = (long long)H * W * D;
@@ -635,8 +635,8 @@ extern "C" int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, voi
   long long rows = (S + want - 1) / want;
   if (rows < 32) rows = 32;
   LTU_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((dwconv_bwd_data_kernel<T>), dim3(sgrid(n)), dim3(256), 27 * C * sizeof(float), (hipStream_t)s, (const T*)dy, w, (T*)dx, B, H, W, D, C, p, seed);
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T>), dim3(cdiv(S, rows), B), dim3(256), (size_t)C * 28 * sizeof(float), (hipStream_t)s, (const T*)dy, (const T*)x, dwt, db, B, H, W, D, C, (int)rows, p, seed);
+    hipLaunchKernelGGL((dwconv_bwd_data_kernel<T>), dim3(sgrid(n)), dim3(256), 27 * C * sizeof(float), (hipStream_t)s, (const T*)dy, w, (T*)dx, B, H, W, D, C, p, seed, step);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T>), dim3(cdiv(S, rows), B), dim3(256), (size_t)C * 28 * sizeof(float), (hipStream_t)s, (const T*)dy, (const T*)x, dwt, db, B, H, W, D, C, (int)rows, p, seed, step);
   });
   return ltu_check_launch();
 }

@@ -49,6 +49,21 @@ def _chk(t, name='tensor'):
     return t
 
 
+_STEP = None      # device-resident uint64 step counter mixed into every dropout seed (see common.h: make_drop)
+
+
+def set_step_counter(t):
+    """Install (or clear with None) the device counter; advance it with `t.add_(1)` once per step, inside a captured graph too."""
+    global _STEP
+    if t is not None and (t.dtype != torch.int64 or not t.is_cuda or t.numel() != 1):
+        raise ValueError('step counter must be a 1-element int64 CUDA tensor')
+    _STEP = t
+
+
+def _step_ptr():
+    return 0 if _STEP is None else _STEP.data_ptr()
+
+
 def _ptr_array(tensors):
     arr = (_c_void_p * 3)()
     for i, t in enumerate(tensors):
@@ -137,6 +152,14 @@ def _w_transposed(ws, rows, cols, dtype):
     for i, w in enumerate(ws):
         _lib.call('ltu_transpose_f32', _p(w), _p(wt), rows, cols, n, i * rows, odt, _s())
     return wt
+
+
+def _wgrad_ws(M, N, K, like):
+    """workspace for the two-stage (atomic-free) weight-gradient reduction of the bf16 path; None selects fp32 atomics"""
+    if like.dtype != torch.bfloat16:
+        return None
+    n = _lib.load().ltu_wgrad_ws_floats(M, N, K)
+    return torch.empty(n, device=like.device, dtype=torch.float32)
 
 
 class ConvPrep:
@@ -265,8 +288,9 @@ class _Conv3d(torch.autograd.Function):
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
         # the weight gradient lands directly in the PyTorch layout [Co,Ci,3,3,3]; padded rows / channels are dropped
+        ws = _wgrad_ws(g.numel() // cop, cop, 27 * CiP, x0)
         _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd, int(ups),
-                  Co, Ci, dt, _s())
+                  Co, Ci, _p(ws), dt, _s())
         return dx0, dx1, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None, None, None, None
 
 
@@ -309,14 +333,12 @@ class _Linear(torch.autograd.Function):
             wt = ctx.prep.wt if ctx.prep is not None else _w_transposed(ws, Ns, K, x.dtype)     # cat(W)^T
             dx = torch.empty((M, K), device=dev, dtype=x.dtype)
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
-        dws, dbs = [], []
-        esz = g.element_size()
-        for i, (w, b) in enumerate(zip(ws, bs)):
-            dw, fw = _grad_buf(w)
-            db, fb = _grad_buf(b)
-            _lib.call('ltu_linear_wgrad', g.data_ptr() + i * Ns * esz, N, _p(x), K, _p(dw), _p(db), M, Ns, K, dt, _s())
-            dws.append(_grad_done(w, dw, fw))
-            dbs.append(_grad_done(b, db, fb))
+        gw = [_grad_buf(w) for w in ws]
+        gb = [_grad_buf(b) for b in bs]
+        _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
+                  M, N, K, _p(_wgrad_ws(M, N, K, x)), dt, _s())
+        dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
+        dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
         return (dx, None, *dws, *dbs)
 
 
@@ -337,7 +359,7 @@ class _InstNormAct(torch.autograd.Function):
         dt = _dt(x)
         _lib.call('ltu_instnorm_stats', _p(x), _p(sums), B, S, C, dt, _s())
         y = torch.empty_like(x)
-        _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, dt, _s())
+        _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, _step_ptr(), dt, _s())
         ctx.save_for_backward(x, sums)
         ctx.cfg = (act, p, seed, res is not None)
         return y
@@ -352,7 +374,7 @@ class _InstNormAct(torch.autograd.Function):
         bsums = scratch_zeros((B, C, 2), x.device)
         dx = torch.empty_like(x)
         _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
-                  _dt(x), _s())
+                  _step_ptr(), _dt(x), _s())
         return dx, (g if has_res else None), None, None, None
 
 
@@ -370,7 +392,7 @@ class _ResLayerNorm(torch.autograd.Function):
         stat = torch.empty((M, 2), device=x.device, dtype=torch.float32)
         # r is overwritten with z = x + dropout(r): it is the producer's private output buffer
         _lib.call('ltu_layernorm_fwd', _p(x), _p(r), _p(gamma), _p(beta), _p(y), _p(stat), M, d, float(eps), float(p), seed,
-                  _dt(x), _s())
+                  _step_ptr(), _dt(x), _s())
         ctx.save_for_backward(r, stat)
         ctx.params = (gamma, beta)
         ctx.cfg = (p, seed)
@@ -388,7 +410,7 @@ class _ResLayerNorm(torch.autograd.Function):
         dgamma, fg = _grad_buf(gamma)
         dbeta, fb = _grad_buf(beta)
         _lib.call('ltu_layernorm_bwd', _p(g), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta), M, d,
-                  float(p), seed, _dt(z), _s())
+                  float(p), seed, _step_ptr(), _dt(z), _s())
         return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None
 
 
@@ -402,7 +424,7 @@ class _GeluDropout(torch.autograd.Function):
     def forward(ctx, u, p, seed):
         _chk(u, 'u')
         h = torch.empty_like(u)
-        _lib.call('ltu_gelu_dropout_fwd', _p(u), _p(h), u.numel(), float(p), seed, _dt(u), _s())
+        _lib.call('ltu_gelu_dropout_fwd', _p(u), _p(h), u.numel(), float(p), seed, _step_ptr(), _dt(u), _s())
         ctx.save_for_backward(u)
         ctx.cfg = (p, seed)
         return h
@@ -413,7 +435,7 @@ class _GeluDropout(torch.autograd.Function):
         p, seed = ctx.cfg
         g = g.contiguous()
         du = torch.empty_like(u)
-        _lib.call('ltu_gelu_dropout_bwd', _p(g), _p(u), _p(du), u.numel(), float(p), seed, _dt(u), _s())
+        _lib.call('ltu_gelu_dropout_bwd', _p(g), _p(u), _p(du), u.numel(), float(p), seed, _step_ptr(), _dt(u), _s())
         return du, None, None
 
 
@@ -469,7 +491,7 @@ class _PosConv(torch.autograd.Function):
         _chk(x, 'x')
         B, H, W, D, C = x.shape
         y = torch.empty_like(x)
-        _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, float(p), seed, _dt(x), _s())
+        _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, float(p), seed, _step_ptr(), _dt(x), _s())
         ctx.save_for_backward(x)
         ctx.params = (w, b)
         ctx.cfg = (p, seed)
@@ -485,7 +507,7 @@ class _PosConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, _dt(x), _s())
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, _step_ptr(), _dt(x), _s())
         return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
 
 
@@ -671,8 +693,10 @@ class _Gate(torch.autograd.Function):
         dbx, f2 = _grad_buf(bx)
         dwg, f3 = _grad_buf(wg)
         dbg, f4 = _grad_buf(bg)
-        _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _p(dwx), _p(dbx), M, C, C, dt, _s())
-        _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _p(dwg), _p(dbg), M, C, Cg, dt, _s())
+        _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _ptr_array([dwx]), _ptr_array([dbx]), 1, M, C, C,
+                  _p(_wgrad_ws(M, C, C, skip)), dt, _s())
+        _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _ptr_array([dwg]), _ptr_array([dbg]), 1, M, C, Cg,
+                  _p(_wgrad_ws(M, C, Cg, skip)), dt, _s())
         return (dskip, dup, _grad_done(wx, dwx, f1), _grad_done(bx, dbx, f2), _grad_done(wg, dwg, f3), _grad_done(bg, dbg, f4),
                 _grad_done(pw, dpw, fpw), _grad_done(pb, dpb, fpb), None, None)
 

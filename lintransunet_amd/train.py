@@ -148,6 +148,14 @@ class GradReducer:
         if self.pending[bi] == 0 and self.world > 1:
             self.handles.append((bi, dist.all_reduce(self.flat[bi], group=self.group, async_op=True)))
 
+    def reduce_all(self):
+        """all-reduce every bucket now (used after a graph replay, where no hooks run)"""
+        if self.world > 1:
+            hs = [dist.all_reduce(f, group=self.group, async_op=True) for f in self.flat]
+            for f, h in zip(self.flat, hs):
+                h.wait()
+                f.div_(self.world)
+
     def finish(self):
         self.active = False
         if self.world > 1:
@@ -159,6 +167,47 @@ class GradReducer:
                 h.wait()
                 self.flat[bi].div_(self.world)
         self.handles = []
+
+
+class GraphedStep:
+    """One training step (arena reset, weight prep, forward, 5-level loss, backward into the reducer's flat gradient
+    buffers) captured once into a HIP graph and replayed: ~1 400 kernel launches become one `hipGraphLaunch`.
+
+    The batch lives in static device buffers (`copy_` new data in); dropout masks stay fresh across replays because the
+    kernels mix a device-resident step counter, advanced inside the graph, into their Philox seeds.  With more than one rank
+    the gradient all-reduce runs after the replay (bucket by bucket, asynchronously) instead of from autograd hooks.
+    """
+
+    def __init__(self, model, images, labels, weights, reducer, step_times=1, specs=None, warmup=2):
+        self.model, self.reducer = model, reducer
+        dev = images.device
+        self.x, self.lab = images.clone(), labels.clone()
+        self.counter = torch.zeros(1, device=dev, dtype=torch.int64)
+        ops.set_step_counter(self.counter)
+
+        def body():
+            self.counter.add_(1)
+            reducer.zero_grad()
+            return train_step(model, self.x, self.lab, weights, step_times=step_times, specs=specs, reducer=None)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):        # warm-up on a side stream: allocator pools, arena size, weight store
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.totals, self.named = body()
+
+    def __call__(self, images=None, labels=None):
+        if images is not None:
+            self.x.copy_(images, non_blocking=True)
+            self.lab.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        self.reducer.reduce_all()
+        return self.totals, self.named
 
 
 UNUSED_PARAMETERS = tuple(f'decode.bridge_list.4.transformer.pos_encoders.{n}.proj.{k}'

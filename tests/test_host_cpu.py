@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_exports_every_declared_symbol():
     from lintransunet_amd import _lib
     header = open(os.path.join(ROOT, 'include', 'ltu_hip.h')).read()
-    declared = set(re.findall(r'^int\s+(ltu_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|long long)\s+(ltu_\w+)\s*\(', header, flags=re.M))
     assert len(declared) >= 35
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()
@@ -24,7 +24,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.ltu_version() >= 1
     # argument counts of the binding table match the C prototypes
-    for name, args in re.findall(r'^int\s+(ltu_\w+)\s*\(([^;]*)\);', header, flags=re.M | re.S):
+    for name, args in re.findall(r'^(?:int|long long)\s+(ltu_\w+)\s*\(([^;]*)\);', header, flags=re.M | re.S):
         n = 0 if args.strip() == 'void' else len(args.split(','))
         assert n == len(_lib.SIGNATURES[name]), name
 
