@@ -53,7 +53,8 @@ int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_str
 /* All of the above for a whole model in ONE launch.  table: n device-resident 40-byte records
  * { const float* src; void* dst; int kind, R, C, p0, p1, pad; } with kind 0 = cast (R*C elements),
  * 1 = transpose ([R][C] -> dst[c*p0 + p1 + r]), 2 = pack wf ([R=Co][C=Ci][27] -> [p0=CoP][27][p1=CiP]),
- * 3 = pack wd (-> [p1=CiP][27][p0=CoP]), 4 = fp32 copy of R*C elements (padded biases). */
+ * 3 = pack wd (-> [p1=CiP][27][p0=CoP]), 4 = fp32 copy of R*C elements (padded biases), 5 / 6 = the sub-pixel
+ * operands of ltu_upconv_* ([8][CoP][8][CiP] and [CiP][64][CoP]). */
 int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
 
 /* ---- dense projections: nn.Linear (model/trans_block.py:144,156,166,187,189) and 1x1x1 convs
@@ -87,6 +88,17 @@ int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B,
 int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi, int Wi,
                      int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co, int torch_ci, float* ws,
                      int dtype, ltu_stream_t s);
+/* ---- nearest x2 upsampling + 3x3x3 conv as a sub-pixel conv: model/Unet_3Dblock.py:419-432 (UpEmbedBlock) ------------
+ * Same result as ltu_conv3d_* with ups = 1 at 64/216 of the multiply-adds: the 8 output parity classes are 2x2x2-tap
+ * convs on the low-res grid with pre-summed weights (ltu_weight_prep kinds 5 / 6).  x [B,H,W,D,Ci] -> y [B,2H,2W,2D,Co]. */
+int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bias, void* y, int B, int H, int W, int D, int Ci, int Co,
+                   int dtype, ltu_stream_t s);
+int ltu_upconv_dgrad(const void* g, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co, int dtype,
+                     ltu_stream_t s);
+/* dweff: zero-filled scratch [8][Co][8][Ci] fp32; dw_torch [co_real][ci_real][3][3][3] += and db[Co] += ;
+ * ws: optional ltu_wgrad_ws_floats(B*H*W*D, Co, 8*Ci) floats (bf16 two-stage reduction) */
+int ltu_upconv_wgrad(const void* g, const void* x, float* dweff, float* db, float* dw_torch, int co_real, int ci_real, float* ws,
+                     int B, int H, int W, int D, int Ci, int Co, int dtype, ltu_stream_t s);
 /* y[b,h,w,d,c] = sum of the 2x2x2 children of x [B,2H,2W,2D,C] (adjoint of nearest x2 upsampling) */
 int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int dtype, ltu_stream_t s);
 

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_kernel(const WGradArgs w
       const long long m = m0 + row;
       const int n = n_blk + nq;
       rg[p] = (idx < BR * BNn / 4 && m < m_end && n < g.N)
-                  ? Vec4<TA>::load(reinterpret_cast<const TA*>(wa.grad) + m * wa.ldg + n)
+                  ? Vec4<TA>::load(reinterpret_cast<const TA*>(wa.grad) + out_voxel(g, m) * wa.ldg + n)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -522,3 +522,7 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
       }
   return LTU_OK;
 }
+
+// fp32 launchers for the other translation units (upconv.hip)
+int launch_nt_f32(const IGemmArgs& g, hipStream_t st) { return launch_nt<float, float>(g, st); }
+int launch_tn_f32(WGradArgs& wa, hipStream_t st) { return launch_tn<float>(wa, st); }

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
       const long long m = m0 + row;
       const int n = n_blk + nq;
       rg[p] = (idx < BR * BNn / 8 && m < m_end && n < g.N)
-                  ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(wa.grad) + m * wa.ldg + n)
+                  ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(wa.grad) + out_voxel_b(g, m) * wa.ldg + n)
                   : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
@@ -513,44 +513,52 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
 }
 
 // second stage: gradient[n][k] += sum over splits of part[z][n][k]; db[n] += sum_z bpart[z][n].
-// grid-stride over the N*K real elements (+ N bias elements), consecutive threads on consecutive k.
-__global__ void wgrad_reduce_kernel(const WGradArgs wa, int nsplit) {
+// A workgroup owns 32 consecutive elements; its 8 thread groups each sum every 8th split (coalesced 128-byte reads),
+// then combine through LDS.  Element e < N*K is (n = e / K, k = e % K); the last N elements are the bias sums.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, int nsplit) {
+  __shared__ float red[8][33];
   const IGemmArgs& g = wa.g;
   const long long nk = (long long)g.N * g.K;
   const long long total = nk + g.N;
   const long long zs = (long long)wa.npad * wa.kpad;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+  const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + el;
+  float a0 = 0.f, a1 = 0.f;
+  int n = 0, k = 0;
+  if (e < total) {
     if (e < nk) {
-      const int n = (int)(e / g.K), k = (int)(e % g.K);
+      n = (int)(e / g.K); k = (int)(e % g.K);
       const float* p = wa.part + (long long)n * wa.kpad + k;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int z = 0;
-      for (; z + 3 < nsplit; z += 4) {
-        a0 += p[z * zs]; a1 += p[(z + 1) * zs]; a2 += p[(z + 2) * zs]; a3 += p[(z + 3) * zs];
-      }
-      for (; z < nsplit; ++z) a0 += p[z * zs];
-      const float v = (a0 + a1) + (a2 + a3);
-      if (wa.t_co) {
-        const int slot = k / g.C, c = k - slot * g.C;
-        if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
-      } else if (wa.nseg_w > 1) {
-        const int nper = g.N / wa.nseg_w, seg = n / nper;
-        wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
-      } else {
-        const int slot = k / g.C, c = k - slot * g.C;
-        wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
-      }
+      int z = zq;
+      for (; z + 8 < nsplit; z += 16) { a0 += p[z * zs]; a1 += p[(z + 8) * zs]; }
+      if (z < nsplit) a0 += p[z * zs];
     } else {
-      const int n = (int)(e - nk);
-      float v = 0.f;
-      for (int z = 0; z < nsplit; ++z) v += wa.bpart[(long long)z * wa.npad + n];
-      if (wa.nseg_w > 1) {
-        const int nper = g.N / wa.nseg_w, seg = n / nper;
-        if (wa.dbseg[seg]) wa.dbseg[seg][n - seg * nper] += v;
-      } else if (wa.db && n < (wa.t_co ? wa.t_co : g.N)) {
-        wa.db[n] += v;
-      }
+      n = (int)(e - nk);
+      for (int z = zq; z < nsplit; z += 8) a0 += wa.bpart[(long long)z * wa.npad + n];
     }
+  }
+  red[zq][el] = a0 + a1;
+  __syncthreads();
+  if (zq != 0 || e >= total) return;
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v += red[q][el];
+  if (e < nk) {
+    if (wa.t_co) {
+      const int slot = k / g.C, c = k - slot * g.C;
+      if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
+    } else if (wa.nseg_w > 1) {
+      const int nper = g.N / wa.nseg_w, seg = n / nper;
+      wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
+    } else {
+      const int slot = k / g.C, c = k - slot * g.C;
+      wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
+    }
+  } else if (wa.nseg_w > 1) {
+    const int nper = g.N / wa.nseg_w, seg = n / nper;
+    if (wa.dbseg[seg]) wa.dbseg[seg][n - seg * nper] += v;
+  } else if (wa.db && n < (wa.t_co ? wa.t_co : g.N)) {
+    wa.db[n] += v;
   }
 }
 
@@ -572,9 +580,7 @@ int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, 4, 1, 1>), grid, dim3(256), 0, st, wa);
   if (wa.part != nullptr) {
     const long long total = (long long)g.N * g.K + g.N;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, wa, t.nsplit);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, wa, t.nsplit);
   }
   return ltu_check_launch();
 }

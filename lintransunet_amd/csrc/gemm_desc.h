@@ -23,7 +23,7 @@ struct IGemmArgs {
   int sh, sw, sd, ups;
   int mh, mw, md;
   int ntaps;
-  Tap tap[27];
+  Tap tap[64];
   int out_identity;
   int omh, omw, omd, ooh, oow, ood, oh, ow, od;
   int n0;            // columns [0,n0) go to o0 (row stride ldo0), the rest to o1 (ldo1)
@@ -76,7 +76,7 @@ static inline TnGeom tn_geometry(long long M, int N, int K, int brows) {
   t.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
   t.nk = (K + t.bk - 1) / t.bk;
   t.nn = (N + t.bn - 1) / t.bn;
-  long long want = 1024 / ((long long)t.nk * t.nn);
+  long long want = 512 / ((long long)t.nk * t.nn);
   if (want < 1) want = 1;
   long long rows = (M + want - 1) / want;
   if (rows < 256) rows = 256;

@@ -9,6 +9,8 @@ extern "C" int ltu_version(void) { return 2; }
 //   2  pack_f      conv [R=Co][C=Ci][27] -> dst [p0=CoP][27][p1=CiP] zero padded
 //   3  pack_d      conv [R=Co][C=Ci][27] -> dst [p1=CiP][27][p0=CoP] zero padded
 //   4  copy_f32    dst[i] = src[i] as fp32 whatever the operand dtype (padded biases)      R*C elements
+//   5  upconv_f    conv [R=Co][C=Ci][27] -> sub-pixel forward operand  dst [8 classes][p0=CoP][8 slots][p1=CiP]
+//   6  upconv_d    conv [R=Co][C=Ci][27] -> sub-pixel data-gradient operand  dst [p1=CiP][64][p0=CoP]   (see upconv.hip)
 struct WPrep {
   const float* src;
   void* dst;
@@ -32,6 +34,29 @@ __global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
     for (long long i = t0; i < n; i += stride) {       // i enumerates the DESTINATION (coalesced writes; sources are L2-resident)
       const int r = (int)(i % d.R), c = (int)(i / d.R);
       st1<TW>(dst + (long long)c * d.p0 + d.p1 + r, d.src[(long long)r * d.C + c]);
+    }
+  } else if (d.kind == 5 || d.kind == 6) {
+    const int CoP = d.p0, CiP = d.p1;
+    const long long n = 64LL * CoP * CiP;
+    for (long long i = t0; i < n; i += stride) {
+      int cls, sl, co, ci;
+      if (d.kind == 5) { ci = (int)(i % CiP); sl = (int)((i / CiP) % 8); co = (int)((i / (8LL * CiP)) % CoP); cls = (int)(i / (8LL * CiP * CoP)); }
+      else { co = (int)(i % CoP); const int cs = (int)((i / CoP) % 64); ci = (int)(i / (64LL * CoP)); cls = cs >> 3; sl = cs & 7; }
+      float v = 0.f;
+      if (co < d.R && ci < d.C) {
+        // per axis: class p, slot a -> taps {0} | {1,2} (p = 0) or {0,1} | {2} (p = 1)
+        int lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+          const int p = (cls >> (2 - a)) & 1, sa = (sl >> (2 - a)) & 1;
+          if (p == 0) { lo[a] = sa == 0 ? 0 : 1; hi[a] = sa == 0 ? 0 : 2; }
+          else { lo[a] = sa == 0 ? 0 : 2; hi[a] = sa == 0 ? 1 : 2; }
+        }
+        const float* w = d.src + ((long long)co * d.C + ci) * 27;
+        for (int th = lo[0]; th <= hi[0]; ++th)
+          for (int tw = lo[1]; tw <= hi[1]; ++tw)
+            for (int td = lo[2]; td <= hi[2]; ++td) v += w[(th * 3 + tw) * 3 + td];
+      }
+      st1<TW>(dst + i, v);
     }
   } else {
     const int CoP = d.p0, CiP = d.p1;

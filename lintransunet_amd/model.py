@@ -88,6 +88,15 @@ class _WeightStore:
             self.recs.append((conv.bias, bias, 4, 1, Co, 0, 0))
         self.conv[id(conv)] = ops.ConvPrep(wf, wd, bias)
 
+    def add_upconv(self, conv):
+        w = conv.weight
+        Co, Ci = w.shape[0], w.shape[1]
+        wf = torch.empty((8, Co, 8, Ci), device=self.device, dtype=self.dtype)
+        wd = torch.empty((Ci, 64, Co), device=self.device, dtype=self.dtype)
+        self.recs.append((w, wf, 5, Co, Ci, Co, Ci))
+        self.recs.append((w, wd, 6, Co, Ci, Co, Ci))
+        self.conv[id(conv)] = ops.UpConvPrep(wf, wd)
+
     def add_linear(self, key, weights):
         """weights: list of [N,K(,1,1,1)] parameters sharing K (a fused q,k,v group or a single projection)"""
         N, K = weights[0].shape[0], weights[0].shape[1]
@@ -210,7 +219,7 @@ class MaskTransUnet(nn.Module):
             tr = br.transformer
             if hasattr(tr, 'down_embed'):
                 st.add_conv(tr.down_embed.module_list[0][0])
-                st.add_conv(tr.up_embed.module_list[0][1])
+                st.add_upconv(tr.up_embed.module_list[0][1])
             for lay in tr.layers:
                 lin = lay.self_attn.linears
                 st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight])
@@ -261,8 +270,10 @@ class MaskTransUnet(nn.Module):
         g = ops.roi_warp(skip, plan)
         e = self._conv_in_act(g, tr.down_embed.module_list[0][0], stride=(2, 2, 2), p=p, seeds=seeds)
         e = self._token_transformer(tr.layers, tr.pos_encoder, e, p, seeds)
-        e = self._conv_in_act(e, tr.up_embed.module_list[0][1], p=p, seeds=seeds, ups=True)
-        # the nearest x2 grid is 2*ceil(n/2) wide: crop back when the ROI grid is odd (F.interpolate gives 2*n_down)
+        up = tr.up_embed.module_list[0][1]       # nearest x2 + conv as a sub-pixel conv (3.4x fewer multiply-adds)
+        e = ops.upconv3d(e, up.weight, up.bias, prep=self._store.conv[id(up)])
+        e = ops.instnorm_act(e, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0)
+        # the un-embedded grid is 2*ceil(n/2) wide; the warp-back plan samples it with the reference's normalisation
         return ops.roi_unwarp(e, plan)
 
     # ------------------------------------------------------------------ forward

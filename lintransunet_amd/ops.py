@@ -294,6 +294,73 @@ class _Conv3d(torch.autograd.Function):
         return dx0, dx1, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None, None, None, None
 
 
+class UpConvPrep:
+    """sub-pixel operands of a nearest-x2 + 3x3x3 conv: wf [8][Co][8][Ci], wd [Ci][64][Co] (activation dtype)"""
+    __slots__ = ('wf', 'wd', 'table')
+
+    def __init__(self, wf, wd, table=None):
+        self.wf, self.wd, self.table = wf, wd, table
+
+
+def upconv_prep(weight, dtype):
+    """stand-alone operand preparation (the model prepares these in its one-launch weight store instead)"""
+    import numpy as np
+    Co, Ci = weight.shape[0], weight.shape[1]
+    dev = weight.device
+    wf = torch.empty((8, Co, 8, Ci), device=dev, dtype=dtype)
+    wd = torch.empty((Ci, 64, Co), device=dev, dtype=dtype)
+    rec = np.zeros(2, dtype=[('src', '<u8'), ('dst', '<u8'), ('kind', '<i4'), ('R', '<i4'), ('C', '<i4'), ('p0', '<i4'),
+                             ('p1', '<i4'), ('pad', '<i4')])
+    rec[0] = (weight.data_ptr(), wf.data_ptr(), 5, Co, Ci, Co, Ci, 0)
+    rec[1] = (weight.data_ptr(), wd.data_ptr(), 6, Co, Ci, Co, Ci, 0)
+    table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    _lib.call('ltu_weight_prep', table.data_ptr(), 2, F32 if dtype == torch.float32 else BF16, _s())
+    return UpConvPrep(wf, wd, table)
+
+
+class _UpConv3d(torch.autograd.Function):
+    """conv3x3x3(nearest_upsample_x2(x)) as a sub-pixel convolution (csrc/upconv.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, prep):
+        _chk(x, 'x')
+        B, H, W, D, Ci = x.shape
+        Co = weight.shape[0]
+        if prep is None:
+            prep = upconv_prep(weight, x.dtype)
+        y = torch.empty((B, 2 * H, 2 * W, 2 * D, Co), device=x.device, dtype=x.dtype)
+        _lib.call('ltu_upconv_fwd', _p(x), _p(prep.wf), _p(bias), _p(y), B, H, W, D, Ci, Co, _dt(x), _s())
+        ctx.save_for_backward(x)
+        ctx.params = (weight, bias)
+        ctx.prep = prep
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        prep = ctx.prep
+        g = g.contiguous()
+        B, H, W, D, Ci = x.shape
+        Co = weight.shape[0]
+        dt = _dt(x)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, dt, _s())
+        dw, fw = _grad_buf(weight)
+        db, fb = _grad_buf(bias)
+        dweff = scratch_zeros((8, Co, 8, Ci), x.device)
+        ws = _wgrad_ws(B * H * W * D, Co, 8 * Ci, x)
+        _lib.call('ltu_upconv_wgrad', _p(g), _p(x), _p(dweff), _p(db), _p(dw), Co, Ci, _p(ws), B, H, W, D, Ci, Co, dt, _s())
+        return dx, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None
+
+
+def upconv3d(x, weight, bias, prep=None):
+    """3x3x3 conv (padding 1) of the nearest-neighbour x2 upsampling of channels-last x, without materialising it."""
+    return _UpConv3d.apply(x, weight, bias, prep)
+
+
 def conv3d(x0, weight, bias, stride=(1, 1, 1), x1=None, ups=False, cop=None, prep=None):
     """3x3x3 conv, padding 1, on channels-last x0 (+ virtual concat x1).  Output has `cop` (>= Co, padded) channels."""
     return _Conv3d.apply(x0, x1, weight, bias, tuple(stride), bool(ups), cop or weight.shape[0], prep)

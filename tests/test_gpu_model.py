@@ -28,6 +28,15 @@ def exact_zero_grad(key):
                                   'self_attn.linears.1.'))
 
 
+def grads_agree(a, b, key):
+    """Two runs of the same step.  fp32 atomics make the InstanceNorm sums differ in the last bits between runs; an
+    activation that sits within 1e-7 of zero can then flip its LeakyReLU/ReLU branch, which changes ONE term of a weight
+    gradient (visible on layers with few rows, e.g. the 896-voxel token embedding).  Hence a relative L2 criterion."""
+    if exact_zero_grad(key):
+        return (a - b).abs().max().item() <= 1e-5
+    return (a - b).double().norm().item() <= 5e-3 * max(b.double().norm().item(), 1e-6)
+
+
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
@@ -159,9 +168,7 @@ def test_fused_gradient_path_matches_autograd_path():
     for k, p in pr.items():
         if p.grad is None:
             continue
-        a, b = pf[k].grad, p.grad
-        tol = 1e-5 if exact_zero_grad(k) else 2e-3 * max(b.abs().max().item(), 1e-3)    # fp32 atomics: run-to-run order
-        assert (a - b).abs().max().item() <= tol, k
+        assert grads_agree(pf[k].grad, p.grad, k), k
 
 
 def test_graphed_step_matches_eager():
@@ -185,8 +192,7 @@ def test_graphed_step_matches_eager():
         for k, p in pr.items():
             if p.grad is None:
                 continue
-            tol = 1e-5 if exact_zero_grad(k) else 2e-3 * max(p.grad.abs().max().item(), 1e-3)
-            assert (pm[k].grad - p.grad).abs().max().item() <= tol, k
+            assert grads_agree(pm[k].grad, p.grad, k), k
         # with dropout the replays must differ (fresh masks) although the captured seeds are frozen
         md = build(cfg, 100, dropout=0.3)
         redd = train.GradReducer(md, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)

@@ -195,6 +195,29 @@ def test_conv3d(ops, case):
     assert rel_err(bd.grad, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize('B,Ci,Co,H,W,D', [(2, 16, 8, 3, 4, 2), (1, 32, 16, 5, 3, 4), (1, 128, 32, 4, 3, 5)])
+def test_upconv_subpixel(ops, dtype, tol, B, Ci, Co, H, W, D):
+    """nearest x2 + conv3x3x3 computed as 8 parity-class 2x2x2 convs with pre-summed weights == the plain formulation"""
+    g = G(13)
+    bf = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = bf(torch.randn(B, Ci, H, W, D, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1)
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(F.interpolate(xr, scale_factor=2), wr, br, padding=1)
+    go = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(go)
+    xd = to_cl(x, dtype).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.upconv3d(xd, wd, bd)
+    yd.backward(to_cl(go, dtype))
+    assert rel_err(from_cl(yd), yr) < tol
+    assert rel_err(from_cl(xd.grad), xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < max(tol / 5, 1e-4)
+    assert rel_err(bd.grad, br.grad) < max(tol / 5, 1e-4)
+
+
 def test_conv3d_stem_padding(ops):
     """stem: 4 real input channels carried in an 8-channel tensor (window embedding)"""
     g = G(4)
