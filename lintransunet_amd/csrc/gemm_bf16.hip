@@ -337,9 +337,12 @@ int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
   if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.wrow % 8 || g.N % 4 || g.n0 % 4 || g.ldo0 % 4 || g.ldo1 % 4)
     return LTU_E_SHAPE;
+  static int small_tile = -1;
+  if (small_tile < 0) { const char* e = getenv("LTU_NT_SMALLTILE"); small_tile = e ? atoi(e) : 0; }
   if (g.N > 64) {
-    if (g.M <= 8192) launch_nt_cfg<2, 2, 1, 2>(g, st);      // few rows: 64-row tiles keep more CUs busy
-    else launch_nt_cfg<2, 2, 2, 2>(g, st);
+    if (small_tile == 2) launch_nt_cfg<2, 2, 1, 1>(g, st);
+    else if (small_tile == 3) launch_nt_cfg<2, 2, 2, 2>(g, st);
+    else launch_nt_cfg<2, 2, 1, 2>(g, st);      // 64x128 tiles: ~100 registers, 30 KB LDS -> 5 workgroups per CU in flight
   } else if (g.N > 32) {
     launch_nt_cfg<4, 1, 1, 2>(g, st);
   } else {
