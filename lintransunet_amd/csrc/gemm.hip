@@ -13,6 +13,8 @@
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) on fp32 LDS tiles; T only
 // selects the HBM storage type.  Waves are 64 wide: a wave owns TM x TN tiles of 32x32.
+#include <stdlib.h>
+
 #include "gemm_desc.h"
 
 // 4 consecutive channels of the A operand at (row, k); zero outside the source / beyond K
@@ -407,6 +409,12 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
   return LTU_OK;
 }
 
+static bool use_halo() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LTU_NO_HALO"); v = (e && atoi(e)) ? 0 : 1; }
+  return v == 1;
+}
+
 // forward-conv gather description (also used by the weight gradient)
 static int conv_fwd_desc(IGemmArgs& g, int B, int Hi, int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd,
                          int ups, int* Ho, int* Wo, int* Do) {
@@ -439,7 +447,19 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
   g.a0 = x0; g.a1 = x1 ? x1 : x0;
   g.w[0] = wf; g.bias[0] = bias;
   g.o0 = y; g.o1 = y; g.ldo0 = Co; g.ldo1 = Co;
-  if (dtype == LTU_BF16) return launch_nt_bf16(g, (hipStream_t)s);
+  if (dtype == LTU_BF16) {
+    if (sh == 1 && sw == 1 && sd == 1 && !ups && use_halo()) {      // LDS-staged halo brick instead of 27 gathers
+      HaloArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x0 = x0; a.x1 = x1 ? x1 : x0; a.w = wf; a.bias = bias; a.o0 = y; a.o1 = y;
+      a.B = B; a.H = Hi; a.W = Wi; a.D = Di;
+      a.C = C0 + C1; a.c0 = C0; a.lda0 = C0; a.lda1 = C1 > 0 ? C1 : C0;
+      a.N = Co; a.n0 = Co; a.ldo0 = Co; a.ldo1 = Co;
+      const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
+      if (hr != 1) return hr;
+    }
+    return launch_nt_bf16(g, (hipStream_t)s);
+  }
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_nt<float, float>(g, (hipStream_t)s);
 }
@@ -468,6 +488,17 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
                                 int C0, int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s) {
   if ((sh != 1 && sh != 2) || (sw != 1 && sw != 2) || (sd != 1 && sd != 2)) return LTU_E_ARG;
   if (Co % 4 != 0) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && sh == 1 && sw == 1 && sd == 1 && use_halo()) {
+    HaloArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = grad; a.x1 = grad; a.w = wd; a.bias = nullptr; a.o0 = dx0; a.o1 = dx1 ? dx1 : dx0;
+    a.B = B; a.H = Hl; a.W = Wl; a.D = Dl;
+    a.C = Co; a.c0 = Co; a.lda0 = Co; a.lda1 = Co;
+    a.N = C0 + C1; a.n0 = C0; a.ldo0 = C0; a.ldo1 = C1 > 0 ? C1 : C0;
+    a.flip = 1;
+    const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
   const int Ho = (Hl - 1) / sh + 1, Wo = (Wl - 1) / sw + 1, Do = (Dl - 1) / sd + 1;
   const int str[3] = {sh, sw, sd};
   const int len[3] = {Hl, Wl, Dl};

@@ -320,7 +320,9 @@ static void launch_nt_cfg(const IGemmArgs& g, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN));
   int v = nt_variant();
-  if (v == 0) v = 1;      // measured on MI355X: BK 32 (3 workgroups per CU) beats BK 64/128 on every shape of this network
+  // measured on MI355X: BK 32 (several workgroups per CU) wins whenever the grid fills the chip more than once; a grid of
+  // at most ~2 workgroups per CU is latency-bound on its serial K loop, where BK 64 halves the number of round trips
+  if (v == 0) v = ((long long)grid.x * grid.y <= 512 && g.K >= 128) ? 2 : 1;
   if (v == 3 && g.K > 128) v = 2;
   if (v == 3)
     hipLaunchKernelGGL((igemm_nt_bf16_kernel<WM, WN, TM, TN, 128, 1>), grid, dim3(WM * WN * 64), 0, st, g);

@@ -91,3 +91,19 @@ static inline TnGeom tn_geometry(long long M, int N, int K, int brows) {
 // bf16-MFMA launchers (gemm_bf16.hip)
 int launch_nt_bf16(const IGemmArgs& g, hipStream_t st);
 int launch_tn_bf16(WGradArgs& wa, hipStream_t st);
+
+// LDS-halo stride-1 3x3x3 convolution (conv_halo.hip)
+struct HaloArgs {
+  const void* x0;
+  const void* x1;
+  const void* w;        // [N][27][C] in bf16
+  const float* bias;
+  void* o0;
+  void* o1;
+  int B, H, W, D;
+  int C, c0, lda0, lda1;
+  int N, n0, ldo0, ldo1;
+  int flip;             // 1: data gradient (tap t reads halo offset 2 - t)
+  int CC;               // channel chunk: 16 or 32 (chosen by the launcher)
+};
+int launch_conv_halo_bf16(HaloArgs a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled (fall back)
