@@ -206,3 +206,188 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   }
   return ltu_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convs:  dW[n][tap][c] = sum over voxels of G[v][n] * X[v + tap][c].
+// A workgroup owns (32-channel chunk, 32-column gradient tile, a range of bricks).  Per brick it stages the halo brick of
+// X and the 128 x 32 gradient tile once; the 27 taps are dealt round-robin to the 4 waves, each keeping its <= 7
+// 32(n) x 32(c) fp32 accumulators in registers for the whole brick range.  Both MFMA operands are K(=voxel)-major in LDS,
+// so they are read with the transposing ds_read_b64_tr_b16; a tap is again only a constant LDS offset.  The splits store
+// their tiles to part[split][N][27*C] (+ bias partials) and wgrad_reduce_kernel (gemm_bf16.hip) folds them.
+typedef __attribute__((ext_vector_type(4))) short hs16x4;
+typedef __attribute__((address_space(3))) hs16x4 lds_hs16x4;
+#define LDGH 40
+
+__global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * LDH];
+  __shared__ __attribute__((aligned(16))) uint16_t Gs[128 * LDGH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int chunk = blockIdx.x, n_blk = blockIdx.y * 32;
+  const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
+  const int VPV = a.CC / 8;
+  const int brick_lo = blockIdx.z * a.bricks_per_split;
+  int brick_hi = brick_lo + a.bricks_per_split;
+  if (brick_hi > a.bricks) brick_hi = a.bricks;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  int tapoff[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    tapoff[i] = (((tap / 9) * HALO_W + (tap / 3) % 3) * HALO_D + tap % 3) * LDH;
+  }
+  // transposing-read lane geometry (see wgrad_tn_bf16_kernel): lane -> (row trow (+4), columns tcol..tcol+3) of a 16-row slab
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tcol = 16 * (gq & 1) + 4 * tp;
+  const int trow = 8 * (gq >> 1) + tq;
+  const int gbase = trow * LDGH + tcol;
+  // slab ks covers brick rows 16ks..16ks+15 = (h = ks>>1, w = 2(ks&1) + (row>>3), d = row&7)
+  const int hbase = ((gq >> 1) * HALO_D + tq) * LDH + tcol;
+
+  uint4 hreg[6], greg[2];
+  auto load_brick = [&](int brick) {
+    int t = brick;
+    const int bd = t % nbd; t /= nbd;
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh;
+    const int b = t / nbh;
+    const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int idx = tid + p * 256;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (idx < HALO_VOX * VPV) {
+        const int hv = idx / VPV, part = idx - hv * VPV;
+        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+        const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+        const int c = chunk * a.CC + part * 8;
+        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C) {
+          const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
+          const uint16_t* src = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + c
+                                         : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (c - a.c0);
+          v = *reinterpret_cast<const uint4*>(src);
+        }
+      }
+      hreg[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int idx = tid + p * 256;
+      const int row = idx >> 2, n = n_blk + (idx & 3) * 8;
+      const int h = h0 + (row >> 5), w = w0 + ((row >> 3) & 3), d = d0 + (row & 7);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (h < a.H && w < a.W && d < a.D && n < a.N) {
+        const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.grad) + vox * a.ldg + n);
+      }
+      greg[p] = v;
+    }
+  };
+  auto store_brick = [&]() {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int idx = tid + p * 256;
+      if (idx < HALO_VOX * VPV) {
+        const int hv = idx / VPV, part = idx - hv * VPV;
+        *reinterpret_cast<uint4*>(&halo[hv * LDH + part * 8]) = hreg[p];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int idx = tid + p * 256;
+      *reinterpret_cast<uint4*>(&Gs[(idx >> 2) * LDGH + (idx & 3) * 8]) = greg[p];
+    }
+  };
+
+  const bool do_bias = chunk == 0 && tid < 32;
+  float bsum = 0.f;
+  if (brick_lo < brick_hi) load_brick(brick_lo);
+  for (int brick = brick_lo; brick < brick_hi; ++brick) {
+    __syncthreads();
+    store_brick();
+    __syncthreads();
+    if (brick + 1 < brick_hi) load_brick(brick + 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      union { struct { hs16x4 l, h; } s; bf16x8 v; } ua;
+      const uint16_t* pg = &Gs[ks * 16 * LDGH + gbase];
+      ua.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)pg);
+      ua.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(pg + 4 * LDGH));
+      const int slab = ((ks >> 1) * HALO_W * HALO_D + (ks & 1) * 2 * HALO_D) * LDH + hbase;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        if (wave + 4 * i < 27) {
+          union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
+          const uint16_t* px = &halo[slab + tapoff[i]];
+          ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
+          ub.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(px + 4 * LDH));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (do_bias) {
+#pragma unroll 8
+      for (int r = 0; r < 128; ++r) bsum += bf16_to_f32(Gs[r * LDGH + tid]);
+    }
+  }
+
+  float* pz = a.part + (long long)blockIdx.z * a.npad * a.kpad;
+  if (do_bias && n_blk + tid < a.N) a.bpart[(long long)blockIdx.z * a.npad + n_blk + tid] = bsum;
+  const int c = chunk * a.CC + li;
+  if (li >= a.CC || c >= a.C) return;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap >= 27) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n_blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < a.N) pz[(long long)n * a.kpad + tap * a.C + c] = acc[i][r];
+    }
+  }
+}
+
+static int whalo_blocks() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LTU_WHALO_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 512; }
+  return v;
+}
+
+static bool whalo_shape_ok(int C, int N) { return N % 8 == 0 && N <= 64 && (C % 16 == 0 || C == 8); }
+
+long long conv_wgrad_halo_ws_floats(int N, int K) {
+  if (K % 27) return 0;
+  const int C = K / 27;
+  if (!whalo_shape_ok(C, N)) return 0;
+  const int CC = C % 32 == 0 ? 32 : 16;
+  long long ns = whalo_blocks() / ((long long)cdiv(C, CC) * cdiv(N, 32));
+  if (ns < 1) ns = 1;
+  return ns * N * ((long long)K + 1);
+}
+
+// fills part/bpart/npad/kpad/splits; returns LTU_OK after launching, or 1 when the shape is not handled
+int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
+  if (!whalo_shape_ok(a.C, a.N) || a.c0 % 8 || a.lda0 % 8 || a.lda1 % 8 || a.ldg % 8) return 1;
+  if (a.H < 2 || a.W < 2 || a.D < 4) return 1;
+  a.CC = a.C % 32 == 0 ? 32 : 16;
+  const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
+  if (bricks >= (1LL << 31)) return 1;
+  const int nchunk = cdiv(a.C, a.CC), ntile = cdiv(a.N, 32);
+  long long ns = whalo_blocks() / ((long long)nchunk * ntile);
+  if (ns < 1) ns = 1;
+  if (ns > bricks) ns = bricks;
+  a.bricks = (int)bricks;
+  a.bricks_per_split = (int)((bricks + ns - 1) / ns);
+  const int nsplit = (int)((bricks + a.bricks_per_split - 1) / a.bricks_per_split);
+  a.npad = a.N;
+  a.kpad = 27 * a.C;
+  a.bpart = a.part + (long long)nsplit * a.npad * a.kpad;
+  *nsplit_out = nsplit;
+  hipLaunchKernelGGL(conv3_wgrad_halo_bf16_kernel, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
+  return ltu_check_launch();
+}

@@ -375,7 +375,10 @@ extern "C" int ltu_linear_fwd(const void* a, int lda, const void* const* w, int 
   return launch_nt<float, float>(g, (hipStream_t)s);
 }
 
-extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) { return tn_geometry(M, N, K, 32).ws_floats; }
+extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) {
+  const long long tn = tn_geometry(M, N, K, 32).ws_floats, halo = conv_wgrad_halo_ws_floats(N, K);
+  return tn > halo ? tn : halo;
+}
 
 extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw,
                                 int M, int N, int K, float* ws, int dtype, ltu_stream_t s) {
@@ -476,6 +479,22 @@ extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1
   wa.g.a0 = x0; wa.g.a1 = x1 ? x1 : x0;
   wa.grad = grad; wa.ldg = Co; wa.dw = dwf; wa.db = db; wa.t_co = torch_co; wa.t_ci = torch_ci;
   wa.part = dtype == LTU_BF16 ? ws : nullptr; wa.nseg_w = 1;
+  if (dtype == LTU_BF16 && ws != nullptr && sh == 1 && sw == 1 && sd == 1 && !ups && use_halo()) {
+    WHaloArgs h;
+    memset(&h, 0, sizeof(h));
+    h.x0 = x0; h.x1 = x1 ? x1 : x0; h.grad = grad;
+    h.B = B; h.H = Hi; h.W = Wi; h.D = Di;
+    h.C = C0 + C1; h.c0 = C0; h.lda0 = C0; h.lda1 = C1 > 0 ? C1 : C0;
+    h.N = Co; h.ldg = Co; h.part = ws;
+    int nsplit = 0;
+    const int hr = launch_conv_wgrad_halo_bf16(h, &nsplit, (hipStream_t)s);
+    if (hr == LTU_OK) {
+      wa.npad = Co; wa.kpad = 27 * (C0 + C1);
+      wa.bpart = ws + (long long)nsplit * wa.npad * wa.kpad;
+      return launch_wgrad_reduce(wa, nsplit, (hipStream_t)s);
+    }
+    if (hr != 1) return hr;
+  }
   if (dtype == LTU_BF16) return launch_tn_bf16(wa, (hipStream_t)s);
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_tn<float>(wa, (hipStream_t)s);

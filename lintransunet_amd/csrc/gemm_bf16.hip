@@ -567,6 +567,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
   }
 }
 
+int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st) {
+  const long long total = (long long)wa.g.N * wa.g.K + wa.g.N;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, wa, nsplit);
+  return ltu_check_launch();
+}
+
 int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   const IGemmArgs& g = wa.g;
   if (g.M <= 0 || g.N <= 0) return LTU_OK;

@@ -107,3 +107,21 @@ struct HaloArgs {
   int CC;               // channel chunk: 16 or 32 (chosen by the launcher)
 };
 int launch_conv_halo_bf16(HaloArgs a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled (fall back)
+
+// LDS-halo weight gradient of the stride-1 3x3x3 convs (conv_halo.hip), two-stage through part / wgrad_reduce_kernel
+struct WHaloArgs {
+  const void* x0;
+  const void* x1;
+  const void* grad;     // [voxels][ldg]
+  int B, H, W, D;
+  int C, c0, lda0, lda1;
+  int N, ldg;
+  int CC;               // channel chunk per workgroup: 16 or 32
+  int bricks, bricks_per_split;
+  float* part;          // [nsplit][npad][kpad]
+  float* bpart;         // [nsplit][npad]
+  int npad, kpad;
+};
+long long conv_wgrad_halo_ws_floats(int N, int K);
+int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st);   // LTU_OK / hipError, or 1 = not handled
+int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st);

@@ -108,6 +108,9 @@ def test_linear_bf16(ops, M, K, N, nw):
     (1, 16, 8, 3, 4, 2, (1, 1, 1), 0, True, None),
     (1, 32, 2, 5, 4, 6, (1, 1, 1), 0, False, 8),
     (1, 64, 128, 4, 4, 4, (1, 1, 1), 0, False, None),
+    (2, 32, 32, 9, 7, 12, (1, 1, 1), 32, False, None),   # halo kernels: two channel chunks, ragged bricks
+    (1, 16, 64, 8, 8, 16, (1, 1, 1), 16, False, None),   # halo kernels: chunk spanning both concat sources, two column tiles
+    (3, 16, 16, 4, 12, 8, (1, 1, 1), 0, False, None),
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
