@@ -377,7 +377,8 @@ extern "C" int ltu_linear_fwd(const void* a, int lda, const void* const* w, int 
 
 extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) {
   const long long tn = tn_geometry(M, N, K, 32).ws_floats, halo = conv_wgrad_halo_ws_floats(N, K);
-  return tn > halo ? tn : halo;
+  const long long ring = tn_ring_ws_floats(M, N, K);
+  return tn > halo ? (tn > ring ? tn : ring) : (halo > ring ? halo : ring);
 }
 
 extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw,

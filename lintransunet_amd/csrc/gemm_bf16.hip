@@ -578,6 +578,10 @@ int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return LTU_OK;
   if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.N % 8 || wa.ldg % 8) return LTU_E_SHAPE;
+  {
+    const int rr = launch_tn_ring_bf16(wa, st);
+    if (rr != 1) return rr;
+  }
   const TnGeom t = tn_geometry(g.M, g.N, g.K, 32);
   wa.rows_per_split = t.rows;
   if (wa.part != nullptr) {

@@ -125,3 +125,8 @@ struct WHaloArgs {
 long long conv_wgrad_halo_ws_floats(int N, int K);
 int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st);   // LTU_OK / hipError, or 1 = not handled
 int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st);
+
+// LDS-DMA ring kernels for the dense projections (gemm_ring.hip)
+bool tn_ring_shape_ok(long long M, int N, int K);
+long long tn_ring_ws_floats(long long M, int N, int K);
+int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled
