@@ -18,12 +18,13 @@ struct bf16_t {
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// round-to-nearest-even, NaN stays NaN: the gfx950 hardware conversion (v_cvt_pk_bf16_f32)
+typedef __bf16 ltu_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ltu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const ltu_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ltu_bf16x2));
 }
 
 // ---- 4-wide vector access (the unit every pointwise kernel works in) ---------------------------
@@ -49,8 +50,8 @@ struct Vec4<bf16_t> {
   }
   static __device__ __forceinline__ void store(bf16_t* p, float4 v) {
     uint2 r;
-    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    r.x = pack_bf16x2(v.x, v.y);
+    r.y = pack_bf16x2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
   }
 };

@@ -298,8 +298,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
       const float s1 = bf16_to_f32((uint16_t)(v.x >> 16)) + bf16_to_f32((uint16_t)(o.x >> 16));
       const float s2 = bf16_to_f32((uint16_t)(v.y & 0xffff)) + bf16_to_f32((uint16_t)(o.y & 0xffff));
       const float s3 = bf16_to_f32((uint16_t)(v.y >> 16)) + bf16_to_f32((uint16_t)(o.y >> 16));
-      v.x = (uint32_t)f32_to_bf16(s0) | ((uint32_t)f32_to_bf16(s1) << 16);
-      v.y = (uint32_t)f32_to_bf16(s2) | ((uint32_t)f32_to_bf16(s3) << 16);
+      v.x = pack_bf16x2(s0, s1);
+      v.y = pack_bf16x2(s2, s3);
     }
     *reinterpret_cast<uint2*>(dst) = v;
   }
@@ -339,6 +339,10 @@ int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
   if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.wrow % 8 || g.N % 4 || g.n0 % 4 || g.ldo0 % 4 || g.ldo1 % 4)
     return LTU_E_SHAPE;
+  {
+    const int rr = launch_nt_ring_bf16(g, st);
+    if (rr != 1) return rr;
+  }
   static int small_tile = -1;
   if (small_tile < 0) { const char* e = getenv("LTU_NT_SMALLTILE"); small_tile = e ? atoi(e) : 0; }
   if (g.N > 64) {

@@ -129,4 +129,5 @@ int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st);
 // LDS-DMA ring kernels for the dense projections (gemm_ring.hip)
 bool tn_ring_shape_ok(long long M, int N, int K);
 long long tn_ring_ws_floats(long long M, int N, int K);
-int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled
+int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st);
+int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled

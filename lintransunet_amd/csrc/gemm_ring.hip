@@ -146,6 +146,187 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
   }
 }
 
+// ------------------------------------------------------------------------------------------------ NT (projection)
+// Y[M][N] = A[M][K] W^T + bias for one column tile of BN = 64 TNW columns; the workgroup is PERSISTENT over row tiles.
+//   * its W tile [BN][K] is fetched once and stays in LDS ("weight stationary"): the k-loop has no weight traffic at all;
+//   * A streams through the ring in units of [128 rows][64 k] (16 KB), R - 1 units in flight, across tile boundaries;
+//   * 128-byte LDS rows, chunk c of row r at slot c ^ (r & 7): conflict-free ds_read_b128 fragments;
+//   * the product is formed transposed (D[n][m]) so a lane owns 4 consecutive n of one row: 8-byte staging writes into the
+//     ring slot just consumed (wave-private quarter), 16-byte row-major reads, 16-byte global stores.
+// vmcnt book-keeping: loads and stores retire in order, so the wait after an epilogue allows for its S stores as well
+// (exact only when every store was issued, i.e. for full tiles; otherwise the stricter count is used).
+template <int WM, int TNW, int R>
+__global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmArgs g, int tiles_m) {
+  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
+  constexpr int NW = 2 * WM, TM = 4 / WM, BN = 64 * TNW, AUNIT = 128 * 64;
+  constexpr int PW = 16 / NW;                               // LDS-DMA pieces of an A unit per wave
+  constexpr int S = 2 * TM * TNW;                           // global stores per wave and tile
+  const int KC = g.K >> 6;
+  uint16_t* Wl = smem;                                      // [KC][BN][64]
+  uint16_t* ring = smem + KC * BN * 64;                     // [R][128][64]
+  float* bias_l = reinterpret_cast<float*>(ring + R * AUNIT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n_blk = blockIdx.y * BN;
+  const int nper = g.N / g.nseg;
+
+  if (tid < BN) {
+    const int n = n_blk + tid;
+    float v = 0.f;
+    if (n < g.N) {
+      const int seg = n / nper;
+      const float* bp = seg == 0 ? g.bias[0] : (seg == 1 ? g.bias[1] : g.bias[2]);
+      if (bp != nullptr) v = bp[n - seg * nper];
+    }
+    bias_l[tid] = v;
+  }
+  __syncthreads();                                          // nothing asynchronous in flight yet
+
+  const int srow = lane >> 3, lchunk = (lane & 7) ^ srow;   // LDS-DMA piece = 8 rows x 128 B
+  {
+    const int wpieces = KC * (BN / 8);
+    for (int p = wave; p < wpieces; p += NW) {
+      const int kc = p / (BN / 8), r8 = p - kc * (BN / 8);
+      int n = n_blk + r8 * 8 + srow;
+      if (n >= g.N) n = g.N - 1;
+      const int seg = n / nper;
+      const uint16_t* wp = reinterpret_cast<const uint16_t*>(seg == 0 ? g.w[0] : (seg == 1 ? g.w[1] : g.w[2]));
+      glds16(wp + (long long)(n - seg * nper) * g.K + kc * 64 + lchunk * 8, Wl + (kc * BN + r8 * 8) * 64);
+    }
+  }
+
+  const int ntile = (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int nunits = ntile * KC;
+  const uint16_t* xbase = reinterpret_cast<const uint16_t*>(g.a0) + lchunk * 8;
+  int it_t = blockIdx.x, it_kc = 0;
+  auto issue = [&](int slot) {
+    uint16_t* base = ring + slot * AUNIT + wave * 512;
+#pragma unroll
+    for (int s = 0; s < PW; ++s) {
+      long long row = (long long)it_t * 128 + (wave + NW * s) * 8 + srow;
+      if (row >= g.M) row = g.M - 1;
+      glds16(xbase + row * g.lda0 + it_kc * 64, base + s * NW * 512);
+    }
+    if (++it_kc == KC) { it_kc = 0; it_t += gridDim.x; }
+  };
+
+  f32x16 acc[TM][TNW];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = li & 7;
+  const int a_off = (wm * 32 * TM + li) * 64, w_off = (wn * 32 * TNW + li) * 64;
+  int kc = 0, tile = blockIdx.x;
+  bool after_store = false;
+  for (int u = 0; u < R - 1 && u < nunits; ++u) issue(u);
+  for (int q = 0; q < nunits; ++q) {
+    if (q + R - 2 < nunits) {
+      if (after_store) ring_sync<PW * (R - 2) + S>(); else ring_sync<PW * (R - 2)>();
+    } else {
+      ring_sync<0>();
+    }
+    after_store = false;
+    if (q + R - 1 < nunits) issue((q + R - 1) % R);
+    const uint16_t* As = ring + (q % R) * AUNIT + a_off;
+    const uint16_t* Ws = Wl + kc * BN * 64 + w_off;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int co = ((ks * 2 + lh) ^ sw) << 3;
+      bf16x8 af[TM], wf[TNW];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 64 + co);
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Ws + j * 32 * 64 + co);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (++kc < KC) continue;
+
+    // ---- tile finished: stage 32 x 32 sub-tiles through this unit's slot (every wave is done with it after the barrier)
+    asm volatile("s_barrier" ::: "memory");
+    uint16_t* stg = ring + (q % R) * AUNIT + wave * 1024;    // wave-private [32][32] bf16, 4 chunks per row
+    const bool full = (long long)(tile + 1) * 128 <= g.M && n_blk + BN <= g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float4 bv = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
+          uint2 pk;
+          pk.x = pack_bf16x2(acc[i][j][4 * rr + 0] + bv.x, acc[i][j][4 * rr + 1] + bv.y);
+          pk.y = pack_bf16x2(acc[i][j][4 * rr + 2] + bv.z, acc[i][j][4 * rr + 3] + bv.w);
+          *reinterpret_cast<uint2*>(stg + li * 32 + ((rr ^ (li & 3)) << 3) + 4 * lh) = pk;
+          acc[i][j][4 * rr + 0] = 0.f; acc[i][j][4 * rr + 1] = 0.f; acc[i][j][4 * rr + 2] = 0.f; acc[i][j][4 * rr + 3] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int idx = lane + 64 * s;
+          const int row = idx >> 2, ch = idx & 3;
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + row * 32 + ((ch ^ (row & 3)) << 3));
+          const long long grow = (long long)tile * 128 + wm * 32 * TM + i * 32 + row;
+          const int gcol = n_blk + wn * 32 * TNW + j * 32 + ch * 8;
+          uint16_t* dst = reinterpret_cast<uint16_t*>(g.o0) + grow * g.ldo0 + gcol;
+          if (full) *reinterpret_cast<uint4*>(dst) = v;
+          else if (grow < g.M && gcol < g.N) *reinterpret_cast<uint4*>(dst) = v;
+        }
+      }
+    kc = 0;
+    tile += gridDim.x;
+    after_store = full;
+  }
+}
+
+template <int WM, int TNW, int R>
+static int launch_lin_ring(const IGemmArgs& g, hipStream_t st) {
+  const int BN = 64 * TNW;
+  const int tiles_m = (int)((g.M + 127) / 128), nt = cdiv(g.N, BN);
+  int P = 256 / nt;
+  if (P < 1) P = 1;
+  if (P > tiles_m) P = tiles_m;
+  if (P >= 8) P &= ~7;                       // column tiles of one row tile then share an XCD (ids differ by P)
+  const int smem_bytes = BN * g.K * 2 + R * 16384 + BN * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_ring_bf16_kernel<WM, TNW, R>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((linear_ring_bf16_kernel<WM, TNW, R>), dim3(P, nt), dim3(128 * WM), smem_bytes, st, g, tiles_m);
+  return ltu_check_launch();
+}
+
+static bool ring_enabled();
+// dense projection through the weight-stationary ring kernel; returns 1 when the shape is not handled
+int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st) {
+  static int on = -1, w8 = -1;
+  if (on < 0) { const char* e = getenv("LTU_NO_NT_RING"); on = (e && atoi(e)) ? 0 : 1; }
+  if (w8 < 0) { const char* e = getenv("LTU_NT_RING_WAVES"); w8 = (e && atoi(e) == 4) ? 0 : 1; }
+  if (!on || !ring_enabled()) return 1;
+  if (g.ntaps != 1 || g.K != g.C || g.c0 != g.C || !g.out_identity || g.accum || g.n0 != g.N || g.dbg) return 1;
+  if (g.K % 64 || g.K > 768 || g.N % 8 || g.N < 96 || g.M < 512 || g.lda0 % 8 || g.ldo0 % 8 || g.N % g.nseg) return 1;
+  uintptr_t al = (uintptr_t)g.a0 | (uintptr_t)g.o0;
+  for (int i = 0; i < g.nseg; ++i) al |= (uintptr_t)g.w[i];
+  if (al & 15) return 1;
+  if (w8) {
+    if (g.K <= 256) return launch_lin_ring<4, 2, 4>(g, st);
+    if (g.K <= 384) return launch_lin_ring<4, 2, 3>(g, st);
+    if (g.K <= 512) return launch_lin_ring<4, 1, 4>(g, st);
+    return launch_lin_ring<4, 1, 3>(g, st);
+  }
+  if (g.K <= 256) return launch_lin_ring<2, 2, 4>(g, st);
+  if (g.K <= 384) return launch_lin_ring<2, 2, 3>(g, st);
+  if (g.K <= 512) return launch_lin_ring<2, 1, 4>(g, st);
+  return launch_lin_ring<2, 1, 3>(g, st);
+}
+
 #define TN_RING 6
 static int ring_blocks() {
   static int v = -1;

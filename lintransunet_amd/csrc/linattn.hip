@@ -65,10 +65,10 @@ struct GVec<bf16_t> {
   static __device__ __forceinline__ void from_lds(bf16_t* gdst, const float* src) {
     const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
     uint4 v;
-    v.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-    v.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-    v.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-    v.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+    v.x = pack_bf16x2(a.x, a.y);
+    v.y = pack_bf16x2(a.z, a.w);
+    v.z = pack_bf16x2(b.x, b.y);
+    v.w = pack_bf16x2(b.z, b.w);
     *reinterpret_cast<uint4*>(gdst) = v;
   }
 };

@@ -72,7 +72,8 @@ def test_linear(ops, M, K, N, nw):
 
 
 @pytest.mark.parametrize('M,K,N,nw', [(400, 128, 64, 1), (1000, 64, 96, 3), (257, 256, 768, 3), (4100, 32, 32, 1), (300, 128, 8, 1),
-                                      (2048, 128, 384, 3), (8640, 256, 128, 1), (1024, 384, 256, 1), (21504, 128, 128, 1)])   # LDS-DMA ring kernels
+                                      (2048, 128, 384, 3), (8640, 256, 128, 1), (1024, 384, 256, 1), (21504, 128, 128, 1),
+                                      (1000, 512, 200, 1), (777, 768, 264, 3), (5000, 64, 136, 1)])   # LDS-DMA ring kernels
 def test_linear_bf16(ops, M, K, N, nw):
     """bf16 matrix-core path (NT forward / data gradient, transposing-read TN weight gradient); bf16 rounding of
     inputs and outputs bounds the error at ~1e-2 of the tensor's max"""
