@@ -501,142 +501,177 @@ __device__ __forceinline__ void dw_tap(int t, int& dh, int& dw, int& dd) {
   dw = t % 3 - 1;
 }
 
-template <typename T>
-__global__ void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                  T* __restrict__ y, int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step) {
-  extern __shared__ float wl[];   // [27][C]
-  for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wl[(i % 27) * C + i / 27] = w[i];
-  __syncthreads();
-  const int cv = C / 4;
-  const long long n = (long long)B * H * W * D * cv;
+// LDS-halo versions.  A workgroup walks 4x4x8 bricks of output voxels for one 128-byte channel chunk (64 bf16 / 32 fp32
+// channels): the 6x6x10 halo brick is staged in LDS once and the 27 taps are LDS reads at constant offsets (27x fewer
+// vector-memory requests than gathering from global, no per-tap address arithmetic).  A thread owns one channel quad and
+// every NV-th voxel of the brick; its 27 x 4 weights (or weight-gradient accumulators) stay in registers across bricks.
+//   MODE 0: y = mask * (x + conv(x) + bias)      MODE 1: dx = mask * (dy + conv_flipped(dy))
+//   MODE 2: dw[c][t] += sum g' x[v + off_t], db[c] += sum g'   (g' = mask * dy; block-level LDS reduction, then atomics)
+#define DWH_VOX 360
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          T* __restrict__ y, float* __restrict__ dwt, float* __restrict__ db, int B,
+                                                          int H, int W, int D, int C, int bricks, int bricks_per_block, float p,
+                                                          uint64_t seed, const uint64_t* step) {
+  constexpr int CC = 128 / (int)sizeof(T);          // channels per chunk (one 128-byte LDS row per voxel)
+  constexpr int QV = CC / 4;                        // channel quads per voxel
+  constexpr int NV = 256 / QV;                      // voxel slots
+  constexpr int NJ = 128 / NV;                      // outputs per thread and brick
+  __shared__ __attribute__((aligned(16))) T halo[DWH_VOX * CC];
+  __shared__ __attribute__((aligned(16))) T gl[MODE == 2 ? 128 * CC : 4];
+  const int tid = threadIdx.x;
+  const int cq = tid % QV, vs = tid / QV;
+  const int c = blockIdx.x * CC + cq * 4;
+  const bool cok = c < C;
+  const int nbh = (H + 3) / 4, nbw = (W + 3) / 4, nbd = (D + 7) / 8;
   const DropCfg dc = make_drop(p, seed, step);
-  GRID_STRIDE(i, n) {
-    const int v = (int)(i % cv);
-    long long t = i / cv;
-    const int d = (int)(t % D); t /= D;
-    const int ww = (int)(t % W); t /= W;
-    const int hh = (int)(t % H);
-    const int b = (int)(t / H);
-    float4 acc = *reinterpret_cast<const float4*>(bias + v * 4);
-    for (int tp = 0; tp < 27; ++tp) {
-      int dh, dw, dd;
-      dw_tap(tp, dh, dw, dd);
-      const int h2 = hh + dh, w2 = ww + dw, d2 = d + dd;
-      if ((unsigned)h2 >= (unsigned)H || (unsigned)w2 >= (unsigned)W || (unsigned)d2 >= (unsigned)D) continue;
-      const float4 q = Vec4<T>::load(x + ((((long long)b * H + h2) * W + w2) * D + d2) * C + v * 4);
-      const float4 k = *reinterpret_cast<const float4*>(&wl[tp * C + v * 4]);
-      acc.x += q.x * k.x; acc.y += q.y * k.y; acc.z += q.z * k.z; acc.w += q.w * k.w;
-    }
-    const float4 c0 = Vec4<T>::load(x + i * 4);
-    acc.x += c0.x; acc.y += c0.y; acc.z += c0.z; acc.w += c0.w;
-    Vec4<T>::store(y + i * 4, drop4(dc, (uint64_t)(((long long)b * C + v * 4) >> 2), acc));
-  }
-}
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 
-// dx = g' + sum_t w[t] g'(vox - off_t),  g' = dy * chanmask
-template <typename T>
-__global__ void dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B, int H,
-                                       int W, int D, int C, float p, uint64_t seed, const uint64_t* step) {
-  extern __shared__ float wl[];
-  for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wl[(i % 27) * C + i / 27] = w[i];
-  __syncthreads();
-  const int cv = C / 4;
-  const long long n = (long long)B * H * W * D * cv;
-  const DropCfg dc = make_drop(p, seed, step);
-  GRID_STRIDE(i, n) {
-    const int v = (int)(i % cv);
-    long long t = i / cv;
-    const int d = (int)(t % D); t /= D;
-    const int ww = (int)(t % W); t /= W;
-    const int hh = (int)(t % H);
-    const int b = (int)(t / H);
-    float4 acc = Vec4<T>::load(dy + i * 4);
-    for (int tp = 0; tp < 27; ++tp) {
-      int dh, dw, dd;
-      dw_tap(tp, dh, dw, dd);
-      const int h2 = hh - dh, w2 = ww - dw, d2 = d - dd;
-      if ((unsigned)h2 >= (unsigned)H || (unsigned)w2 >= (unsigned)W || (unsigned)d2 >= (unsigned)D) continue;
-      const float4 q = Vec4<T>::load(dy + ((((long long)b * H + h2) * W + w2) * D + d2) * C + v * 4);
-      const float4 k = *reinterpret_cast<const float4*>(&wl[tp * C + v * 4]);
-      acc.x += q.x * k.x; acc.y += q.y * k.y; acc.z += q.z * k.z; acc.w += q.w * k.w;
+  float4 wr[27];                                    // weights (MODE 0/1) or gradient accumulators (MODE 2)
+  float4 bs = z;                                    // bias (MODE 0) or bias-gradient accumulator (MODE 2)
+  if (MODE != 2 && cok) {                           // w[c..c+3][0..26] is one contiguous 432-byte run: 27 vector loads
+    float flat[108];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+      const float4 r = *reinterpret_cast<const float4*>(w + (long long)c * 27 + i * 4);
+      flat[4 * i] = r.x; flat[4 * i + 1] = r.y; flat[4 * i + 2] = r.z; flat[4 * i + 3] = r.w;
     }
-    const float4 m = dropmask4(dc, (uint64_t)(((long long)b * C + v * 4) >> 2));
-    Vec4<T>::store(dx + i * 4, make_float4(acc.x * m.x, acc.y * m.y, acc.z * m.z, acc.w * m.w));
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int ts = MODE == 1 ? 26 - t : t;
+      wr[t] = make_float4(flat[ts], flat[27 + ts], flat[54 + ts], flat[81 + ts]);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wr[t] = z;
   }
-}
+  if (MODE == 0 && cok && bias != nullptr) bs = *reinterpret_cast<const float4*>(bias + c);
 
-// dw[c][t] += sum_vox g'[vox][c] x[vox+off_t][c];  db[c] += sum g'.   grid (chunks, B); a thread owns 4 channels.
-template <typename T>
-__global__ void dwconv_bwd_weight_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dwt,
-                                         float* __restrict__ db, int B, int H, int W, int D, int C, int rows_per_block, float p,
-                                         uint64_t seed, const uint64_t* step) {
-  extern __shared__ float red[];   // [C][28]
-  for (int i = threadIdx.x; i < C * 28; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
-  const int cv = C / 4;
-  const int v = threadIdx.x % cv, rg = threadIdx.x / cv, nrg = blockDim.x / cv;
-  const int b = blockIdx.y;
-  const DropCfg dc = make_drop(p, seed, step);
-  const float4 m = dropmask4(dc, (uint64_t)(((long long)b * C + v * 4) >> 2));
-  float acc[28][4];
-#pragma unroll
-  for (int t = 0; t < 28; ++t)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[t][k] = 0.f;
-  const long long S = (long long)H * W * D;
-  const long long s0 = (long long)blockIdx.x * rows_per_block;
-  long long s1 = s0 + rows_per_block;
-  if (s1 > S) s1 = S;
-  if (rg < nrg) {
-    for (long long sv = s0 + rg; sv < s1; sv += nrg) {
-      const int d = (int)(sv % D);
-      const int ww = (int)((sv / D) % W);
-      const int hh = (int)(sv / ((long long)D * W));
-      float4 g = Vec4<T>::load(dy + ((long long)b * S + sv) * C + v * 4);
-      g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
-      acc[27][0] += g.x; acc[27][1] += g.y; acc[27][2] += g.z; acc[27][3] += g.w;
-#pragma unroll
-      for (int tp = 0; tp < 27; ++tp) {
-        int dh, dw, dd;
-        dw_tap(tp, dh, dw, dd);
-        const int h2 = hh + dh, w2 = ww + dw, d2 = d + dd;
-        if ((unsigned)h2 >= (unsigned)H || (unsigned)w2 >= (unsigned)W || (unsigned)d2 >= (unsigned)D) continue;
-        const float4 q = Vec4<T>::load(x + ((((long long)b * H + h2) * W + w2) * D + d2) * C + v * 4);
-        acc[tp][0] += g.x * q.x; acc[tp][1] += g.y * q.y; acc[tp][2] += g.z * q.z; acc[tp][3] += g.w * q.w;
+  int brick = blockIdx.y * bricks_per_block;
+  int brick_end = brick + bricks_per_block;
+  if (brick_end > bricks) brick_end = bricks;
+  for (; brick < brick_end; ++brick) {
+    int t = brick;
+    const int bd = t % nbd; t /= nbd;
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh;
+    const int b = t / nbh;
+    const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
+    __syncthreads();                                // previous brick fully consumed
+    for (int idx = tid; idx < DWH_VOX * 8; idx += 256) {
+      const int hv = idx >> 3, part = idx & 7;      // 8 x 16 bytes per voxel row
+      const int hd = hv % 10, hw = (hv / 10) % 6, hh = hv / 60;
+      const int h = h0 - 1 + hh, ww = w0 - 1 + hw, d = d0 - 1 + hd;
+      const int cc = blockIdx.x * CC + part * (16 / (int)sizeof(T));
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if ((unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W && (unsigned)d < (unsigned)D && cc < C)
+        v = *reinterpret_cast<const uint4*>(x + ((((long long)b * H + h) * W + ww) * D + d) * C + cc);
+      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(halo) + hv * 128 + part * 16) = v;
+    }
+    if (MODE == 2) {                                // the brick's output gradients: 128 voxels x 128 bytes
+      for (int idx = tid; idx < 128 * 8; idx += 256) {
+        const int ov = idx >> 3, part = idx & 7;
+        const int h = h0 + (ov >> 5), ww = w0 + ((ov >> 3) & 3), d = d0 + (ov & 7);
+        const int cc = blockIdx.x * CC + part * (16 / (int)sizeof(T));
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (h < H && ww < W && d < D && cc < C)
+          v = *reinterpret_cast<const uint4*>(g + ((((long long)b * H + h) * W + ww) * D + d) * C + cc);
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gl) + ov * 128 + part * 16) = v;
       }
     }
+    __syncthreads();
+    if (!cok) continue;
+    const float4 m = dropmask4(dc, (uint64_t)(((long long)b * C + c) >> 2));
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+      const int ov = vs + NV * j;
+      const int oh = ov >> 5, ow = (ov >> 3) & 3, od = ov & 7;
+      const int h = h0 + oh, ww = w0 + ow, d = d0 + od;
+      const bool inside = h < H && ww < W && d < D;
+      const T* hp = halo + ((oh * 6 + ow) * 10 + od) * CC + cq * 4;
+      const long long e = ((((long long)b * H + h) * W + ww) * D + d) * C + c;
+      if (MODE == 2) {
+        float4 gv = Vec4<T>::load(gl + ov * CC + cq * 4);      // zero outside the volume
+        gv.x *= m.x; gv.y *= m.y; gv.z *= m.z; gv.w *= m.w;
+        bs.x += gv.x; bs.y += gv.y; bs.z += gv.z; bs.w += gv.w;
 #pragma unroll
-    for (int tp = 0; tp < 28; ++tp)
+        for (int tp = 0; tp < 27; ++tp) {
+          const int td = tp / 9, th = (tp / 3) % 3, tw = tp % 3;
+          const float4 q = Vec4<T>::load(hp + ((th * 6 + tw) * 10 + td) * CC);
+          wr[tp].x += gv.x * q.x; wr[tp].y += gv.y * q.y; wr[tp].z += gv.z * q.z; wr[tp].w += gv.w * q.w;
+        }
+      } else {
+        const float4 ctr = Vec4<T>::load(hp + ((1 * 6 + 1) * 10 + 1) * CC);
+        float4 acc = make_float4(bs.x + ctr.x, bs.y + ctr.y, bs.z + ctr.z, bs.w + ctr.w);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) atomicAdd(&red[(v * 4 + k) * 28 + tp], acc[tp][k]);   // LDS atomics
+        for (int tp = 0; tp < 27; ++tp) {
+          const int td = tp / 9, th = (tp / 3) % 3, tw = tp % 3;
+          const float4 q = Vec4<T>::load(hp + ((th * 6 + tw) * 10 + td) * CC);
+          acc.x += wr[tp].x * q.x; acc.y += wr[tp].y * q.y; acc.z += wr[tp].z * q.z; acc.w += wr[tp].w * q.w;
+        }
+        if (inside) Vec4<T>::store(y + e, make_float4(acc.x * m.x, acc.y * m.y, acc.z * m.z, acc.w * m.w));
+      }
+    }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * 28; i += blockDim.x) {
-    const int c = i / 28, tp = i % 28;
-    if (tp < 27) atomicAdd(dwt + (long long)c * 27 + tp, red[i]);
-    else atomicAdd(db + c, red[i]);
+  if (MODE == 2) {
+    // reduce over the voxel slots: lanes l, l+16, l+32, l+48 of a wave share a channel quad (bf16; l, l+8, .. for fp32) ->
+    // cross-lane adds, then the 4 wave sums meet in LDS (the halo region is free now).  No LDS atomics: they cost ~200
+    // cycles per wave instruction on this chip.
+    __syncthreads();
+    float* wsum = reinterpret_cast<float*>(halo);       // [4 waves][28][CC]
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int tp = 0; tp < 28; ++tp) {
+      float4 v = tp < 27 ? wr[tp] : bs;
+#pragma unroll
+      for (int o = QV; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+      }
+      if (lane < QV) *reinterpret_cast<float4*>(wsum + (wave * 28 + tp) * CC + lane * 4) = v;
+    }
+    __syncthreads();
+    // consecutive lanes -> consecutive gradient addresses: dwt[chunk channels][27] is one contiguous run
+    for (int f = tid; f < 27 * CC; f += 256) {
+      const int cl = f / 27, tp = f - cl * 27;
+      if (blockIdx.x * CC + cl >= C) continue;
+      const float v = wsum[tp * CC + cl] + wsum[(28 + tp) * CC + cl] + wsum[(56 + tp) * CC + cl] + wsum[(84 + tp) * CC + cl];
+      atomicAdd(dwt + (long long)blockIdx.x * CC * 27 + f, v);
+    }
+    if (tid < CC && blockIdx.x * CC + tid < C) {
+      const float v = wsum[27 * CC + tid] + wsum[(28 + 27) * CC + tid] + wsum[(56 + 27) * CC + tid] + wsum[(84 + 27) * CC + tid];
+      atomicAdd(db + blockIdx.x * CC + tid, v);
+    }
   }
+}
+
+template <typename T, int MODE>
+static void launch_dwconv_halo(const void* x, const void* g, const float* w, const float* bias, void* y, float* dwt, float* db, int B,
+                               int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, hipStream_t st) {
+  constexpr int CC = 128 / (int)sizeof(T);
+  const int nchunk = cdiv(C, CC);
+  const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
+  long long nblk = (MODE == 2 ? 512 : 1024) / nchunk;      // fewer, longer-lived workgroups for the reduction
+  if (nblk < 1) nblk = 1;
+  if (nblk > bricks) nblk = bricks;
+  const int bpb = (int)((bricks + nblk - 1) / nblk);
+  nblk = (bricks + bpb - 1) / bpb;
+  hipLaunchKernelGGL((dwconv_halo_kernel<T, MODE>), dim3(nchunk, (unsigned)nblk), dim3(256), 0, st, (const T*)x, (const T*)g, w, bias,
+                     (T*)y, dwt, db, B, H, W, D, C, (int)bricks, bpb, p, seed, step);
 }
 
 extern "C" int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C,
                               float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
-  if (C % 4) return LTU_E_SHAPE;
-  const long long n = (long long)B * H * W * D * (C / 4);
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((dwconv_fwd_kernel<T>), dim3(sgrid(n)), dim3(256), 27 * C * sizeof(float), (hipStream_t)s, (const T*)x, w, bias, (T*)y, B, H, W, D, C, p, seed, step); });
+  if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
+  LTU_DISPATCH_T(dtype, { launch_dwconv_halo<T, 0>(x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s); });
   return ltu_check_launch();
 }
 extern "C" int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dwt, float* db, int B, int H,
                               int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
-  if (C % 4 || 256 % (C / 4)) return LTU_E_SHAPE;
-  const long long n = (long long)B * H * W * D * (C / 4);
-  const long long S = (long long)H * W * D;
-  long long want = 512 / (B > 0 ? B : 1);
-  if (want < 1) want = 1;
-  long long rows = (S + want - 1) / want;
-  if (rows < 32) rows = 32;
+  if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
   LTU_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((dwconv_bwd_data_kernel<T>), dim3(sgrid(n)), dim3(256), 27 * C * sizeof(float), (hipStream_t)s, (const T*)dy, w, (T*)dx, B, H, W, D, C, p, seed, step);
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T>), dim3(cdiv(S, rows), B), dim3(256), (size_t)C * 28 * sizeof(float), (hipStream_t)s, (const T*)dy, (const T*)x, dwt, db, B, H, W, D, C, (int)rows, p, seed, step);
+    launch_dwconv_halo<T, 1>(dy, nullptr, w, nullptr, dx, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s);
+    launch_dwconv_halo<T, 2>(x, dy, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s);
   });
   return ltu_check_launch();
 }

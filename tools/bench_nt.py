@@ -47,11 +47,13 @@ def run(M, K, N):
     print(f'M={M:7d} K={K:4d} N={N:4d}: fwd {t:7.1f} us  {byts / t / 1e6:5.2f} TB/s {2 * M * K * N / t / 1e6:6.0f} TF | '
           f'wgrad(+reduce) {tw:7.1f} us {byts / tw / 1e6:5.2f} TB/s', flush=True)
 
-shapes = [(114816, 128, 128), (114816, 128, 256), (114816, 256, 128), (114816, 128, 384), (114816, 384, 128),
-          (21504, 256, 256), (21504, 256, 512), (21504, 512, 256), (21504, 256, 768), (8640, 256, 512), (1024, 256, 512)]
-if len(sys.argv) > 3:
-    a = list(map(int, sys.argv[1:]))
-    shapes = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)]
-print('variant', os.environ.get('LTU_NT_VARIANT', '0'), 'dbg', os.environ.get('LTU_NT_DBG', '0'))
-for s in shapes:
-    run(*s)
+if __name__ == "__main__":
+    shapes = [(114816, 128, 128), (114816, 128, 256), (114816, 256, 128), (114816, 128, 384), (114816, 384, 128),
+              (21504, 256, 256), (21504, 256, 512), (21504, 512, 256), (21504, 256, 768), (8640, 256, 512), (1024, 256, 512)]
+    if len(sys.argv) > 3:
+        a = list(map(int, sys.argv[1:]))
+        shapes = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)]
+    print('variant', os.environ.get('LTU_NT_VARIANT', '0'), 'dbg', os.environ.get('LTU_NT_DBG', '0'))
+    for s in shapes:
+        run(*s)
+
