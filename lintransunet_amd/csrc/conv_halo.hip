@@ -11,6 +11,8 @@
 //   K     = 27 taps x C channels, walked chunk by chunk (outer) and tap by tap (inner)
 //   N     = output channels, BN per workgroup (32 / 64 / 128)
 // Data gradient = same kernel on the output gradient with mirrored tap offsets and the [Ci][27][Co] operand.
+#include <type_traits>
+
 #include "gemm_desc.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -389,5 +391,421 @@ int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
   a.bpart = a.part + (long long)nsplit * a.npad * a.kpad;
   *nsplit_out = nsplit;
   hipLaunchKernelGGL(conv3_wgrad_halo_bf16_kernel, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
+  return ltu_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "Class" convolutions: every output voxel o = m q + p of a finer grid (m = 1 or 2 per axis, p < m its parity class) is a
+// small stencil over the COARSE grid around q.  Two layers of the network have this shape:
+//   * nearest-x2 upsampling + 3x3x3 conv (the ROI token un-embedding): 8 classes x 8 taps (sub-pixel form, upconv.hip);
+//   * the data gradient of a stride-2 (or 2,2,1) 3x3x3 conv: class p of an axis sees tap 1 (p = 0) or taps 0 and 2 (p = 1).
+// As 8 separate implicit GEMMs the coarse tensor is gathered once per (class, tap): 27-64 times.  Here a workgroup owns a
+// 4x4x8 brick of coarse voxels, stages its halo once per 32-channel chunk and produces ALL classes from it: the stream of
+// (class, offset, weight tile) entries only moves an LDS offset and selects an accumulator.
+template <int NC, int TN>
+__global__ void __launch_bounds__(256) conv_class_halo_bf16_kernel(const ClassHaloArgs a) {
+  constexpr int BN = 32 * TN, TS = 4;
+  constexpr int HALO_ELEMS = HALO_VOX * LDH, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
+  constexpr int SMEM_ELEMS = (HALO_ELEMS + B_ELEMS) > STAGE_ELEMS ? (HALO_ELEMS + B_ELEMS) : STAGE_ELEMS;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
+  uint16_t* halo = smem;                   // [HALO_VOX][LDH]
+  uint16_t* Bs = smem + HALO_ELEMS;        // [2][TS][BN][LDH]
+  constexpr int LBV = TS * BN * 4 / 256;   // weight vectors per thread and stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
+  int bid = blockIdx.x;
+  const int bd = bid % nbd; bid /= nbd;
+  const int bw = bid % nbw; bid /= nbw;
+  const int bh = bid % nbh;
+  const int b = bid / nbh;
+  const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
+  const int n_blk = blockIdx.y * BN;
+  const int nchunk = a.C / 32;
+  const int nstage = (a.nent + TS - 1) / TS;
+
+  f32x16 acc[NC][TN];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+
+  // wave w owns brick rows 32w..32w+31 = the h-plane w of the brick; row r -> (w, (r >> 3) & 3, r & 7)
+  const int arow = ((wave * HALO_W + (li >> 3)) * HALO_D + (li & 7)) * LDH + lh * 8;
+
+  uint4 hreg[6];
+  auto load_halo = [&](int chunk) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int idx = tid + p * 256;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (idx < HALO_VOX * 4) {
+        const int hv = idx >> 2, part = idx & 3;
+        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+        const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
+          v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.x) +
+                                              ((((long long)b * a.H + h) * a.W + w) * a.D + d) * a.lda + chunk * 32 + part * 8);
+      }
+      hreg[p] = v;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int idx = tid + p * 256;
+      if (idx < HALO_VOX * 4) *reinterpret_cast<uint4*>(&halo[(idx >> 2) * LDH + (idx & 3) * 8]) = hreg[p];
+    }
+  };
+  uint4 breg[LBV];
+  auto load_b = [&](int chunk, int stage) {
+#pragma unroll
+    for (int p = 0; p < LBV; ++p) {
+      const int idx = tid + p * 256;
+      const int part = idx & 3, nl = (idx >> 2) % BN, t = idx / (4 * BN);
+      const int n = n_blk + nl, e = stage * TS + t;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (n < a.N && e < a.nent)
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + a.ent[e].wbase + (long long)n * a.wrow + chunk * 32 + part * 8);
+      breg[p] = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < LBV; ++p) {
+      const int idx = tid + p * 256;
+      const int part = idx & 3, nl = (idx >> 2) % BN, t = idx / (4 * BN);
+      *reinterpret_cast<uint4*>(&Bs[((buf * TS + t) * BN + nl) * LDH + part * 8]) = breg[p];
+    }
+  };
+
+  load_halo(0);
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();                       // previous chunk fully consumed (halo and both weight buffers)
+    store_halo();
+    load_b(chunk, 0);
+    store_b(0);
+    __syncthreads();
+    if (chunk + 1 < nchunk) load_halo(chunk + 1);
+    for (int s = 0; s < nstage; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nstage) load_b(chunk, s + 1);
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        const int e = s * TS + t;
+        if (e < a.nent) {
+          const ClsEntry en = a.ent[e];
+          const int tapoff = (((en.dh + 1) * HALO_W + (en.dw + 1)) * HALO_D + (en.dd + 1)) * LDH;
+          bf16x8 av[2], bv[2][TN];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            av[ks] = *reinterpret_cast<const bf16x8*>(&halo[arow + tapoff + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              bv[ks][j] = *reinterpret_cast<const bf16x8*>(&Bs[((buf * TS + t) * BN + j * 32 + li) * LDH + ks * 16 + lh * 8]);
+          }
+#define CLS_BODY(c)                                                                                         \
+  case c:                                                                                                   \
+    if (c < NC) {                                                                                           \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
+        acc[c < NC ? c : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks], bv[ks][j], acc[c < NC ? c : 0][j], 0, 0, 0); \
+    }                                                                                                       \
+    break;
+          switch (en.cls) {
+            CLS_BODY(0) CLS_BODY(1) CLS_BODY(2) CLS_BODY(3) CLS_BODY(4) CLS_BODY(5) CLS_BODY(6) CLS_BODY(7)
+            default: break;
+          }
+#undef CLS_BODY
+        }
+      }
+      if (s + 1 < nstage) store_b(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue, class by class: bias, convert, stage the 128 x BN tile in LDS, 8-byte stores to the fine grid
+  uint16_t* Cs = smem;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c >= a.ncls) break;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = j * 32 + li;
+      const int n = n_blk + nl;
+      const float bvv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Cs[ml * LDC + nl] = f32_to_bf16(acc[c][j][r] + bvv);
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 4;
+    const int ph = a.cls_p[c][0], pw = a.cls_p[c][1], pd = a.cls_p[c][2];
+    for (int idx = tid; idx < 128 * CPR; idx += 256) {
+      const int ml = idx / CPR, nl = (idx % CPR) * 4;
+      const int n = n_blk + nl;
+      const int qh = h0 + (ml >> 5), qw = w0 + ((ml >> 3) & 3), qd = d0 + (ml & 7);
+      const int h = qh * a.mh + ph, w = qw * a.mw + pw, d = qd * a.md + pd;
+      if (n >= a.N || qh >= a.H || qw >= a.W || qd >= a.D || h >= a.Hh || w >= a.Wh || d >= a.Dh) continue;
+      const long long vox = (((long long)b * a.Hh + h) * a.Wh + w) * a.Dh + d;
+      const uint2 v = *reinterpret_cast<const uint2*>(&Cs[ml * LDC + nl]);
+      uint16_t* dst = n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + vox * a.ldo0 + n
+                               : reinterpret_cast<uint16_t*>(a.o1) + vox * a.ldo1 + (n - a.n0);
+      *reinterpret_cast<uint2*>(dst) = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- the same computation with everything asynchronous (LDS-DMA) -------------------------------------------------------
+// The register-staged version above keeps 8 accumulator tiles per wave, which leaves one workgroup per CU: nothing hides the
+// L2 round trip of each weight stage.  Here a workgroup owns a 4x8x8 brick (256 coarse voxels, 4 waves x 64 rows), the weight
+// tiles stream through a 4-deep ring of 16 KB stages and the halo of the next channel chunk lands in a second buffer, all by
+// global_load_lds with hand-counted vmcnt (see gemm_ring.hip for the idiom).  64-byte LDS rows, chunk c of row r at slot
+// c ^ ((r >> 2) & 1) (conflict-free ds_read_b128 per 8-lane group).  Entries arrive sorted by offset so that an A fragment
+// is fetched once per distinct offset (27 instead of 64 for the un-embedding); each B fragment feeds two row tiles.
+__device__ __attribute__((aligned(64))) uint32_t ltu_zero_line[32];     // source of out-of-volume / padding rows
+
+__device__ __forceinline__ void cglds16(const uint16_t* src, uint16_t* lds_wave_base) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void cring_sync() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+#define CR_HVOX 600          // 6 x 10 x 10 halo voxels
+#define CR_HROWS 640         // padded to 40 LDS-DMA pieces of 16 rows
+template <int I, int N, class F>
+__device__ __forceinline__ void cr_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    cr_static_for<I + 1, N>(f);
+  }
+}
+// The weight stream is organised class by class: stage (chunk, class c, sub-stage sc) holds up to TS entries of class c, so
+// the accumulator a stage updates is known at compile time (a run-time class index makes hipcc shuffle all 256 accumulator
+// registers around every entry).  SPCLS sub-stages per class; entries e in [cls_begin[c], cls_begin[c + 1]).
+template <int NC, int TN, int SPCLS>
+__global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHaloArgs a) {
+  static_assert(NC * TN == 8, "8 accumulator tile pairs per wave");
+  constexpr int BN = 32 * TN, TS = 8 / TN, R = 4, SPC = NC * SPCLS;
+  constexpr int HBUF = CR_HROWS * 32, WSTAGE = TS * BN * 32;       // elements (bf16)
+  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
+  uint16_t* halo = smem;                   // [2][640][32]
+  uint16_t* ring = smem + 2 * HBUF;        // [R][TS][BN][32]
+  // the entry table lives in LDS: indexing the kernel-argument copy per lane would be a vector-memory load inside the
+  // asynchronous span (and hipcc drains vmcnt to 0 for it)
+  int* s_doff = reinterpret_cast<int*>(ring + R * WSTAGE);   // halo voxel offset of the entry
+  int* s_wbase = s_doff + 64;
+  int* s_cb = s_wbase + 64;                                   // class -> first entry; [NC] = end
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nbh = (a.H + 3) / 4, nbw = (a.W + 7) / 8, nbd = (a.D + 7) / 8;
+  int bid = blockIdx.x;
+  const int bd = bid % nbd; bid /= nbd;
+  const int bw = bid % nbw; bid /= nbw;
+  const int bh = bid % nbh;
+  const int b = bid / nbh;
+  const int h0 = bh * 4, w0 = bw * 8, d0 = bd * 8;
+  const int n_blk = blockIdx.y * BN;
+  const int nchunk = a.C / 32;
+  const int total = nchunk * SPC;
+  const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(ltu_zero_line) + (lane & 3) * 8;
+  if (tid < 64) {
+    const ClsEntry en = a.ent[tid < a.nent ? tid : 0];
+    s_doff[tid] = (en.dh * 10 + en.dw) * 10 + en.dd;
+    s_wbase[tid] = tid < a.nent ? en.wbase : -1;
+    if (tid <= 8) s_cb[tid] = a.cls_begin[tid];
+  }
+  __syncthreads();                                           // nothing asynchronous in flight yet
+
+  // LDS-DMA lane geometry: piece = 16 rows x 64 B, lane -> (row lane >> 2, slot lane & 3), logical chunk = slot ^ ((row >> 2) & 1)
+  const int prow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 1);
+
+  auto issue_halo = [&](int chunk) {
+    uint16_t* hb = halo + (chunk & 1) * HBUF;
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+      const int piece = wave * 10 + s;
+      const int hv = piece * 16 + prow;
+      const int hd = hv % 10, hw = (hv / 10) % 10, hh = hv / 100;
+      const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+      const uint16_t* src = zsrc;
+      if (hv < CR_HVOX && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
+        src = reinterpret_cast<const uint16_t*>(a.x) + ((((long long)b * a.H + h) * a.W + w) * a.D + d) * a.lda + chunk * 32 + lchunk * 8;
+      cglds16(src, hb + piece * 512);
+    }
+  };
+  auto issue_w = [&](int g) {
+    const int chunk = g / SPC, st = g - chunk * SPC;
+    const int c = st / SPCLS, sc = st - c * SPCLS;
+    const int e0 = s_cb[c] + sc * TS, e1 = s_cb[c + 1];
+    uint16_t* wb = ring + (g % R) * WSTAGE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int piece = wave * 4 + s;                  // 16 pieces of 16 rows per stage
+      const int row = piece * 16 + prow;               // = t * BN + n_local
+      const int t = row / BN, nl = row - t * BN;
+      const int e = e0 + t, n = n_blk + nl;
+      const uint16_t* src = zsrc;
+      if (e < e1 && n < a.N)
+        src = reinterpret_cast<const uint16_t*>(a.w) + s_wbase[e] + (long long)n * a.wrow + chunk * 32 + lchunk * 8;
+      cglds16(src, wb + piece * 512);
+    }
+  };
+
+  f32x16 acc[NC][2][TN];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
+
+  // wave w owns brick rows 64w.. = h-plane w; tile i covers w positions 4i..4i+3; halo voxel of (row, offset 0,0,0 -> +1,+1,+1)
+  int hv0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) hv0[i] = ((wave + 1) * 10 + (i * 4 + (li >> 3) + 1)) * 10 + (li & 7) + 1;
+  const int wsw = (li >> 2) & 1;
+
+  issue_halo(0);
+  for (int g = 0; g < R - 1 && g < total; ++g) issue_w(g);
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const uint16_t* hb = halo + (chunk & 1) * HBUF;
+    cr_static_for<0, SPC>([&](auto ST) {
+      constexpr int st = decltype(ST)::value, c = st / SPCLS, sc = st % SPCLS;
+      const int g = chunk * SPC + st;
+      if (g + 2 < total) {
+        // LDS-DMA issued after W(g): W(g+1), W(g+2) and the halos issued at iterations g-3..g-1 (those with st == 0)
+        constexpr bool near0 = st >= 1 && st <= 3;
+        if (near0 && chunk + 1 < nchunk) cring_sync<18>(); else cring_sync<8>();
+      } else {
+        cring_sync<0>();
+      }
+      if (g + R - 1 < total) issue_w(g + R - 1);
+      if (st == 0 && chunk + 1 < nchunk) issue_halo(chunk + 1);
+      const uint16_t* wb = ring + (g % R) * WSTAGE;
+      const int e0 = a.cls_begin[c] + sc * TS, e1 = a.cls_begin[c + 1];
+#pragma unroll 2
+      for (int t = 0; t < TS; ++t) {
+        const int e = e0 + t;
+        if (e >= e1) break;
+        const int doff = __builtin_amdgcn_readfirstlane(s_doff[e]);
+        bf16x8 af[2][2], wf[TN][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hv = hv0[i] + doff;
+          const uint16_t* p = hb + hv * 32;
+          const int sw = (hv >> 2) & 1;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(p + (((ks * 2 + lh) ^ sw) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            wf[j][ks] = *reinterpret_cast<const bf16x8*>(wb + (t * BN + j * 32 + li) * 32 + (((ks * 2 + lh) ^ wsw) << 3));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], wf[j][ks], acc[c][i][j], 0, 0, 0);
+      }
+    });
+  }
+
+  // epilogue, class by class (everything asynchronous has landed: the last iterations waited vmcnt(0))
+  constexpr int LDC = BN + 8;
+  uint16_t* Cs = smem;                     // [256][LDC]
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c >= a.ncls) break;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = j * 32 + li;
+      const int n = n_blk + nl;
+      const float bvv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          Cs[ml * LDC + nl] = f32_to_bf16(acc[c][i][j][r] + bvv);
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 4;
+    const int ph = a.cls_p[c][0], pw = a.cls_p[c][1], pd = a.cls_p[c][2];
+    for (int idx = tid; idx < 256 * CPR; idx += 256) {
+      const int ml = idx / CPR, nl = (idx % CPR) * 4;
+      const int n = n_blk + nl;
+      const int qh = h0 + (ml >> 6), qw = w0 + ((ml >> 3) & 7), qd = d0 + (ml & 7);
+      const int h = qh * a.mh + ph, w = qw * a.mw + pw, d = qd * a.md + pd;
+      if (n >= a.N || qh >= a.H || qw >= a.W || qd >= a.D || h >= a.Hh || w >= a.Wh || d >= a.Dh) continue;
+      const long long vox = (((long long)b * a.Hh + h) * a.Wh + w) * a.Dh + d;
+      const uint2 v = *reinterpret_cast<const uint2*>(&Cs[ml * LDC + nl]);
+      uint16_t* dst = n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + vox * a.ldo0 + n
+                               : reinterpret_cast<uint16_t*>(a.o1) + vox * a.ldo1 + (n - a.n0);
+      *reinterpret_cast<uint2*>(dst) = v;
+    }
+  }
+}
+
+// LTU_OK after launching, or 1 when the shape is not handled (the caller keeps its implicit-GEMM path)
+int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st) {
+  if (a.C % 32 || a.lda % 8 || a.N % 4 || a.n0 % 4 || a.ldo0 % 4 || a.ldo1 % 4 || a.wrow % 8) return 1;
+  if (a.H < 2 || a.W < 2 || a.D < 2 || a.nent > 64 || a.ncls > 8) return 1;
+  for (int e = 0; e < a.nent; ++e)
+    if (a.ent[e].wbase % 8) return 1;
+  const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
+  if (bricks >= (1LL << 31)) return 1;
+  if (!getenv("LTU_NO_CLASS_RING") && a.ncls >= 3 && a.W >= 4) {
+    // entries grouped by class; the ring kernel holds at most 8 (8 classes) / 12 (4 classes) entries per class
+    ClassHaloArgs r = a;
+    int ne = 0;
+    bool fits = true;
+    for (int c = 0; c < a.ncls; ++c) {
+      r.cls_begin[c] = ne;
+      for (int i = 0; i < a.nent; ++i)
+        if (a.ent[i].cls == c) r.ent[ne++] = a.ent[i];
+      if (ne - r.cls_begin[c] > (a.ncls > 4 ? 8 : 12)) fits = false;
+    }
+    for (int c = a.ncls; c <= 8; ++c) r.cls_begin[c] = ne;
+    if (fits) {
+      const long long rb = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 7) / 8) * ((a.D + 7) / 8);
+      constexpr int smem_bytes = 2 * CR_HROWS * 64 + 4 * 16384 + (64 + 64 + 16) * 4;
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        attr_done = true;
+      }
+      if (a.ncls > 4) hipLaunchKernelGGL((conv_class_ring_bf16_kernel<8, 1, 1>), dim3((unsigned)rb, cdiv(a.N, 32)), dim3(256), smem_bytes, st, r);
+      else hipLaunchKernelGGL((conv_class_ring_bf16_kernel<4, 2, 3>), dim3((unsigned)rb, cdiv(a.N, 64)), dim3(256), smem_bytes, st, r);
+      return ltu_check_launch();
+    }
+  }
+  // 8 classes keep 8 accumulator tiles per wave: 32 columns per workgroup (and more workgroups for the small grids)
+  const bool wide = a.N > 32 && a.ncls <= 4;
+  dim3 grid((unsigned)bricks, cdiv(a.N, wide ? 64 : 32));
+  if (a.ncls <= 4) {
+    if (wide) hipLaunchKernelGGL((conv_class_halo_bf16_kernel<4, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_class_halo_bf16_kernel<4, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_class_halo_bf16_kernel<8, 1>), grid, dim3(256), 0, st, a);
+  }
   return ltu_check_launch();
 }

@@ -520,6 +520,45 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
     if (hr != 1) return hr;
   }
   const int Ho = (Hl - 1) / sh + 1, Wo = (Wl - 1) / sw + 1, Do = (Dl - 1) / sd + 1;
+  if (dtype == LTU_BF16 && (sh == 2 || sw == 2 || sd == 2) && use_halo() && !getenv("LTU_NO_CLASS_HALO")) {
+    // every parity class of the input grid from one LDS halo brick of the output gradient
+    ClassHaloArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = grad; a.w = wd; a.bias = nullptr; a.o0 = dx0; a.o1 = dx1 ? dx1 : dx0;
+    a.B = B; a.H = Ho; a.W = Wo; a.D = Do; a.C = Co; a.lda = Co;
+    a.N = C0 + C1; a.n0 = C0; a.ldo0 = C0; a.ldo1 = C1 > 0 ? C1 : C0;
+    a.Hh = Hl; a.Wh = Wl; a.Dh = Dl; a.mh = sh; a.mw = sw; a.md = sd;
+    a.wrow = 27 * Co;
+    // per axis and parity: list of (coarse offset, tap).  stride 2: i = 2c -> tap 1 at o = c; i = 2c+1 -> tap 0 at c+1, tap 2 at c.
+    // stride 1: o = i + 1 - t.
+    const int st3[3] = {sh, sw, sd};
+    int cnt[3][2], off[3][2][3], tap[3][2][3];
+    for (int ax = 0; ax < 3; ++ax) {
+      if (st3[ax] == 2) {
+        cnt[ax][0] = 1; off[ax][0][0] = 0; tap[ax][0][0] = 1;
+        cnt[ax][1] = 2; off[ax][1][0] = 1; tap[ax][1][0] = 0; off[ax][1][1] = 0; tap[ax][1][1] = 2;
+      } else {
+        cnt[ax][0] = 3; cnt[ax][1] = 0;
+        for (int t = 0; t < 3; ++t) { off[ax][0][t] = 1 - t; tap[ax][0][t] = t; }
+      }
+    }
+    int ne = 0, nc = 0;
+    for (int ph = 0; ph < sh; ++ph)
+      for (int pw = 0; pw < sw; ++pw)
+        for (int pd = 0; pd < sd; ++pd) {
+          a.cls_p[nc][0] = (int8_t)ph; a.cls_p[nc][1] = (int8_t)pw; a.cls_p[nc][2] = (int8_t)pd;
+          for (int i = 0; i < cnt[0][ph]; ++i)
+            for (int j = 0; j < cnt[1][pw]; ++j)
+              for (int k = 0; k < cnt[2][pd]; ++k) {
+                const int wt = (tap[0][ph][i] * 3 + tap[1][pw][j]) * 3 + tap[2][pd][k];
+                a.ent[ne++] = ClsEntry{(int8_t)off[0][ph][i], (int8_t)off[1][pw][j], (int8_t)off[2][pd][k], (int8_t)nc, wt * Co};
+              }
+          ++nc;
+        }
+    a.nent = ne; a.ncls = nc;
+    const int hr = launch_conv_class_halo_bf16(a, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
   const int str[3] = {sh, sw, sd};
   const int len[3] = {Hl, Wl, Dl};
   const int nclass[3] = {sh, sw, sd};

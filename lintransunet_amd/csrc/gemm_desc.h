@@ -131,3 +131,27 @@ bool tn_ring_shape_ok(long long M, int N, int K);
 long long tn_ring_ws_floats(long long M, int N, int K);
 int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st);
 int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled
+
+// class convolutions on an LDS halo brick (conv_halo.hip): fine voxel o = m q + p gets sum_e [cls_e == class(p)] x[q + d_e] . W_e^T
+struct ClsEntry {
+  int8_t dh, dw, dd, cls;
+  int wbase;            // element offset of the entry's weight tile: W_e[n][k] = w[wbase + n * wrow + k]
+};
+struct ClassHaloArgs {
+  const void* x;        // coarse source [B][H][W][D][lda]
+  const void* w;
+  const float* bias;
+  void* o0;
+  void* o1;             // fine outputs: columns [0,n0) -> o0, the rest -> o1
+  int B, H, W, D;
+  int C, lda;
+  int N, n0, ldo0, ldo1;
+  int Hh, Wh, Dh;       // fine grid
+  int mh, mw, md;       // 1 or 2 per axis
+  int wrow;
+  int nent, ncls;
+  int cls_begin[9];     // filled by the launcher of the ring kernel: entries of class c are [cls_begin[c], cls_begin[c+1])
+  int8_t cls_p[8][4];   // parity (ph, pw, pd) of each class
+  ClsEntry ent[64];
+};
+int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled

@@ -6,6 +6,8 @@
 // 64-tap launch, no pooling pass) and weight gradient (8 launches + a fold of the 8x8 effective taps onto the 27 real ones).
 // Zero padding commutes: a tap outside the upsampled volume is exactly a source voxel outside the low-res volume.
 // Everything runs on the tap-table implicit GEMM kernels of gemm.hip / gemm_bf16.hip.
+#include <stdlib.h>
+
 #include "gemm_desc.h"
 
 int launch_nt_f32(const IGemmArgs& g, hipStream_t st);
@@ -23,6 +25,24 @@ extern "C" int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bi
                               int Co, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
   const size_t esz = dtype == LTU_BF16 ? 2 : 4;
+  if (dtype == LTU_BF16 && !getenv("LTU_NO_CLASS_HALO")) {      // all 8 classes from one LDS halo brick
+    ClassHaloArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = wsub_f; a.bias = bias; a.o0 = y; a.o1 = y;
+    a.B = B; a.H = H; a.W = W; a.D = D; a.C = Ci; a.lda = Ci;
+    a.N = Co; a.n0 = Co; a.ldo0 = Co; a.ldo1 = Co;
+    a.Hh = 2 * H; a.Wh = 2 * W; a.Dh = 2 * D; a.mh = a.mw = a.md = 2;
+    a.wrow = 8 * Ci; a.ncls = 8; a.nent = 64;
+    for (int cls = 0; cls < 8; ++cls) {
+      const int p[3] = {cls >> 2, (cls >> 1) & 1, cls & 1};
+      a.cls_p[cls][0] = (int8_t)p[0]; a.cls_p[cls][1] = (int8_t)p[1]; a.cls_p[cls][2] = (int8_t)p[2];
+      for (int sl = 0; sl < 8; ++sl)
+        a.ent[cls * 8 + sl] = ClsEntry{(int8_t)sub_off(p[0], sl >> 2), (int8_t)sub_off(p[1], (sl >> 1) & 1), (int8_t)sub_off(p[2], sl & 1),
+                                       (int8_t)cls, (cls * Co * 8 + sl) * Ci};
+    }
+    const int hr = launch_conv_class_halo_bf16(a, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
   for (int cls = 0; cls < 8; ++cls) {
     const int p[3] = {cls >> 2, (cls >> 1) & 1, cls & 1};
     IGemmArgs g;

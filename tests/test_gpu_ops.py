@@ -113,6 +113,8 @@ def test_linear_bf16(ops, M, K, N, nw):
     (2, 32, 32, 9, 7, 12, (1, 1, 1), 32, False, None),   # halo kernels: two channel chunks, ragged bricks
     (1, 16, 64, 8, 8, 16, (1, 1, 1), 16, False, None),   # halo kernels: chunk spanning both concat sources, two column tiles
     (3, 16, 16, 4, 12, 8, (1, 1, 1), 0, False, None),
+    (2, 16, 64, 9, 7, 10, (2, 2, 2), 0, False, None),    # class-halo data gradient: 8 parity classes, odd input dims
+    (1, 40, 32, 8, 5, 17, (2, 2, 1), 0, False, None),    # 4 classes
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
@@ -201,7 +203,7 @@ def test_conv3d(ops, case):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
-@pytest.mark.parametrize('B,Ci,Co,H,W,D', [(2, 16, 8, 3, 4, 2), (1, 32, 16, 5, 3, 4), (1, 128, 32, 4, 3, 5)])
+@pytest.mark.parametrize('B,Ci,Co,H,W,D', [(2, 16, 8, 3, 4, 2), (1, 32, 16, 5, 3, 4), (1, 128, 32, 4, 3, 5), (2, 64, 72, 5, 6, 9)])
 def test_upconv_subpixel(ops, dtype, tol, B, Ci, Co, H, W, D):
     """nearest x2 + conv3x3x3 computed as 8 parity-class 2x2x2 convs with pre-summed weights == the plain formulation"""
     g = G(13)
