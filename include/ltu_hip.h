@@ -70,6 +70,10 @@ long long ltu_wgrad_ws_floats(long long M, int N, int K);
 int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw, int M, int N,
                      int K, float* ws, int dtype, ltu_stream_t s);
 
+/* Workspace (floats) that ltu_upconv_wgrad needs for M = B*H*W*D coarse voxels (bf16 path; sub-pixel un-embedding of
+ * model/Unet_3Dblock.py:419-432). */
+long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci);
+
 /* ---- 3x3x3 convolution, padding 1: model/Unet_3Dblock.py:310,314,375,421,523,528,588,1328,1353 --
  * x0 [B,Hi,Wi,Di,C0] (+ optional x1 [..,C1]: the channel concat of Unet_3Dblock.py:553 without
  * materialising it), wf [Co][27][C0+C1], stride (sh,sw,sd) in {1,2}; ups != 0: the conv reads the

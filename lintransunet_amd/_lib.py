@@ -22,6 +22,7 @@ SIGNATURES = {
     'ltu_cast_f32': [P, P, L, I, P],
     'ltu_linear_fwd': [P, I, P, I, P, P, I, I, I, I, I, I, P],
     'ltu_wgrad_ws_floats': [L, I, I],
+    'ltu_upconv_wgrad_ws_floats': [L, I, I],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, I, P],
     'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
@@ -77,7 +78,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
-        fn.restype = c_longlong if name == 'ltu_wgrad_ws_floats' else c_int
+        fn.restype = c_longlong if name.endswith('_ws_floats') else c_int
     _lib = lib
     return lib
 

@@ -809,3 +809,196 @@ int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st) {
   }
   return ltu_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the sub-pixel un-embedding (nearest x2 + 3x3x3 conv):  dWeff[class][slot] = sum_q G_class(q)^T X(q + off),
+// folded onto the 27 real taps.  A workgroup owns (32-channel chunk of Ci, 32-column tile of Co, a range of coarse 4x4x8
+// bricks); per brick it stages the X halo once and the 8 class tiles of the fine-grid gradient.  Each of the 4 waves
+// keeps ALL 64 (class, slot) products for a 16 x 16 sub-tile (v_mfma_f32_16x16x32_bf16, 4 accumulator registers each),
+// so the fold 64 -> 27 is a register add at the end and the partial sums leave in the [split][Co][27 Ci] layout that
+// wgrad_reduce_kernel already folds into the PyTorch gradient.  An X fragment is read once per distinct offset (27), a
+// gradient fragment once per class (8); next brick's tiles are prefetched into registers during the 256 MFMAs.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__global__ void __launch_bounds__(256) upconv_wgrad_class_bf16_kernel(const UpWgradArgs a) {
+  constexpr int LDX = 40, LDG = 40;
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[HALO_VOX * LDX];         // 28.8 KB
+  __shared__ __attribute__((aligned(16))) uint16_t Gs[8 * 128 * LDG];          // 80 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1;                 // 16-column sub-tile of Co / of the Ci chunk
+  const int chunk = blockIdx.x, n_blk = blockIdx.y * 32;
+  const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
+  const int brick_lo = blockIdx.z * a.bricks_per_split;
+  int brick_hi = brick_lo + a.bricks_per_split;
+  if (brick_hi > a.bricks) brick_hi = a.bricks;
+
+  f32x4_t acc[64];
+#pragma unroll
+  for (int e = 0; e < 64; ++e) acc[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  uint4 xreg[6], greg[16];
+  auto load_brick = [&](int brick) {
+    int t = brick;
+    const int bd = t % nbd; t /= nbd;
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh;
+    const int b = t / nbh;
+    const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int idx = tid + p * 256;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (idx < HALO_VOX * 4) {
+        const int hv = idx >> 2, part = idx & 3;
+        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+        const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
+          v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.x) +
+                                              ((((long long)b * a.H + h) * a.W + w) * a.D + d) * a.Ci + chunk * 32 + part * 8);
+      }
+      xreg[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int idx = tid + p * 256;                       // [class][row][4 parts]
+      const int part = idx & 3, row = (idx >> 2) & 127, cls = idx >> 9;
+      const int qh = h0 + (row >> 5), qw = w0 + ((row >> 3) & 3), qd = d0 + (row & 7);
+      const int n = n_blk + part * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (qh < a.H && qw < a.W && qd < a.D && n < a.Co) {
+        const int h = 2 * qh + (cls >> 2), w = 2 * qw + ((cls >> 1) & 1), d = 2 * qd + (cls & 1);
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.grad) +
+                                            ((((long long)b * 2 * a.H + h) * 2 * a.W + w) * 2 * a.D + d) * a.Co + n);
+      }
+      greg[p] = v;
+    }
+  };
+  auto store_brick = [&]() {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int idx = tid + p * 256;
+      if (idx < HALO_VOX * 4) *reinterpret_cast<uint4*>(&Xs[(idx >> 2) * LDX + (idx & 3) * 8]) = xreg[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int idx = tid + p * 256;
+      *reinterpret_cast<uint4*>(&Gs[(idx >> 2) * LDG + (idx & 3) * 8]) = greg[p];
+    }
+  };
+
+  // transposing-read geometry for 16x16x32: 16-lane group gq supplies k rows 8 gq .. 8 gq + 7 of the 32-row slab;
+  // lane 4q + p of the group addresses row q (and q + 4), columns 4p..4p+3
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int growoff = (8 * gq + tq) * LDG + wn * 16 + 4 * tp;
+  // slab ks covers brick rows 32 ks.. = h-plane ks; row r of it -> (w = r >> 3, d = r & 7); this lane: r = 8 gq + tq (+4)
+  const int xrowoff = ((gq + 1) * HALO_D + tq + 1) * LDX + wc * 16 + 4 * tp;     // +1: offset (0,0,0) sits at halo (1,1,1)
+  const bool do_bias = chunk == 0 && wc == 0;
+
+  if (brick_lo < brick_hi) load_brick(brick_lo);
+  for (int brick = brick_lo; brick < brick_hi; ++brick) {
+    __syncthreads();
+    store_brick();
+    __syncthreads();
+    if (brick + 1 < brick_hi) load_brick(brick + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 ga[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        union { struct { hs16x4 l, h; } s; bf16x8 v; } u;
+        const uint16_t* pg = &Gs[(c * 128 + ks * 32) * LDG + growoff];
+        u.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)pg);
+        u.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(pg + 4 * LDG));
+        ga[c] = u.v;
+        if (do_bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum += (float)u.v[e];
+        }
+      }
+#pragma unroll
+      for (int oh = -1; oh <= 1; ++oh)
+#pragma unroll
+        for (int ow = -1; ow <= 1; ++ow)
+#pragma unroll
+          for (int od = -1; od <= 1; ++od) {
+            union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
+            const uint16_t* px = &Xs[(((ks + 1 + oh) * HALO_W + ow) * HALO_D + od) * LDX + xrowoff];
+            ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
+            ub.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(px + 4 * LDX));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int ph = c >> 2, pw = (c >> 1) & 1, pd = c & 1;
+              const int sh = oh + 1 - ph, sw = ow + 1 - pw, sd = od + 1 - pd;      // the slot of class c that reads this offset
+              if (sh >= 0 && sh <= 1 && sw >= 0 && sw <= 1 && sd >= 0 && sd <= 1) {
+                const int e = c * 8 + (sh * 2 + sw) * 2 + sd;
+                acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[c], ub.v, acc[e], 0, 0, 0);
+              }
+            }
+          }
+    }
+  }
+
+  // fold the 64 (class, slot) products onto the 27 taps and store this split's partial sums
+  float* pz = a.part + (long long)blockIdx.z * a.Co * a.kpad;
+  const int ci = chunk * 32 + wc * 16 + (lane & 15);
+#pragma unroll
+  for (int th = 0; th < 3; ++th)
+#pragma unroll
+    for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+      for (int td = 0; td < 3; ++td) {
+        f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int ph = c >> 2, pw = (c >> 1) & 1, pd = c & 1;
+          const int sh = ph == 0 ? (th == 0 ? 0 : 1) : (th == 2 ? 1 : 0);
+          const int sw = pw == 0 ? (tw == 0 ? 0 : 1) : (tw == 2 ? 1 : 0);
+          const int sd = pd == 0 ? (td == 0 ? 0 : 1) : (td == 2 ? 1 : 0);
+          s += acc[c * 8 + (sh * 2 + sw) * 2 + sd];
+        }
+        const int tap = (th * 3 + tw) * 3 + td;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n_blk + wn * 16 + 4 * gq + r;
+          if (n < a.Co) pz[(long long)n * a.kpad + tap * a.Ci + ci] = s[r];
+        }
+      }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    const int n = n_blk + wn * 16 + (lane & 15);
+    if (lane < 16 && n < a.Co) a.bpart[(long long)blockIdx.z * a.Co + n] = bsum;
+  }
+}
+
+static int upw_blocks() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LTU_UPW_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 256; }
+  return v;
+}
+static bool upw_shape_ok(int Ci, int Co, int H, int W, int D) { return Ci % 32 == 0 && Co % 8 == 0 && H >= 2 && W >= 2 && D >= 2; }
+long long upconv_wgrad_class_ws_floats(int Ci, int Co) {
+  if (Ci % 32 || Co % 8) return 0;
+  long long ns = upw_blocks() / ((long long)(Ci / 32) * cdiv(Co, 32));
+  if (ns < 1) ns = 1;
+  return ns * Co * (27LL * Ci + 1);
+}
+// fills the split geometry, launches; returns 1 when the shape is not handled
+int launch_upconv_wgrad_class_bf16(UpWgradArgs a, int* nsplit_out, hipStream_t st) {
+  if (!upw_shape_ok(a.Ci, a.Co, a.H, a.W, a.D)) return 1;
+  const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
+  if (bricks >= (1LL << 31)) return 1;
+  const int nchunk = a.Ci / 32, ntile = cdiv(a.Co, 32);
+  long long ns = upw_blocks() / ((long long)nchunk * ntile);
+  if (ns < 1) ns = 1;
+  if (ns > bricks) ns = bricks;
+  a.bricks = (int)bricks;
+  a.bricks_per_split = (int)((bricks + ns - 1) / ns);
+  const int nsplit = (int)((bricks + a.bricks_per_split - 1) / a.bricks_per_split);
+  a.kpad = 27 * a.Ci;
+  a.bpart = a.part + (long long)nsplit * a.Co * a.kpad;
+  *nsplit_out = nsplit;
+  hipLaunchKernelGGL(upconv_wgrad_class_bf16_kernel, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
+  return ltu_check_launch();
+}

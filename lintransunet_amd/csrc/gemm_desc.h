@@ -155,3 +155,16 @@ struct ClassHaloArgs {
   ClsEntry ent[64];
 };
 int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled
+
+// weight gradient of the sub-pixel un-embedding from LDS halo bricks (conv_halo.hip), two-stage through wgrad_reduce_kernel
+struct UpWgradArgs {
+  const void* x;        // coarse [B][H][W][D][Ci]
+  const void* grad;     // fine   [B][2H][2W][2D][Co]
+  int B, H, W, D, Ci, Co;
+  int bricks, bricks_per_split;
+  float* part;          // [nsplit][Co][27 Ci]
+  float* bpart;         // [nsplit][Co]
+  int kpad;
+};
+long long upconv_wgrad_class_ws_floats(int Ci, int Co);
+int launch_upconv_wgrad_class_bf16(UpWgradArgs a, int* nsplit_out, hipStream_t st);   // LTU_OK / hipError, or 1 = not handled

@@ -10,6 +10,7 @@
 
 #include "gemm_desc.h"
 
+extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K);
 int launch_nt_f32(const IGemmArgs& g, hipStream_t st);
 int launch_tn_f32(WGradArgs& wa, hipStream_t st);
 
@@ -125,6 +126,26 @@ __global__ void upconv_fold_kernel(const float* __restrict__ dweff, float* __res
 extern "C" int ltu_upconv_wgrad(const void* grad, const void* x, float* dweff, float* db, float* dw_torch, int co_real,
                                 int ci_real, float* ws, int B, int H, int W, int D, int Ci, int Co, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && ws != nullptr && !getenv("LTU_NO_CLASS_HALO")) {
+    // all classes and taps from LDS halo bricks, folded in registers; the reduce kernel writes the PyTorch layout
+    UpWgradArgs u;
+    memset(&u, 0, sizeof(u));
+    u.x = x; u.grad = grad; u.B = B; u.H = H; u.W = W; u.D = D; u.Ci = Ci; u.Co = Co; u.part = ws;
+    int nsplit = 0;
+    const int hr = launch_upconv_wgrad_class_bf16(u, &nsplit, (hipStream_t)s);
+    if (hr == LTU_OK) {
+      WGradArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      IGemmArgs& g = wa.g;
+      g.N = Co; g.C = Ci; g.c0 = Ci; g.K = 27 * Ci; g.wrow = 27 * Ci; g.ntaps = 27;
+      for (int t = 0; t < 27; ++t) g.tap[t] = Tap{0, 0, 0, (int8_t)t};
+      wa.dw = dw_torch; wa.db = db; wa.t_co = co_real; wa.t_ci = ci_real; wa.nseg_w = 1;
+      wa.part = ws; wa.npad = Co; wa.kpad = 27 * Ci;
+      wa.bpart = ws + (long long)nsplit * Co * wa.kpad;
+      return launch_wgrad_reduce(wa, nsplit, (hipStream_t)s);
+    }
+    if (hr != 1) return hr;
+  }
   for (int cls = 0; cls < 8; ++cls) {
     const int p[3] = {cls >> 2, (cls >> 1) & 1, cls & 1};
     WGradArgs wa;
@@ -162,4 +183,10 @@ extern "C" int ltu_upconv_wgrad(const void* grad, const void* x, float* dweff, f
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(upconv_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, dweff, dw_torch, co_real, ci_real, Co, Ci);
   return ltu_check_launch();
+}
+
+// workspace (floats) ltu_upconv_wgrad needs for M coarse voxels
+extern "C" long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci) {
+  const long long a = ltu_wgrad_ws_floats(M, Co, 8 * Ci), b = upconv_wgrad_class_ws_floats(Ci, Co);
+  return a > b ? a : b;
 }

@@ -351,7 +351,9 @@ class _UpConv3d(torch.autograd.Function):
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
         dweff = scratch_zeros((8, Co, 8, Ci), x.device)
-        ws = _wgrad_ws(B * H * W * D, Co, 8 * Ci, x)
+        ws = None
+        if x.dtype == torch.bfloat16:
+            ws = torch.empty(_lib.load().ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci), device=x.device, dtype=torch.float32)
         _lib.call('ltu_upconv_wgrad', _p(g), _p(x), _p(dweff), _p(db), _p(dw), Co, Ci, _p(ws), B, H, W, D, Ci, Co, dt, _s())
         return dx, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None
 
