@@ -183,7 +183,7 @@ def main():
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights', 'global_batch': args.batch * world,
                        'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': 'eager' if args.no_graph else 'hip-graph replay'},
-            'roofline': {'bound': 'hbm', 'kernel': 'igemm_nt_bf16_kernel<2,2,2,2,32,2> (transformer projections, forward launches)',
+            'roofline': {'bound': 'hbm', 'kernel': 'linear_ring_bf16_kernel (transformer projections, forward launches)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),
                          'algorithmic_bytes_per_launch': timer.flops / max(n_lin, 1), 'traffic': traffic},

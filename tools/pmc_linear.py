@@ -44,7 +44,7 @@ def parse(fetch_dir, write_dir):
         tot, n = 0.0, 0
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
-                if r['Counter_Name'] == name and 'igemm_nt_bf16' in r['Kernel_Name']:
+                if r['Counter_Name'] == name and ('linear_ring_bf16' in r['Kernel_Name'] or 'igemm_nt_bf16' in r['Kernel_Name']):
                     tot += float(r['Counter_Value'])
                     n += 1
         return tot, n
@@ -54,7 +54,7 @@ def parse(fetch_dir, write_dir):
     algo = sum((M * K + M * N + N * K) * 2 for M, K, N, _ in L)
     # MI355X_MICROARCH.md (HBM): counters are in KiB; FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950
     hbm = (2.0 * fetch + write) * 1024.0
-    print(json.dumps({'kernel': 'igemm_nt_bf16_kernel (forward transformer projections of one bench step)',
+    print(json.dumps({'kernel': 'linear_ring_bf16_kernel (forward transformer projections of one bench step)',
                       'launches': len(L), 'dispatches_seen': [nf, nw], 'FETCH_SIZE_KiB': fetch, 'WRITE_SIZE_KiB': write,
                       'correction': 'hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE counts half of 16 B/lane reads)',
                       'hbm_bytes_total': hbm, 'hbm_bytes_per_launch': hbm / len(L),
