@@ -187,6 +187,130 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
   }
 }
 
+// Few-channel variant (C <= 32, N <= 32: the two finest U-Net levels, 0.25-1 M voxels).  There the work per brick is 27-54
+// MFMAs per wave and the kernel above is bound by workgroup turnover (8192 short-lived workgroups, each exposing one halo
+// round trip and re-streaming the same 27 weight tiles).  Here the whole weight tensor [27][32][CC] stays in LDS, a workgroup
+// is persistent over bricks and the next brick's halo is in flight (registers) during the current MFMAs and epilogue.
+// Unpadded LDS rows (2 workgroups per CU): 64-byte rows are bank-spread by slot = chunk ^ ((row >> 2) & 1), 32-byte rows
+// need nothing.
+template <int CC>
+__global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs a, int bricks) {
+  constexpr int VPV = CC / 8, KS = CC / 16, LDC = 40;
+  constexpr int NH = (HALO_VOX * VPV + 255) / 256, NWV = (27 * 32 * VPV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * CC];     // also the 128 x LDC output staging
+  __shared__ __attribute__((aligned(16))) uint16_t Wl[27 * 32 * CC];
+  static_assert(HALO_VOX * CC >= 128 * LDC, "staging fits");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
+
+  // weights once: row (tap, n) <- w[n][tap (mirrored for the data gradient)][0..C)
+#pragma unroll
+  for (int p = 0; p < NWV; ++p) {
+    const int idx = tid + p * 256;
+    if (idx >= 27 * 32 * VPV) break;
+    const int part = idx % VPV, row = idx / VPV;
+    const int n = row & 31, tap = row >> 5;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (n < a.N && part * 8 < a.C)
+      v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + ((long long)n * 27 + tap) * a.C + part * 8);
+    const int slot = CC == 32 ? (part ^ ((row >> 2) & 1)) : part;
+    *reinterpret_cast<uint4*>(&Wl[row * CC + slot * 8]) = v;
+  }
+
+  uint4 hreg[NH];
+  auto load_halo = [&](int brick) {
+    int t = brick;
+    const int bd = t % nbd; t /= nbd;
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh;
+    const int b = t / nbh;
+#pragma unroll
+    for (int p = 0; p < NH; ++p) {
+      const int idx = tid + p * 256;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (idx < HALO_VOX * VPV) {
+        const int hv = idx / VPV, part = idx - hv * VPV;
+        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+        const int h = bh * 4 - 1 + hh, w = bw * 4 - 1 + hw, d = bd * 8 - 1 + hd;
+        const int c = part * 8;
+        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C) {
+          const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
+          const uint16_t* src = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + c
+                                         : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (c - a.c0);
+          v = *reinterpret_cast<const uint4*>(src);
+        }
+      }
+      hreg[p] = v;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int p = 0; p < NH; ++p) {
+      const int idx = tid + p * 256;
+      if (idx < HALO_VOX * VPV) {
+        const int hv = idx / VPV, part = idx - hv * VPV;
+        const int slot = CC == 32 ? (part ^ ((hv >> 2) & 1)) : part;
+        *reinterpret_cast<uint4*>(&halo[hv * CC + slot * 8]) = hreg[p];
+      }
+    }
+  };
+
+  const int hv0 = (wave * HALO_W + (li >> 3)) * HALO_D + (li & 7);      // halo voxel of this lane's row at tap (0,0,0)
+  const int wsw = (li >> 2) & 1;
+  const float bvv = (a.bias != nullptr && li < a.N) ? a.bias[li] : 0.f;
+  uint16_t* Cs = halo;
+
+  int brick = blockIdx.x;
+  if (brick < bricks) load_halo(brick);
+  for (; brick < bricks; brick += gridDim.x) {
+    __syncthreads();                       // staging reads of the previous brick are done (and the weights are in place)
+    store_halo();
+    __syncthreads();
+    if (brick + (int)gridDim.x < bricks) load_halo(brick + gridDim.x);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      int th = tap / 9, tw = (tap / 3) % 3, td = tap % 3;
+      const int ts = a.flip ? 26 - tap : tap;        // data gradient: tap t reads the mirrored halo offset
+      th = ts / 9; tw = (ts / 3) % 3; td = ts % 3;
+      const int hv = hv0 + (th * HALO_W + tw) * HALO_D + td;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ca = CC == 32 ? (((ks * 2 + lh) ^ ((hv >> 2) & 1)) << 3) : (lh << 3);
+        const int cb = CC == 32 ? (((ks * 2 + lh) ^ wsw) << 3) : (lh << 3);
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(&halo[hv * CC + ca]);
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&Wl[(tap * 32 + li) * CC + cb]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();                       // every wave is done with the halo: it becomes the output staging
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      Cs[ml * LDC + li] = f32_to_bf16(acc[r] + bvv);
+    }
+    __syncthreads();
+    int t = brick;
+    const int bd = t % nbd; t /= nbd;
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh;
+    const int b = t / nbh;
+    for (int idx = tid; idx < 128 * 8; idx += 256) {
+      const int ml = idx >> 3, nl = (idx & 7) * 4;
+      const int h = bh * 4 + (ml >> 5), w = bw * 4 + ((ml >> 3) & 3), d = bd * 8 + (ml & 7);
+      if (nl >= a.N || h >= a.H || w >= a.W || d >= a.D) continue;
+      const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
+      const uint2 v = *reinterpret_cast<const uint2*>(&Cs[ml * LDC + nl]);
+      uint16_t* dst = nl < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + vox * a.ldo0 + nl
+                                : reinterpret_cast<uint16_t*>(a.o1) + vox * a.ldo1 + (nl - a.n0);
+      *reinterpret_cast<uint2*>(dst) = v;
+    }
+  }
+}
+
 // returns LTU_OK after launching, or 1 when the shape is not handled here (the caller falls back to the implicit GEMM)
 int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   if (a.C % 8 || a.c0 % 8 || a.lda0 % 8 || a.lda1 % 8 || a.N % 4 || a.n0 % 4 || a.ldo0 % 4 || a.ldo1 % 4) return 1;
@@ -196,6 +320,12 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   if (a.c0 % a.CC != 0 && a.c0 != a.C) return 1;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
+  if (a.N <= 32 && a.C <= 32 && !getenv("LTU_NO_HALO_WS")) {      // few channels: weights stationary, persistent over bricks
+    const unsigned nblk = (unsigned)(bricks < 512 ? bricks : 512);
+    if (a.C > 16) hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<32>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
+    else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
+    return ltu_check_launch();
+  }
   if (a.N > 64) {
     dim3 grid((unsigned)bricks, cdiv(a.N, 128));
     hipLaunchKernelGGL((conv3_halo_bf16_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, a);
