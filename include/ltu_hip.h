@@ -121,11 +121,14 @@ int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const f
 /* ---- InstanceNorm3d (+LeakyReLU, residual, dropout): model/Unet_3Dblock.py:312-339,526-556,593 ----
  * x [B][S][C].  sums [B][C][3] = {shift, sum(x-shift), sum((x-shift)^2)} (zero-filled by the caller).
  * apply: y = dropout(act((x-mean)*rstd)) + res (res may be NULL). */
-int ltu_instnorm_stats(const void* x, float* sums, int B, long long S, int C, int dtype, ltu_stream_t s);
+/* `ws` (nullable) is a scratch buffer of at least ltu_norm_ws_floats() floats: with it the per-block partial sums are folded by a
+ * second small kernel instead of fp32 atomics (same results up to summation order).  One buffer can serve every call on a stream. */
+long long ltu_norm_ws_floats(void);
+int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s);
 int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C, int act,
                        float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dx from dy; bsums [B][C][2] zero-filled scratch */
-int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, void* dx, int B, long long S, int C,
+int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, float* ws, void* dx, int B, long long S, int C,
                      int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- residual LayerNorm: model/trans_block.py:205-206,209-210 -----------------------------------
@@ -135,7 +138,8 @@ int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* b
                       int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dz (gradient of x) and dr = dz*dropmask (dr may alias dz when p = 0); dgamma/dbeta += (zero-filled) */
 int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                      float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+                      float* dgamma, float* dbeta, float* ws, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype,
+                      ltu_stream_t s);
 
 /* ---- GELU(erf) + dropout: model/trans_block.py:208 ---------------------------------------------- */
 int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);

@@ -35,11 +35,12 @@ SIGNATURES = {
     'ltu_linattn_splits': [I, I],
     'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],
     'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
-    'ltu_instnorm_stats': [P, P, I, L, I, I, P],
+    'ltu_norm_ws_floats': [],
+    'ltu_instnorm_stats': [P, P, P, I, L, I, I, P],
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
-    'ltu_instnorm_bwd': [P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_instnorm_bwd': [P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
-    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
+    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
     'ltu_gelu_dropout_fwd': [P, P, L, F, U, P, I, P],
     'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, P, I, P],
     'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],

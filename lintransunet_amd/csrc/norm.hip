@@ -9,6 +9,8 @@
 //   bwd     : g = dy*dropmask*act'(xhat);  s1 = sum g, s2 = sum g*xhat;  dx = rstd*(g - s1/S - xhat*s2/S)
 // LayerNorm (model/trans_block.py:205-206, 209-210, eps 1e-6): y = LN(x + drop(r)) * gamma + beta; the
 // pre-norm sum z = x + drop(r) overwrites r (it is what the backward pass needs).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define IN_EPS 1e-5f
@@ -26,10 +28,47 @@ __device__ __forceinline__ InStat in_stat(const float* sums, float invS) {
   return s;
 }
 
+// ---- two-stage reductions ---------------------------------------------------------------------
+// Per-block partial sums used to be added with fp32 atomics: a few hundred blocks adding to the same few addresses form a
+// serial chain at the memory side (~25 ns per link: 25 us for 1024 blocks).  With a workspace the blocks store their partials
+// ([group][part][n]) and this kernel folds them.  mode 0: out[g*n + i];  mode 1 (InstanceNorm sums [B][C][3]):
+// out[(g*n/2 + i/2)*3 + 1 + (i&1)];  mode 2 (LayerNorm): i even -> out[i/2], odd -> out2[i/2].
+#define LTU_NORM_WS_FLOATS (1 << 20)
+__global__ void __launch_bounds__(1024) reduce_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out,
+                                                            float* __restrict__ out2, int mode) {
+  __shared__ float red[32][33];
+  const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + el, g = blockIdx.y;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < n) {
+    const float* p = part + (long long)g * nparts * n + i;
+    int z = zq;
+    for (; z + 96 < nparts; z += 128) {
+      a0 += p[(long long)z * n]; a1 += p[(long long)(z + 32) * n]; a2 += p[(long long)(z + 64) * n]; a3 += p[(long long)(z + 96) * n];
+    }
+    for (; z < nparts; z += 32) a0 += p[(long long)z * n];
+  }
+  red[zq][el] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (zq != 0 || i >= n) return;
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) v += red[q][el];
+  if (mode == 0) out[(long long)g * n + i] += v;
+  else if (mode == 1) out[((long long)g * (n >> 1) + (i >> 1)) * 3 + 1 + (i & 1)] += v;
+  else if (i & 1) out2[i >> 1] += v;
+  else out[i >> 1] += v;
+}
+static void launch_reduce_parts(const float* part, int nparts, int n, int groups, float* out, float* out2, int mode, hipStream_t st) {
+  if (getenv("LTU_DBG_NO_STAGE2")) return;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 32), groups), dim3(1024), 0, st, part, nparts, n, out, out2, mode);
+}
+extern "C" long long ltu_norm_ws_floats(void) { return LTU_NORM_WS_FLOATS; }
+
 // grid (nchunks, B), block 256.  x [B][S][C]; sums [B][C][3] must be zero on entry.
 template <typename T>
-__global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, long long S, int C,
-                                      int rows_per_block) {
+__global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, float* __restrict__ ws, long long S,
+                                      int C, int rows_per_block) {
   extern __shared__ float red[];   // [rowgroups][C][2]
   const int b = blockIdx.y;
   const int cv = C / 4;                       // vectors per row
@@ -58,7 +97,8 @@ __global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict
     for (int g = 0; g < nrg; ++g) acc += red[(long long)g * C * 2 + i];
     const int c = i >> 1, which = i & 1;
     float* s = sums + ((long long)b * C + c) * 3;
-    atomicAdd(s + 1 + which, acc);
+    if (ws != nullptr) ws[((long long)b * gridDim.x + blockIdx.x) * C * 2 + i] = acc;
+    else atomicAdd(s + 1 + which, acc);
     if (blockIdx.x == 0 && which == 0) s[0] = ld1<T>(xb + c);
   }
 }
@@ -96,8 +136,8 @@ __global__ void instnorm_apply_kernel(const T* __restrict__ x, const float* __re
 // backward reductions: bsums[b][c][2] += { sum g, sum g*xhat },  g = dy*mask*act'(xhat)
 template <typename T>
 __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
-                                          float* __restrict__ bsums, long long S, int C, int rows_per_block, int act,
-                                          float slope, float p, uint64_t seed, const uint64_t* step) {
+                                          float* __restrict__ bsums, float* __restrict__ ws, long long S, int C,
+                                          int rows_per_block, int act, float slope, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];
   const int b = blockIdx.y;
   const int cv = C / 4;
@@ -134,7 +174,8 @@ __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __r
   for (int i = tid; i < C * 2; i += blockDim.x) {
     float acc = 0.f;
     for (int g = 0; g < nrg; ++g) acc += red[(long long)g * C * 2 + i];
-    atomicAdd(bsums + (long long)b * C * 2 + i, acc);
+    if (ws != nullptr) ws[((long long)b * gridDim.x + blockIdx.x) * C * 2 + i] = acc;
+    else atomicAdd(bsums + (long long)b * C * 2 + i, acc);
   }
 }
 
@@ -209,8 +250,8 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
 template <typename T, int G>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ stat,
                                      const float* __restrict__ gamma, T* __restrict__ dz, T* __restrict__ dr,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int rows_per_block,
-                                     float p, uint64_t seed, const uint64_t* step) {
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, long long M,
+                                     int rows_per_block, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];   // [rowgroups][d][2]
   const int d = G * 4;
   const int gl = threadIdx.x % G, rg = threadIdx.x / G, nrg = blockDim.x / G;
@@ -220,17 +261,33 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
+  // software pipeline: the next row's operands are in flight while this row goes through its two cross-lane reductions
+  float4 gn = make_float4(0.f, 0.f, 0.f, 0.f), zn = gn;
+  float2 stn = make_float2(0.f, 0.f);
+  {
+    const long long row = r0 + rg;
+    if (row < r1) {
+      gn = Vec4<T>::load(dy + row * d + gl * 4);
+      zn = Vec4<T>::load(z + row * d + gl * 4);
+      stn = *reinterpret_cast<const float2*>(stat + row * 2);
+    }
+  }
   for (long long rb = r0; rb < r1; rb += nrg) {
     const long long row = rb + rg;
     const bool ok = row < r1;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), h = g;
-    float rstd = 0.f;
+    const float4 g = gn, zv = zn;
+    const float mean = stn.x, rstd = ok ? stn.y : 0.f;
+    {
+      const long long nrow = row + nrg;
+      gn = make_float4(0.f, 0.f, 0.f, 0.f); zn = gn;
+      if (nrow < r1) {
+        gn = Vec4<T>::load(dy + nrow * d + gl * 4);
+        zn = Vec4<T>::load(z + nrow * d + gl * 4);
+        stn = *reinterpret_cast<const float2*>(stat + nrow * 2);
+      }
+    }
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
-      const long long e = row * d + gl * 4;
-      g = Vec4<T>::load(dy + e);
-      const float4 zv = Vec4<T>::load(z + e);
-      const float mean = stat[row * 2];
-      rstd = stat[row * 2 + 1];
       h = make_float4((zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd);
       ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
       ag.x += g.x * h.x; ag.y += g.y * h.y; ag.z += g.z * h.z; ag.w += g.w * h.w;
@@ -252,7 +309,8 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
   for (int i = threadIdx.x; i < d * 2; i += blockDim.x) {
     float acc = 0.f;
     for (int g = 0; g < nrg; ++g) acc += red[(long long)g * d * 2 + i];
-    atomicAdd(((i & 1) ? dbeta : dgamma) + (i >> 1), acc);
+    if (ws != nullptr) ws[(long long)blockIdx.x * d * 2 + i] = acc;
+    else atomicAdd(((i & 1) ? dbeta : dgamma) + (i >> 1), acc);
   }
 }
 
@@ -266,7 +324,7 @@ static int stats_rows(long long S, int B, int* nchunks) {
   return (int)rows;
 }
 
-extern "C" int ltu_instnorm_stats(const void* x, float* sums, int B, long long S, int C, int dtype, ltu_stream_t s) {
+extern "C" int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
   int nchunks;
   const int rows = stats_rows(S, B, &nchunks);
@@ -275,7 +333,9 @@ extern "C" int ltu_instnorm_stats(const void* x, float* sums, int B, long long S
   if (nrg < 1) return LTU_E_SHAPE;
   const size_t lds = (size_t)nrg * C * 2 * sizeof(float);
   LTU_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((instnorm_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)x, sums, S, C, rows);
+    if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
+    hipLaunchKernelGGL((instnorm_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)x, sums, ws, S, C, rows);
+    if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, sums, nullptr, 1, (hipStream_t)s);
   });
   return ltu_check_launch();
 }
@@ -298,8 +358,9 @@ extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* 
   return ltu_check_launch();
 }
 
-extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, void* dx, int B, long long S,
-                                int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, float* ws, void* dx, int B,
+                                long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype,
+                                ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
   int nchunks;
   const int rows = stats_rows(S, B, &nchunks);
@@ -309,8 +370,10 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
   const size_t lds = (size_t)nrg * C * 2 * sizeof(float);
   const long long nvec = (long long)B * S * C / 4;
   LTU_DISPATCH_T(dtype, {
+    if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
     hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)dy,
-                       (const T*)x, sums, bsums, S, C, rows, act, slope, p, seed, step);
+                       (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
+    if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, bsums, nullptr, 0, (hipStream_t)s);
     hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
                        (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
   });
@@ -339,8 +402,8 @@ extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, con
 }
 
 extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                                 float* dgamma, float* dbeta, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype,
-                                 ltu_stream_t s) {
+                                 float* dgamma, float* dbeta, float* ws, long long M, int d, float p, uint64_t seed,
+                                 const uint64_t* step, int dtype, ltu_stream_t s) {
   LTU_DISPATCH_T(dtype, {
     LN_DISPATCH_G(d, {
       const int nrg = 256 / G;
@@ -348,8 +411,11 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* sta
       if (rows < nrg) rows = nrg;
       rows = (rows + nrg - 1) / nrg * nrg;
       const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(cdiv(M, rows)), dim3(256), lds, (hipStream_t)s, (const T*)dy,
-                         (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, M, (int)rows, p, seed, step);
+      const int nblk = cdiv(M, rows);
+      if ((long long)nblk * d * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy,
+                         (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, ws, M, (int)rows, p, seed, step);
+      if (ws != nullptr) launch_reduce_parts(ws, nblk, d * 2, 1, dgamma, dbeta, 2, (hipStream_t)s);
     });
   });
   return ltu_check_launch();

@@ -154,6 +154,17 @@ def _w_transposed(ws, rows, cols, dtype):
     return wt
 
 
+_NORM_WS = {}
+
+
+def _norm_ws(device):
+    """per-device scratch for the two-stage norm reductions (written and consumed inside one C call, so one buffer serves all)"""
+    ws = _NORM_WS.get(device)
+    if ws is None:
+        ws = _NORM_WS[device] = torch.empty(_lib.load().ltu_norm_ws_floats(), device=device, dtype=torch.float32)
+    return ws
+
+
 def _wgrad_ws(M, N, K, like):
     """workspace for the two-stage (atomic-free) weight-gradient reduction of the bf16 path; None selects fp32 atomics"""
     if like.dtype != torch.bfloat16:
@@ -426,7 +437,7 @@ class _InstNormAct(torch.autograd.Function):
         S = x.numel() // (B * C)
         sums = scratch_zeros((B, C, 3), x.device)
         dt = _dt(x)
-        _lib.call('ltu_instnorm_stats', _p(x), _p(sums), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(_norm_ws(x.device)), B, S, C, dt, _s())
         y = torch.empty_like(x)
         _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, _step_ptr(), dt, _s())
         ctx.save_for_backward(x, sums)
@@ -442,7 +453,7 @@ class _InstNormAct(torch.autograd.Function):
         S = x.numel() // (B * C)
         bsums = scratch_zeros((B, C, 2), x.device)
         dx = torch.empty_like(x)
-        _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
+        _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(_norm_ws(x.device)), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
                   _step_ptr(), _dt(x), _s())
         return dx, (g if has_res else None), None, None, None
 
@@ -478,7 +489,7 @@ class _ResLayerNorm(torch.autograd.Function):
         dr = torch.empty_like(z) if p > 0 else dz
         dgamma, fg = _grad_buf(gamma)
         dbeta, fb = _grad_buf(beta)
-        _lib.call('ltu_layernorm_bwd', _p(g), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta), M, d,
+        _lib.call('ltu_layernorm_bwd', _p(g), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta), _p(_norm_ws(g.device)), M, d,
                   float(p), seed, _step_ptr(), _dt(z), _s())
         return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None
 
@@ -720,8 +731,8 @@ class _Gate(torch.autograd.Function):
         _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([wgo]), 1, _ptr_array([bg]), _p(u2), C, M, C, Cg, 0, dt, _s())
         s1 = scratch_zeros((B, C, 3), dev)
         s2 = scratch_zeros((B, C, 3), dev)
-        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), B, S, C, dt, _s())
-        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), _p(_norm_ws(dev)), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), _p(_norm_ws(dev)), B, S, C, dt, _s())
         a = torch.empty(M, device=dev, dtype=torch.float32)
         out = torch.empty_like(skip)
         _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, dt, _s())
