@@ -326,11 +326,11 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
     else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     return ltu_check_launch();
   }
-  if (a.N > 64) {
+  if (a.N > 64 && bricks * cdiv(a.N, 128) >= 256) {
     dim3 grid((unsigned)bricks, cdiv(a.N, 128));
     hipLaunchKernelGGL((conv3_halo_bf16_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, a);
-  } else if (a.N > 32) {
-    dim3 grid((unsigned)bricks, 1);
+  } else if (a.N > 32) {                    // also wide outputs on small grids: 64-column tiles double the workgroup count
+    dim3 grid((unsigned)bricks, cdiv(a.N, 64));
     hipLaunchKernelGGL((conv3_halo_bf16_kernel<4, 1, 1, 2, 3>), grid, dim3(256), 0, st, a);
   } else {
     dim3 grid((unsigned)bricks, 1);
