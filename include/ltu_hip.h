@@ -137,7 +137,9 @@ int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bs
 int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat, long long M,
                       int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dz (gradient of x) and dr = dz*dropmask (dr may alias dz when p = 0); dgamma/dbeta += (zero-filled) */
-int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
+/* dy2 (nullable): a second upstream gradient, summed with dy on load (the layer output feeds both the next projection and the next
+ * residual; folding the sum here saves autograd's separate add pass) */
+int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
                       float* dgamma, float* dbeta, float* ws, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype,
                       ltu_stream_t s);
 

@@ -40,7 +40,7 @@ SIGNATURES = {
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_instnorm_bwd': [P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
-    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
+    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
     'ltu_gelu_dropout_fwd': [P, P, L, F, U, P, I, P],
     'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, P, I, P],
     'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],

@@ -248,7 +248,7 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
 // dz = rstd*(g*gamma - mean_d(g*gamma) - xhat*mean_d(g*gamma*xhat));  dr = dz*dropmask;
 // dgamma += sum_rows g*xhat, dbeta += sum_rows g   (block partials through LDS, then fp32 atomics)
 template <typename T, int G>
-__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ stat,
+__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ z, const float* __restrict__ stat,
                                      const float* __restrict__ gamma, T* __restrict__ dz, T* __restrict__ dr,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, long long M,
                                      int rows_per_block, float p, uint64_t seed, const uint64_t* step) {
@@ -268,6 +268,7 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     const long long row = r0 + rg;
     if (row < r1) {
       gn = Vec4<T>::load(dy + row * d + gl * 4);
+      if (dy2 != nullptr) { const float4 t2 = Vec4<T>::load(dy2 + row * d + gl * 4); gn.x += t2.x; gn.y += t2.y; gn.z += t2.z; gn.w += t2.w; }
       zn = Vec4<T>::load(z + row * d + gl * 4);
       stn = *reinterpret_cast<const float2*>(stat + row * 2);
     }
@@ -282,6 +283,7 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
       gn = make_float4(0.f, 0.f, 0.f, 0.f); zn = gn;
       if (nrow < r1) {
         gn = Vec4<T>::load(dy + nrow * d + gl * 4);
+        if (dy2 != nullptr) { const float4 t2 = Vec4<T>::load(dy2 + nrow * d + gl * 4); gn.x += t2.x; gn.y += t2.y; gn.z += t2.z; gn.w += t2.w; }
         zn = Vec4<T>::load(z + nrow * d + gl * 4);
         stn = *reinterpret_cast<const float2*>(stat + nrow * 2);
       }
@@ -401,7 +403,7 @@ extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, con
   return ltu_check_launch();
 }
 
-extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
+extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
                                  float* dgamma, float* dbeta, float* ws, long long M, int d, float p, uint64_t seed,
                                  const uint64_t* step, int dtype, ltu_stream_t s) {
   LTU_DISPATCH_T(dtype, {
@@ -413,7 +415,7 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* z, const float* sta
       const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
       const int nblk = cdiv(M, rows);
       if ((long long)nblk * d * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy,
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy, (const T*)dy2,
                          (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, ws, M, (int)rows, p, seed, step);
       if (ws != nullptr) launch_reduce_parts(ws, nblk, d * 2, 1, dgamma, dbeta, 2, (hipStream_t)s);
     });

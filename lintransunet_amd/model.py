@@ -235,31 +235,36 @@ class MaskTransUnet(nn.Module):
         y = ops.conv3d(x, conv.weight, conv.bias, stride=stride, x1=x1, ups=ups, prep=self._store.conv[id(conv)])
         return ops.instnorm_act(y, res=res, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0)
 
-    def _layer(self, lay, t, B, N, d, p, seeds):
-        """post-norm transformer layer on tokens t [B*N, d] (model/trans_block.py:148-166, 203-211)"""
+    def _layer(self, lay, t, tres, B, N, d, p, seeds, last):
+        """post-norm transformer layer on tokens t [B*N, d] (model/trans_block.py:148-166, 203-211).  `t` feeds the
+        projections, `tres` (same values) the residual: two autograd edges whose gradients the LayerNorm backward sums."""
         lin = lay.self_attn.linears
         wl = self._store.lin
         qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
                          prep=wl[(id(lay), 'qkv')])
         a = ops.linear_attention(qkv, B, N, d)
         a = ops.linear(a, [lin[3].weight], [lin[3].bias], prep=wl[(id(lay), 'o')])
-        t = ops.res_layernorm(t, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0)
+        t, tres = ops.res_layernorm(tres, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0,
+                                    fork=True)
         f = ops.linear(t, [lay.linear1.weight], [lay.linear1.bias], prep=wl[(id(lay), 'f1')])
         f = ops.gelu_dropout(f, p, seeds.next() if p > 0 else 0)
         f = ops.linear(f, [lay.linear2.weight], [lay.linear2.bias], prep=wl[(id(lay), 'f2')])
-        return ops.res_layernorm(t, f, lay.layer_norm2.weight, lay.layer_norm2.bias, 1e-6, p, seeds.next() if p > 0 else 0)
+        out = ops.res_layernorm(tres, f, lay.layer_norm2.weight, lay.layer_norm2.bias, 1e-6, p, seeds.next() if p > 0 else 0,
+                                fork=not last)
+        return out if not last else (out, out)
 
     def _token_transformer(self, layers, pos, x, p, seeds):
         """8 layers over the voxels of x [B,H,W,D,d]; positional conv after layer 0.  Token order does not
         matter to the layers (per-token ops + a set reduction over tokens), so voxels stay in place."""
         B, H, W, D, d = x.shape
         N = H * W * D
-        t = x.reshape(B * N, d)
+        t = tres = x.reshape(B * N, d)
         for n, lay in enumerate(layers):
-            t = self._layer(lay, t, B, N, d, p, seeds)
+            # the positional conv after layer 0 consumes a single tensor; so does whatever follows the last layer
+            t, tres = self._layer(lay, t, tres, B, N, d, p, seeds, last=(n == 0 or n == len(layers) - 1))
             if n == 0:
                 g = ops.pos_conv(t.view(B, H, W, D, d), pos.proj.weight, pos.proj.bias, p, seeds.next() if p > 0 else 0)
-                t = g.view(B * N, d)
+                t = tres = g.view(B * N, d)
         return t.view(B, H, W, D, d)
 
     def _roi_bridge(self, br, skip, mask, roi_size, p, seeds):

@@ -465,7 +465,7 @@ def instnorm_act(x, res=None, act=ACT_LRELU, p=0.0, seed=0):
 
 class _ResLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps, p, seed):
+    def forward(ctx, x, r, gamma, beta, eps, p, seed, fork=False):
         _chk(x, 'x'); _chk(r, 'r')
         M, d = x.shape
         y = torch.empty_like(x)
@@ -476,27 +476,37 @@ class _ResLayerNorm(torch.autograd.Function):
         ctx.save_for_backward(r, stat)
         ctx.params = (gamma, beta)
         ctx.cfg = (p, seed)
+        ctx.fork = fork
+        if fork:
+            # two autograd outputs over one buffer: the consumers' gradients then arrive separately and are summed inside the
+            # backward kernel instead of by a stand-alone add pass
+            return y, y.view_as(y)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g2=None):
         z, stat = ctx.saved_tensors
         gamma, beta = ctx.params
         p, seed = ctx.cfg
+        if g is None:
+            g, g2 = g2, None
         g = g.contiguous()
+        if g2 is not None:
+            g2 = g2.contiguous()
         M, d = z.shape
         dz = torch.empty_like(z)
         dr = torch.empty_like(z) if p > 0 else dz
         dgamma, fg = _grad_buf(gamma)
         dbeta, fb = _grad_buf(beta)
-        _lib.call('ltu_layernorm_bwd', _p(g), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta), _p(_norm_ws(g.device)), M, d,
-                  float(p), seed, _step_ptr(), _dt(z), _s())
-        return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None
+        _lib.call('ltu_layernorm_bwd', _p(g), _p(g2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta),
+                  _p(_norm_ws(g.device)), M, d, float(p), seed, _step_ptr(), _dt(z), _s())
+        return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None, None
 
 
-def res_layernorm(x, r, gamma, beta, eps=1e-6, p=0.0, seed=0):
-    """LayerNorm(x + dropout(r)) * gamma + beta over the last dim of [M,d]; consumes (overwrites) r."""
-    return _ResLayerNorm.apply(x, r, gamma, beta, eps, p, seed)
+def res_layernorm(x, r, gamma, beta, eps=1e-6, p=0.0, seed=0, fork=False):
+    """LayerNorm(x + dropout(r)) * gamma + beta over the last dim of [M,d]; consumes (overwrites) r.
+    fork=True returns the result twice (for the projection and for the next residual)."""
+    return _ResLayerNorm.apply(x, r, gamma, beta, eps, p, seed, fork)
 
 
 class _GeluDropout(torch.autograd.Function):
