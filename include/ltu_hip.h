@@ -63,12 +63,26 @@ int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
  * be NULL.  accumulate != 0 adds to y. */
 int ltu_linear_fwd(const void* a, int lda, const void* const* w, int nw, const float* const* bias, void* y, int ldy,
                    int M, int N, int K, int accumulate, int dtype, ltu_stream_t s);
+/* ---- deferred second stage of the two-stage reductions ------------------------------------------
+ * ltu_linear_wgrad / ltu_layernorm_bwd can leave the folding of their per-split partial sums to the caller: pass a job
+ * record, collect a few, and fold them with ONE launch (ltu_reduce_batch) before the gradients are read.  A record whose
+ * `part` comes back NULL needs nothing (the call reduced in place).  The workspace handed to the producing call must stay
+ * untouched until the batch has run. */
+typedef struct ltu_reduce_job {
+  const float* part;   /* mode 0: [nsplit][n][k] tiles followed by [nsplit][n] bias partials; mode 1: [nsplit][n] */
+  int nsplit, n, k, nseg;
+  float* out[3];       /* mode 0: weight-gradient blocks [n/nseg][k] (+=);  mode 1: out[0][i/2] (i even), out[1][i/2] (i odd) */
+  float* outb[3];      /* mode 0: bias-gradient blocks (nullable) */
+  int mode;
+} ltu_reduce_job;
+int ltu_reduce_batch(const ltu_reduce_job* jobs, int njobs, ltu_stream_t s);   /* jobs: host array */
+
 /* dw_i[N/nw,K] += g[:, block i]^T . a[M,K];  db_i += column sums of g (fp32 gradients, accumulated; db may be NULL).
  * ws: optional workspace of ltu_wgrad_ws_floats(M,N,K) floats - with it (bf16) the row-split partial tiles are stored and
  * summed by a second kernel (no atomics, one launch for all nw blocks); without it fp32 atomics are used. */
 long long ltu_wgrad_ws_floats(long long M, int N, int K);
 int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw, int M, int N,
-                     int K, float* ws, int dtype, ltu_stream_t s);
+                     int K, float* ws, ltu_reduce_job* defer, int dtype, ltu_stream_t s);
 
 /* Workspace (floats) that ltu_upconv_wgrad needs for M = B*H*W*D coarse voxels (bf16 path; sub-pixel un-embedding of
  * model/Unet_3Dblock.py:419-432). */
@@ -140,8 +154,8 @@ int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* b
 /* dy2 (nullable): a second upstream gradient, summed with dy on load (the layer output feeds both the next projection and the next
  * residual; folding the sum here saves autograd's separate add pass) */
 int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                      float* dgamma, float* dbeta, float* ws, long long M, int d, float p, uint64_t seed, const uint64_t* step, int dtype,
-                      ltu_stream_t s);
+                      float* dgamma, float* dbeta, float* ws, ltu_reduce_job* defer, long long M, int d, float p, uint64_t seed,
+                      const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- GELU(erf) + dropout: model/trans_block.py:208 ---------------------------------------------- */
 int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);

@@ -12,6 +12,13 @@ LIB_PATH = os.path.join(_HERE, 'libltu_hip.so')
 
 P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_uint64
 
+
+class ReduceJob(ctypes.Structure):
+    """struct ltu_reduce_job (include/ltu_hip.h): a pending second-stage reduction"""
+    _fields_ = [('part', c_void_p), ('nsplit', c_int), ('n', c_int), ('k', c_int), ('nseg', c_int),
+                ('out', c_void_p * 3), ('outb', c_void_p * 3), ('mode', c_int)]
+
+
 # name -> argument types (return type is always int).  Mirrors include/ltu_hip.h one to one.
 SIGNATURES = {
     'ltu_version': [],
@@ -23,7 +30,8 @@ SIGNATURES = {
     'ltu_linear_fwd': [P, I, P, I, P, P, I, I, I, I, I, I, P],
     'ltu_wgrad_ws_floats': [L, I, I],
     'ltu_upconv_wgrad_ws_floats': [L, I, I],
-    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, I, P],
+    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
+    'ltu_reduce_batch': [P, I, P],
     'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
@@ -40,7 +48,7 @@ SIGNATURES = {
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_instnorm_bwd': [P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
-    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
+    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
     'ltu_gelu_dropout_fwd': [P, P, L, F, U, P, I, P],
     'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, P, I, P],
     'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],

@@ -382,7 +382,8 @@ extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) {
 }
 
 extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw,
-                                int M, int N, int K, float* ws, int dtype, ltu_stream_t s) {
+                                int M, int N, int K, float* ws, ltu_reduce_job* defer, int dtype, ltu_stream_t s) {
+  if (defer != nullptr) defer->part = nullptr;
   if (nw < 1 || nw > 3 || N % nw != 0 || K % 4 != 0 || lda % 4 != 0 || ldg % 4 != 0 || N % 4 != 0) return LTU_E_SHAPE;
   WGradArgs wa;
   memset(&wa, 0, sizeof(wa));
@@ -394,6 +395,16 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
     wa.nseg_w = nw;
     for (int i = 0; i < nw; ++i) { wa.dwseg[i] = dw[i]; wa.dbseg[i] = db ? db[i] : nullptr; }
     wa.dw = dw[0]; wa.db = db ? db[0] : nullptr;
+    if (defer != nullptr) {                  // ring kernel only; its second stage is left to ltu_reduce_batch
+      int nsplit = 0;
+      const int rr = launch_tn_ring_bf16(wa, (hipStream_t)s, &nsplit);
+      if (rr == LTU_OK) {
+        defer->part = ws; defer->nsplit = nsplit; defer->n = N; defer->k = K; defer->nseg = nw; defer->mode = 0;
+        for (int i = 0; i < 3; ++i) { defer->out[i] = i < nw ? dw[i] : nullptr; defer->outb[i] = (i < nw && db) ? db[i] : nullptr; }
+        return LTU_OK;
+      }
+      if (rr != 1) return rr;
+    }
     return launch_tn_bf16(wa, (hipStream_t)s);
   }
   const int Ns = N / nw;

@@ -356,8 +356,9 @@ static RingGeom tn_ring_geometry(long long M, int N, int K) {
 bool tn_ring_shape_ok(long long M, int N, int K) { return ring_enabled() && M % 32 == 0 && M >= 1024 && N % 128 == 0 && K % 128 == 0; }
 long long tn_ring_ws_floats(long long M, int N, int K) { return tn_ring_shape_ok(M, N, K) ? tn_ring_geometry(M, N, K).ws_floats : 0; }
 
-// dense weight gradient through the ring kernel + wgrad_reduce_kernel; returns 1 when the shape is not handled
-int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st) {
+// dense weight gradient through the ring kernel + wgrad_reduce_kernel; returns 1 when the shape is not handled.
+// With `defer` set the second stage is left to the caller (ltu_reduce_batch), *nsplit_out tells it how many splits to fold.
+int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out) {
   const IGemmArgs& g = wa.g;
   if (wa.part == nullptr || g.ntaps != 1 || g.K != g.C || g.c0 != g.C || !g.out_identity) return 1;
   if (!tn_ring_shape_ok(g.M, g.N, g.K) || g.lda0 % 8 || wa.ldg % 8) return 1;
@@ -376,5 +377,6 @@ int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st) {
   hipLaunchKernelGGL((wgrad_ring_bf16_kernel<TN_RING>), dim3(t.nk, t.nn, t.nsplit), dim3(256), smem_bytes, st, wa);
   int rc = ltu_check_launch();
   if (rc) return rc;
+  if (nsplit_out != nullptr) { *nsplit_out = t.nsplit; return LTU_OK; }
   return launch_wgrad_reduce(wa, t.nsplit, st);
 }

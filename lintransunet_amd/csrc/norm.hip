@@ -10,6 +10,7 @@
 // LayerNorm (model/trans_block.py:205-206, 209-210, eps 1e-6): y = LN(x + drop(r)) * gamma + beta; the
 // pre-norm sum z = x + drop(r) overwrites r (it is what the backward pass needs).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -404,8 +405,9 @@ extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, con
 }
 
 extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                                 float* dgamma, float* dbeta, float* ws, long long M, int d, float p, uint64_t seed,
-                                 const uint64_t* step, int dtype, ltu_stream_t s) {
+                                 float* dgamma, float* dbeta, float* ws, ltu_reduce_job* defer, long long M, int d, float p,
+                                 uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+  if (defer != nullptr) defer->part = nullptr;
   LTU_DISPATCH_T(dtype, {
     LN_DISPATCH_G(d, {
       const int nrg = 256 / G;
@@ -417,8 +419,84 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z,
       if ((long long)nblk * d * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy, (const T*)dy2,
                          (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, ws, M, (int)rows, p, seed, step);
-      if (ws != nullptr) launch_reduce_parts(ws, nblk, d * 2, 1, dgamma, dbeta, 2, (hipStream_t)s);
+      if (ws != nullptr && defer != nullptr) {
+        defer->part = ws; defer->nsplit = nblk; defer->n = d * 2; defer->k = 1; defer->nseg = 1; defer->mode = 1;
+        defer->out[0] = dgamma; defer->out[1] = dbeta; defer->out[2] = nullptr;
+        defer->outb[0] = defer->outb[1] = defer->outb[2] = nullptr;
+      } else if (ws != nullptr) {
+        launch_reduce_parts(ws, nblk, d * 2, 1, dgamma, dbeta, 2, (hipStream_t)s);
+      }
     });
   });
+  return ltu_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ deferred second stages
+// One launch folds up to 8 pending two-stage reductions (grid.y = job).  A workgroup owns 32 consecutive output elements;
+// its 32 thread groups each sum every 32nd split (coalesced 128-byte reads, 4 loads in flight), then combine through LDS.
+struct ReduceBatch {
+  ltu_reduce_job j[8];
+};
+__global__ void __launch_bounds__(1024) reduce_batch_kernel(const ReduceBatch b) {
+  __shared__ float red[32][33];
+  const ltu_reduce_job& jb = b.j[blockIdx.y];
+  const long long nk = (long long)jb.n * jb.k;
+  const long long total = jb.mode == 0 ? nk + jb.n : jb.n;
+  const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + el;
+  if ((long long)blockIdx.x * 32 >= total) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < total) {
+    const float* p;
+    long long zs;
+    if (jb.mode == 0 && e >= nk) { p = jb.part + (long long)jb.nsplit * nk + (e - nk); zs = jb.n; }
+    else { p = jb.part + e; zs = jb.mode == 0 ? nk : jb.n; }
+    int z = zq;
+    for (; z + 96 < jb.nsplit; z += 128) { a0 += p[z * zs]; a1 += p[(z + 32) * zs]; a2 += p[(z + 64) * zs]; a3 += p[(z + 96) * zs]; }
+    for (; z < jb.nsplit; z += 32) a0 += p[z * zs];
+  }
+  red[zq][el] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (zq != 0 || e >= total) return;
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) v += red[q][el];
+  if (jb.mode == 1) {
+    float* o = (e & 1) ? jb.out[1] : jb.out[0];
+    o[e >> 1] += v;
+    return;
+  }
+  const int nper = jb.n / jb.nseg;
+  if (e < nk) {
+    const int n = (int)(e / jb.k), k = (int)(e - (long long)n * jb.k);
+    const int seg = n / nper;
+    float* o = seg == 0 ? jb.out[0] : (seg == 1 ? jb.out[1] : jb.out[2]);
+    o[(long long)(n - seg * nper) * jb.k + k] += v;
+  } else {
+    const int n = (int)(e - nk);
+    const int seg = n / nper;
+    float* o = seg == 0 ? jb.outb[0] : (seg == 1 ? jb.outb[1] : jb.outb[2]);
+    if (o != nullptr) o[n - seg * nper] += v;
+  }
+}
+
+extern "C" int ltu_reduce_batch(const ltu_reduce_job* jobs, int njobs, ltu_stream_t s) {
+  for (int i0 = 0; i0 < njobs; i0 += 8) {
+    ReduceBatch b;
+    memset(&b, 0, sizeof(b));
+    int cnt = 0;
+    long long maxblk = 0;
+    for (int i = i0; i < njobs && cnt < 8; ++i) {
+      const ltu_reduce_job& j = jobs[i];
+      if (j.part == nullptr) continue;
+      if (j.nseg < 1 || j.nseg > 3 || j.n % j.nseg) return LTU_E_ARG;
+      b.j[cnt++] = j;
+      const long long total = j.mode == 0 ? (long long)j.n * j.k + j.n : j.n;
+      const long long nb = (total + 31) / 32;
+      if (nb > maxblk) maxblk = nb;
+    }
+    if (cnt == 0) continue;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)maxblk, cnt), dim3(1024), 0, (hipStream_t)s, b);
+  }
   return ltu_check_launch();
 }

@@ -154,6 +154,35 @@ def _w_transposed(ws, rows, cols, dtype):
     return wt
 
 
+# ---- deferred second stages ------------------------------------------------------------------------
+# The two-stage reductions (projection weight gradients, LayerNorm gamma/beta gradients) leave their fold to
+# `flush_deferred`, which folds up to 8 of them per launch.  Only gradients that live in a reducer's flat buffer are
+# deferred (nothing reads those before the end of backward / the bucket's all-reduce, both of which flush first).
+_DEFERRED = []          # (ReduceJob, workspace kept alive)
+_DEFER_MAX = 8
+DEFER_WGRAD = False
+
+
+def _defer_job():
+    return _lib.ReduceJob()
+
+
+def _defer_push(job, ws):
+    if job.part:
+        _DEFERRED.append((job, ws))
+        if len(_DEFERRED) >= _DEFER_MAX:
+            flush_deferred()
+
+
+def flush_deferred():
+    """fold every pending partial-sum workspace into its gradient (stream-ordered; call before gradients are consumed)"""
+    if not _DEFERRED:
+        return
+    arr = (_lib.ReduceJob * len(_DEFERRED))(*[j for j, _ in _DEFERRED])
+    _lib.call('ltu_reduce_batch', ctypes.addressof(arr), len(_DEFERRED), _s())
+    _DEFERRED.clear()
+
+
 _NORM_WS = {}
 
 
@@ -415,8 +444,14 @@ class _Linear(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         gw = [_grad_buf(w) for w in ws]
         gb = [_grad_buf(b) for b in bs]
+        wsb = _wgrad_ws(M, N, K, x)
+        # Not deferred by default: 16 MB of partial tiles per projection are folded straight away while they still sit in
+        # L2 / MALL (measured: a batched fold of 8 cold workspaces costs twice the 8 separate hot ones).
+        job = _defer_job() if (DEFER_WGRAD and wsb is not None and all(f for _, f in gw) and all(f for _, f in gb)) else None
         _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
-                  M, N, K, _p(_wgrad_ws(M, N, K, x)), dt, _s())
+                  M, N, K, _p(wsb), ctypes.addressof(job) if job is not None else 0, dt, _s())
+        if job is not None:
+            _defer_push(job, wsb)
         dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
         dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
         return (dx, None, *dws, *dbs)
@@ -498,8 +533,14 @@ class _ResLayerNorm(torch.autograd.Function):
         dr = torch.empty_like(z) if p > 0 else dz
         dgamma, fg = _grad_buf(gamma)
         dbeta, fb = _grad_buf(beta)
+        job, ws = None, _norm_ws(g.device)
+        if fg and fb:                      # gamma/beta gradients live in a reducer bucket: fold the partials later, batched
+            job = _defer_job()
+            ws = torch.empty(2048 * 2 * d, device=g.device, dtype=torch.float32)       # private: it outlives this call
         _lib.call('ltu_layernorm_bwd', _p(g), _p(g2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta),
-                  _p(_norm_ws(g.device)), M, d, float(p), seed, _step_ptr(), _dt(z), _s())
+                  _p(ws), ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, _step_ptr(), _dt(z), _s())
+        if job is not None:
+            _defer_push(job, ws)
         return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None, None
 
 
@@ -784,9 +825,9 @@ class _Gate(torch.autograd.Function):
         dwg, f3 = _grad_buf(wg)
         dbg, f4 = _grad_buf(bg)
         _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _ptr_array([dwx]), _ptr_array([dbx]), 1, M, C, C,
-                  _p(_wgrad_ws(M, C, C, skip)), dt, _s())
+                  _p(_wgrad_ws(M, C, C, skip)), 0, dt, _s())
         _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _ptr_array([dwg]), _ptr_array([dbg]), 1, M, C, Cg,
-                  _p(_wgrad_ws(M, C, Cg, skip)), dt, _s())
+                  _p(_wgrad_ws(M, C, Cg, skip)), 0, dt, _s())
         return (dskip, dup, _grad_done(wx, dwx, f1), _grad_done(bx, dbx, f2), _grad_done(wg, dwg, f3), _grad_done(bg, dbg, f4),
                 _grad_done(pw, dpw, fpw), _grad_done(pb, dpb, fpb), None, None)
 

@@ -84,6 +84,7 @@ def train_step(model, images, labels, weights, step_times=1, specs=None, reducer
     if reducer is not None:
         reducer.prepare()
     torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    ops.flush_deferred()                    # second stages of the two-stage reductions still queued by backward
     if reducer is not None:
         reducer.finish()
     return totals, named
@@ -146,6 +147,7 @@ class GradReducer:
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.world > 1:
+            ops.flush_deferred()            # pending second-stage reductions may still owe this bucket their sums
             self.handles.append((bi, dist.all_reduce(self.flat[bi], group=self.group, async_op=True)))
 
     def reduce_all(self):

@@ -17,7 +17,7 @@ def ln(M, d):
     dg, db = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
     stat = torch.empty(M, 2, device='cuda')
     f = lambda: _lib.call('ltu_layernorm_fwd', _p(x), _p(r), _p(gamma), _p(beta), _p(y), _p(stat), M, d, 1e-5, 0.3, 1, 0, 1, _s())
-    b = lambda: _lib.call('ltu_layernorm_bwd', _p(g), 0, _p(r), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(WS), M, d, 0.3, 1, 0, 1, _s())
+    b = lambda: _lib.call('ltu_layernorm_bwd', _p(g), 0, _p(r), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(WS), 0, M, d, 0.3, 1, 0, 1, _s())
     tf, tb = timed(f), timed(b)
     mb = M * d * 2 / 1e6
     print(f'LN   M={M:7d} d={d:4d}: fwd {tf:6.1f} us ({4 * mb / tf / 1e0:.0f} GB/s)  bwd {tb:6.1f} us ({4 * mb / tb:.0f} GB/s)', flush=True)
