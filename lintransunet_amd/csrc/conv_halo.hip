@@ -724,7 +724,7 @@ __device__ __forceinline__ void cr_static_for(F&& f) {
 // The weight stream is organised class by class: stage (chunk, class c, sub-stage sc) holds up to TS entries of class c, so
 // the accumulator a stage updates is known at compile time (a run-time class index makes hipcc shuffle all 256 accumulator
 // registers around every entry).  SPCLS sub-stages per class; entries e in [cls_begin[c], cls_begin[c + 1]).
-template <int NC, int TN, int SPCLS>
+template <int NC, int TN, int SPCLS, bool FULL>
 __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHaloArgs a) {
   static_assert(NC * TN == 8, "8 accumulator tile pairs per wave");
   constexpr int BN = 32 * TN, TS = 8 / TN, R = 4, SPC = NC * SPCLS;
@@ -732,11 +732,6 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
   extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
   uint16_t* halo = smem;                   // [2][640][32]
   uint16_t* ring = smem + 2 * HBUF;        // [R][TS][BN][32]
-  // the entry table lives in LDS: indexing the kernel-argument copy per lane would be a vector-memory load inside the
-  // asynchronous span (and hipcc drains vmcnt to 0 for it)
-  int* s_doff = reinterpret_cast<int*>(ring + R * WSTAGE);   // halo voxel offset of the entry
-  int* s_wbase = s_doff + 64;
-  int* s_cb = s_wbase + 64;                                   // class -> first entry; [NC] = end
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int nbh = (a.H + 3) / 4, nbw = (a.W + 7) / 8, nbd = (a.D + 7) / 8;
@@ -750,16 +745,34 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
   const int nchunk = a.C / 32;
   const int total = nchunk * SPC;
   const uint16_t* zsrc = reinterpret_cast<const uint16_t*>(ltu_zero_line) + (lane & 3) * 8;
-  if (tid < 64) {
-    const ClsEntry en = a.ent[tid < a.nent ? tid : 0];
-    s_doff[tid] = (en.dh * 10 + en.dw) * 10 + en.dd;
-    s_wbase[tid] = tid < a.nent ? en.wbase : -1;
-    if (tid <= 8) s_cb[tid] = a.cls_begin[tid];
+  // The entry table is held one entry per lane in two VGPRs and read with v_readlane (wave-uniform index): indexing the
+  // kernel-argument copy at run time would be a vector-memory load inside the asynchronous span (hipcc drains vmcnt for it),
+  // an LDS copy costs a round trip per use.
+  int ent_doff, ent_wbase;                 // (halo voxel offset) * 4 + (dw + 1);  weight tile base or -1
+  {
+    const ClsEntry en = a.ent[lane < a.nent ? lane : 0];
+    ent_doff = ((en.dh * 10 + en.dw) * 10 + en.dd) * 4 + (en.dw + 1);
+    ent_wbase = lane < a.nent ? en.wbase : -1;
   }
-  __syncthreads();                                           // nothing asynchronous in flight yet
-
-  // LDS-DMA lane geometry: piece = 16 rows x 64 B, lane -> (row lane >> 2, slot lane & 3), logical chunk = slot ^ ((row >> 2) & 1)
-  const int prow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the table is in registers before anything asynchronous starts
+  // LDS-DMA lane geometry: piece = 16 rows x 64 B, lane -> (row lane >> 2, slot lane & 3).  64-byte rows: a quarter-wave of a
+  // ds_read_b128 covers 16 rows = four times each 64-byte residue of the 256-byte bank row, so the slot needs two row-dependent
+  // bits.  A ds_read_b128 lane group is lanes {0-3, 12-15, 20-27} (and its three siblings): for the weight tile those are rows
+  // whose (row >> 2) & 3 are all different -> slot = chunk ^ ((row >> 2) & 3); for the halo they are four d-runs on four
+  // consecutive w positions -> slot = chunk ^ (w & 3).
+  const int prow = lane >> 2;
+  const int wchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  // per-lane constant part of a weight source address: piece s of a stage holds rows (wave*4 + s)*16 + prow = t*BN + nl with a
+  // wave-uniform t
+  long long woff[4];
+  int wt[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = (wave * 4 + s) * 16 + prow;
+    wt[s] = row / BN;
+    const int n = n_blk + row % BN;
+    woff[s] = n < a.N ? (long long)n * a.wrow + wchunk * 8 : -1;
+  }
 
   auto issue_halo = [&](int chunk) {
     uint16_t* hb = halo + (chunk & 1) * HBUF;
@@ -769,27 +782,31 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
       const int hv = piece * 16 + prow;
       const int hd = hv % 10, hw = (hv / 10) % 10, hh = hv / 100;
       const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+      const int lc = (lane & 3) ^ (hw & 3);
       const uint16_t* src = zsrc;
       if (hv < CR_HVOX && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
-        src = reinterpret_cast<const uint16_t*>(a.x) + ((((long long)b * a.H + h) * a.W + w) * a.D + d) * a.lda + chunk * 32 + lchunk * 8;
+        src = reinterpret_cast<const uint16_t*>(a.x) + ((((long long)b * a.H + h) * a.W + w) * a.D + d) * a.lda + chunk * 32 + lc * 8;
       cglds16(src, hb + piece * 512);
     }
   };
   auto issue_w = [&](int g) {
     const int chunk = g / SPC, st = g - chunk * SPC;
     const int c = st / SPCLS, sc = st - c * SPCLS;
-    const int e0 = s_cb[c] + sc * TS, e1 = s_cb[c + 1];
-    uint16_t* wb = ring + (g % R) * WSTAGE;
+    int e0 = a.cls_begin[0], e1 = a.cls_begin[1];              // class c of a run-time stage index: uniform selects, no memory
+#pragma unroll
+    for (int q = 1; q < NC; ++q) {
+      e0 = c == q ? a.cls_begin[q] : e0;
+      e1 = c == q ? a.cls_begin[q + 1] : e1;
+    }
+    e0 += sc * TS;
+    uint16_t* wb = ring + (g % R) * WSTAGE + wave * 4 * 512;
+    const uint16_t* wsrc = reinterpret_cast<const uint16_t*>(a.w) + chunk * 32;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int piece = wave * 4 + s;                  // 16 pieces of 16 rows per stage
-      const int row = piece * 16 + prow;               // = t * BN + n_local
-      const int t = row / BN, nl = row - t * BN;
-      const int e = e0 + t, n = n_blk + nl;
-      const uint16_t* src = zsrc;
-      if (e < e1 && n < a.N)
-        src = reinterpret_cast<const uint16_t*>(a.w) + s_wbase[e] + (long long)n * a.wrow + chunk * 32 + lchunk * 8;
-      cglds16(src, wb + piece * 512);
+      const int e = e0 + __builtin_amdgcn_readfirstlane(wt[s]);
+      const int wbase = e < e1 ? __builtin_amdgcn_readlane(ent_wbase, e & 63) : -1;
+      const uint16_t* src = (wbase >= 0 && woff[s] >= 0) ? wsrc + wbase + woff[s] : zsrc;
+      cglds16(src, wb + s * 512);
     }
   };
 
@@ -807,7 +824,8 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
   int hv0[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) hv0[i] = ((wave + 1) * 10 + (i * 4 + (li >> 3) + 1)) * 10 + (li & 7) + 1;
-  const int wsw = (li >> 2) & 1;
+  const int hwl = li >> 3;                                    // this lane's w inside its tile (halo w = 4 i + hwl + 1 + dw)
+  const int wsw = (li >> 2) & 3;
 
   issue_halo(0);
   for (int g = 0; g < R - 1 && g < total; ++g) issue_w(g);
@@ -826,18 +844,15 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
       if (g + R - 1 < total) issue_w(g + R - 1);
       if (st == 0 && chunk + 1 < nchunk) issue_halo(chunk + 1);
       const uint16_t* wb = ring + (g % R) * WSTAGE;
-      const int e0 = a.cls_begin[c] + sc * TS, e1 = a.cls_begin[c + 1];
-#pragma unroll 2
-      for (int t = 0; t < TS; ++t) {
-        const int e = e0 + t;
-        if (e >= e1) break;
-        const int doff = __builtin_amdgcn_readfirstlane(s_doff[e]);
-        bf16x8 af[2][2], wf[TN][2];
+      const int e0 = a.cls_begin[c] + sc * TS;
+      // fragments of entry t+1 are fetched before the MFMAs of entry t are issued (pinned with sched_barrier: left alone,
+      // hipcc sinks every ds_read next to its MFMA and each MFMA then waits a full LDS round trip)
+      auto load_frags = [&](int t, int dv, bf16x8 (&af)[2][2], bf16x8 (&wf)[TN][2]) {
+        const int doff = dv >> 2, sw = (hwl + (dv & 3)) & 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int hv = hv0[i] + doff;
           const uint16_t* p = hb + hv * 32;
-          const int sw = (hv >> 2) & 1;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(p + (((ks * 2 + lh) ^ sw) << 3));
         }
@@ -846,12 +861,41 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
             wf[j][ks] = *reinterpret_cast<const bf16x8*>(wb + (t * BN + j * 32 + li) * 32 + (((ks * 2 + lh) ^ wsw) << 3));
+      };
+      // transposed product D[n][voxel]: a lane then owns 4 consecutive n of one voxel (8-byte staging writes in the epilogue)
+      auto mma = [&](const bf16x8 (&af)[2][2], const bf16x8 (&wf)[TN][2]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], wf[j][ks], acc[c][i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][ks], af[i][ks], acc[c][i][j], 0, 0, 0);
+      };
+      if constexpr (FULL) {                // every stage holds TS entries: straight-line, software-pipelined
+        int dv[TS];
+#pragma unroll
+        for (int t = 0; t < TS; ++t) dv[t] = __builtin_amdgcn_readlane(ent_doff, (e0 + t) & 63);
+        bf16x8 afA[2][2], wfA[TN][2], afB[2][2], wfB[TN][2];
+        load_frags(0, dv[0], afA, wfA);
+#pragma unroll
+        for (int t = 0; t < TS; t += 2) {
+          if (t + 1 < TS) load_frags(t + 1, dv[t + 1], afB, wfB);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(afA, wfA);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 2 < TS) load_frags(t + 2, dv[t + 2], afA, wfA);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < TS) mma(afB, wfB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        const int cnt = a.cls_begin[c + 1] - e0;
+#pragma unroll 1
+        for (int t = 0; t < cnt && t < TS; ++t) {
+          bf16x8 af[2][2], wf[TN][2];
+          load_frags(t, __builtin_amdgcn_readlane(ent_doff, (e0 + t) & 63), af, wf);
+          mma(af, wf);
+        }
       }
     });
   }
@@ -859,23 +903,29 @@ __global__ void __launch_bounds__(256) conv_class_ring_bf16_kernel(const ClassHa
   // epilogue, class by class (everything asynchronous has landed: the last iterations waited vmcnt(0))
   constexpr int LDC = BN + 8;
   uint16_t* Cs = smem;                     // [256][LDC]
+  float4 bv4[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int n = n_blk + j * 32 + 8 * rr + 4 * lh;
+      bv4[j][rr] = (a.bias != nullptr && n < a.N) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     if (c >= a.ncls) break;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nl = j * 32 + li;
-      const int n = n_blk + nl;
-      const float bvv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          Cs[ml * LDC + nl] = f32_to_bf16(acc[c][i][j][r] + bvv);
+        for (int rr = 0; rr < 4; ++rr) {
+          uint2 pk;
+          pk.x = pack_bf16x2(acc[c][i][j][4 * rr + 0] + bv4[j][rr].x, acc[c][i][j][4 * rr + 1] + bv4[j][rr].y);
+          pk.y = pack_bf16x2(acc[c][i][j][4 * rr + 2] + bv4[j][rr].z, acc[c][i][j][4 * rr + 3] + bv4[j][rr].w);
+          *reinterpret_cast<uint2*>(&Cs[(wave * 64 + i * 32 + li) * LDC + j * 32 + 8 * rr + 4 * lh]) = pk;
         }
-    }
     __syncthreads();
     constexpr int CPR = BN / 4;
     const int ph = a.cls_p[c][0], pw = a.cls_p[c][1], pd = a.cls_p[c][2];
@@ -916,15 +966,20 @@ int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st) {
     for (int c = a.ncls; c <= 8; ++c) r.cls_begin[c] = ne;
     if (fits) {
       const long long rb = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 7) / 8) * ((a.D + 7) / 8);
-      constexpr int smem_bytes = 2 * CR_HROWS * 64 + 4 * 16384 + (64 + 64 + 16) * 4;
+      constexpr int smem_bytes = 2 * CR_HROWS * 64 + 4 * 16384;
       static bool attr_done = false;
       if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<8, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<8, 1, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<4, 2, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
         attr_done = true;
       }
-      if (a.ncls > 4) hipLaunchKernelGGL((conv_class_ring_bf16_kernel<8, 1, 1>), dim3((unsigned)rb, cdiv(a.N, 32)), dim3(256), smem_bytes, st, r);
-      else hipLaunchKernelGGL((conv_class_ring_bf16_kernel<4, 2, 3>), dim3((unsigned)rb, cdiv(a.N, 64)), dim3(256), smem_bytes, st, r);
+      bool full = a.ncls == 8;
+      for (int c = 0; c < a.ncls; ++c) full = full && (r.cls_begin[c + 1] - r.cls_begin[c] == 8);
+      const dim3 g8((unsigned)rb, cdiv(a.N, 32)), g4((unsigned)rb, cdiv(a.N, 64));
+      if (a.ncls > 4 && full) hipLaunchKernelGGL((conv_class_ring_bf16_kernel<8, 1, 1, true>), g8, dim3(256), smem_bytes, st, r);
+      else if (a.ncls > 4) hipLaunchKernelGGL((conv_class_ring_bf16_kernel<8, 1, 1, false>), g8, dim3(256), smem_bytes, st, r);
+      else hipLaunchKernelGGL((conv_class_ring_bf16_kernel<4, 2, 3, false>), g4, dim3(256), smem_bytes, st, r);
       return ltu_check_launch();
     }
   }

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
 // Y[M][N] = A[M][K] W^T + bias for one column tile of BN = 64 TNW columns; the workgroup is PERSISTENT over row tiles.
 //   * its W tile [BN][K] is fetched once and stays in LDS ("weight stationary"): the k-loop has no weight traffic at all;
 //   * A streams through the ring in units of [128 rows][64 k] (16 KB), R - 1 units in flight, across tile boundaries;
-//   * 128-byte LDS rows, chunk c of row r at slot c ^ (r & 7): conflict-free ds_read_b128 fragments;
+//   * 128-byte LDS rows, chunk c of row r at slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128 fragments;
 //   * the product is formed transposed (D[n][m]) so a lane owns 4 consecutive n of one row: 8-byte staging writes into the
 //     ring slot just consumed (wave-private quarter), 16-byte row-major reads, 16-byte global stores.
 // vmcnt book-keeping: loads and stores retire in order, so the wait after an epilogue allows for its S stores as well
@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
   }
   __syncthreads();                                          // nothing asynchronous in flight yet
 
-  const int srow = lane >> 3, lchunk = (lane & 7) ^ srow;   // LDS-DMA piece = 8 rows x 128 B
+  // LDS-DMA piece = 8 rows x 128 B.  Slot = chunk ^ ((row >> 1) & 7): the 16 rows a quarter-wave reads with ds_read_b128 then
+  // occupy 16 distinct 16-byte slots of the 256-byte bank row.  Every piece this wave fills has the parity of `wave`.
+  const int srow = lane >> 3, lchunk = (lane & 7) ^ (((wave & 1) << 2) | (srow >> 1));
   {
     const int wpieces = KC * (BN / 8);
     for (int p = wave; p < wpieces; p += NW) {
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int sw = li & 7;
+  const int sw = (li >> 1) & 7;
   const int a_off = (wm * 32 * TM + li) * 64, w_off = (wn * 32 * TNW + li) * 64;
   int kc = 0, tile = blockIdx.x;
   bool after_store = false;
