@@ -221,6 +221,11 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float4 bias4[TNW][4];                                    // this lane's 4 x 4 consecutive columns of each 32-column tile
+#pragma unroll
+  for (int j = 0; j < TNW; ++j)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bias4[j][rr] = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
   const int sw = (li >> 1) & 7;
   const int a_off = (wm * 32 * TM + li) * 64, w_off = (wn * 32 * TNW + li) * 64;
   int kc = 0, tile = blockIdx.x;
@@ -236,19 +241,25 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
     if (q + R - 1 < nunits) issue((q + R - 1) % R);
     const uint16_t* As = ring + (q % R) * AUNIT + a_off;
     const uint16_t* Ws = Wl + kc * BN * 64 + w_off;
+    // all fragment reads of the unit first, then its MFMAs (pinned: hipcc otherwise sinks each read next to its MFMA, which
+    // then waits a full LDS round trip)
+    bf16x8 af[4][TM], wf[4][TNW];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int co = ((ks * 2 + lh) ^ sw) << 3;
-      bf16x8 af[TM], wf[TNW];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 64 + co);
+      for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 64 + co);
 #pragma unroll
-      for (int j = 0; j < TNW; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Ws + j * 32 * 64 + co);
+      for (int j = 0; j < TNW; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(Ws + j * 32 * 64 + co);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (++kc < KC) continue;
 
     // ---- tile finished: stage 32 x 32 sub-tiles through this unit's slot (every wave is done with it after the barrier)
@@ -261,7 +272,7 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
       for (int j = 0; j < TNW; ++j) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const float4 bv = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
+          const float4 bv = bias4[j][rr];
           uint2 pk;
           pk.x = pack_bf16x2(acc[i][j][4 * rr + 0] + bv.x, acc[i][j][4 * rr + 1] + bv.y);
           pk.y = pack_bf16x2(acc[i][j][4 * rr + 2] + bv.z, acc[i][j][4 * rr + 3] + bv.w);
