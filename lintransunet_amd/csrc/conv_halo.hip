@@ -490,7 +490,7 @@ static int whalo_blocks() {
   return v;
 }
 
-static bool whalo_shape_ok(int C, int N) { return N % 8 == 0 && N <= 64 && (C % 16 == 0 || C == 8); }
+static bool whalo_shape_ok(int C, int N) { return N % 8 == 0 && N <= 256 && (C % 16 == 0 || C == 8); }
 
 long long conv_wgrad_halo_ws_floats(int N, int K) {
   if (K % 27) return 0;

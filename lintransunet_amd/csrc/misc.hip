@@ -74,7 +74,7 @@ __global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
 extern "C" int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s) {
   if (n <= 0) return LTU_OK;
   LTU_DISPATCH_T(out_dtype, {
-    hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(64, n), dim3(256), 0, (hipStream_t)s, (const WPrep*)table);
+    hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(256, n), dim3(256), 0, (hipStream_t)s, (const WPrep*)table);
   });
   return ltu_check_launch();
 }
