@@ -91,7 +91,7 @@ class KernelTimer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
+        with torch.cuda.graph(g, capture_error_mode='thread_local'), torch.no_grad():
             for c in self.calls:
                 replay_fn(c)
         g.replay()

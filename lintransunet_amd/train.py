@@ -199,8 +199,12 @@ class GraphedStep:
                 body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()                 # no collective in flight while the stream is capturing
+            torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.totals, self.named = body()
 
     def __call__(self, images=None, labels=None):
