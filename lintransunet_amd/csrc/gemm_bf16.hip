@@ -539,8 +539,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
       n = (int)(e / g.K); k = (int)(e % g.K);
       const float* p = wa.part + (long long)n * wa.kpad + k;
       int z = zq;
-      for (; z + 8 < nsplit; z += 16) { a0 += p[z * zs]; a1 += p[(z + 8) * zs]; }
-      if (z < nsplit) a0 += p[z * zs];
+      float a2 = 0.f, a3 = 0.f;
+      for (; z + 24 < nsplit; z += 32) { a0 += p[z * zs]; a1 += p[(z + 8) * zs]; a2 += p[(z + 16) * zs]; a3 += p[(z + 24) * zs]; }
+      for (; z < nsplit; z += 8) a0 += p[z * zs];
+      a0 += a2; a1 += a3;
     } else {
       n = (int)(e - nk);
       for (int z = zq; z < nsplit; z += 8) a0 += wa.bpart[(long long)z * wa.npad + n];
