@@ -258,7 +258,18 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
 
   const int hv0 = (wave * HALO_W + (li >> 3)) * HALO_D + (li & 7);      // halo voxel of this lane's row at tap (0,0,0)
   const int wsw = (li >> 2) & 1;
-  const float bvv = (a.bias != nullptr && li < a.N) ? a.bias[li] : 0.f;
+  float4 bv4[4];                           // bias of this lane's 4 x 4 consecutive output channels
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int n = 8 * rr + 4 * lh;
+    bv4[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias != nullptr) {
+      if (n + 0 < a.N) bv4[rr].x = a.bias[n + 0];
+      if (n + 1 < a.N) bv4[rr].y = a.bias[n + 1];
+      if (n + 2 < a.N) bv4[rr].z = a.bias[n + 2];
+      if (n + 3 < a.N) bv4[rr].w = a.bias[n + 3];
+    }
+  }
   uint16_t* Cs = halo;
 
   int brick = blockIdx.x;
@@ -271,26 +282,47 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // taps in 9 groups of 3 (one d-run); all fragments of a group are fetched before its MFMAs are issued (pinned with
+    // sched_barrier: left alone, hipcc sinks each ds_read next to its MFMA, which then waits an LDS round trip).
+    // Transposed product D[n][voxel]: a lane then owns 4 consecutive channels of one voxel (8-byte staging writes).
+    auto load_group = [&](int gidx, bf16x8 (&av)[3][KS], bf16x8 (&bv)[3][KS]) {
 #pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      int th = tap / 9, tw = (tap / 3) % 3, td = tap % 3;
-      const int ts = a.flip ? 26 - tap : tap;        // data gradient: tap t reads the mirrored halo offset
-      th = ts / 9; tw = (ts / 3) % 3; td = ts % 3;
-      const int hv = hv0 + (th * HALO_W + tw) * HALO_D + td;
+      for (int q = 0; q < 3; ++q) {
+        const int tap = gidx * 3 + q;
+        const int ts = a.flip ? 26 - tap : tap;      // data gradient: tap t reads the mirrored halo offset
+        const int th = ts / 9, tw = (ts / 3) % 3, td = ts % 3;
+        const int hv = hv0 + (th * HALO_W + tw) * HALO_D + td;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int ca = CC == 32 ? (((ks * 2 + lh) ^ ((hv >> 2) & 1)) << 3) : (lh << 3);
-        const int cb = CC == 32 ? (((ks * 2 + lh) ^ wsw) << 3) : (lh << 3);
-        const bf16x8 av = *reinterpret_cast<const bf16x8*>(&halo[hv * CC + ca]);
-        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&Wl[(tap * 32 + li) * CC + cb]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ca = CC == 32 ? (((ks * 2 + lh) ^ ((hv >> 2) & 1)) << 3) : (lh << 3);
+          const int cb = CC == 32 ? (((ks * 2 + lh) ^ wsw) << 3) : (lh << 3);
+          av[q][ks] = *reinterpret_cast<const bf16x8*>(&halo[hv * CC + ca]);
+          bv[q][ks] = *reinterpret_cast<const bf16x8*>(&Wl[(tap * 32 + li) * CC + cb]);
+        }
       }
+    };
+    auto mma_group = [&](const bf16x8 (&av)[3][KS], const bf16x8 (&bv)[3][KS]) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[q][ks], av[q][ks], acc, 0, 0, 0);
+    };
+    // one fragment set per group (the SIMD's second wave covers the read latency; a second set would cost that occupancy)
+#pragma unroll
+    for (int gi = 0; gi < 9; ++gi) {
+      bf16x8 avA[3][KS], bvA[3][KS];
+      load_group(gi, avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group(avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                       // every wave is done with the halo: it becomes the output staging
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Cs[ml * LDC + li] = f32_to_bf16(acc[r] + bvv);
+    for (int rr = 0; rr < 4; ++rr) {
+      uint2 pk;
+      pk.x = pack_bf16x2(acc[4 * rr + 0] + bv4[rr].x, acc[4 * rr + 1] + bv4[rr].y);
+      pk.y = pack_bf16x2(acc[4 * rr + 2] + bv4[rr].z, acc[4 * rr + 3] + bv4[rr].w);
+      *reinterpret_cast<uint2*>(&Cs[(wave * 32 + li) * LDC + 8 * rr + 4 * lh]) = pk;
     }
     __syncthreads();
     int t = brick;
