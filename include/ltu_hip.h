@@ -223,6 +223,24 @@ int ltu_loss_bwd(const float* p, const uint8_t* label, const float* coef, const 
 /* label pyramid (utils/utils_3D_embed_full.py:64,73-76): u8 [B,H,W,D] -> max over (2,2,kd) windows */
 int ltu_label_maxpool(const uint8_t* x, uint8_t* y, int B, int H, int W, int D, int kd, ltu_stream_t s);
 
+/* ---- sliding-window whole-volume inference (inference_embed_attn.py:92-185; monai 0.7.0 sliding_window_inference,
+ * constant blending) ------------------------------------------------------------------------------------------------
+ * desc int32 [n][4] = (sample, h0, w0, d0) of each window in the PADDED image (a dimension smaller than the window is padded
+ * symmetrically with zeros: pad_lo = (roi - dim) / 2).  vol f32 [B][H][W][D] (one channel); win f32 [n][h][w][d];
+ * seg f32 [n][h][w][d][C] = the model's eval output (channels-last one-hot); votes f32 [B][C][Hp][Wp][Dp] and
+ * count f32 [B][Hp][Wp][Dp] zero-filled accumulators; out f32 [B][C][H][W][D] = votes / count without the padding. */
+int ltu_window_gather(const float* vol, float* win, const int* desc, int n, int H, int W, int D, int h, int w, int d, int ph, int pw,
+                      int pd, ltu_stream_t s);
+int ltu_vote_accumulate(const float* seg, float* votes, float* count, const int* desc, int n, int Hp, int Wp, int Dp, int h, int w,
+                        int d, int C, ltu_stream_t s);
+int ltu_vote_finalize(const float* votes, const float* count, float* out, int B, int C, int H, int W, int D, int Hp, int Wp, int Dp,
+                      int ph, int pw, int pd, ltu_stream_t s);
+/* evaluation metrics of the driver on p = [pred[b][ci] >= threshold] against target u8 [B][H][W][D] (0/1):
+ * values[0..3] = DiceClassLoss (criterions.py:35-70), Recall (280-311), Precision (348-379), LocalizationLoss (179-241),
+ * means over the batch; rows f32 [B][3][H] scratch (per-h sums of p, t, p*t over W*D = WD elements). */
+int ltu_seg_metrics(const float* pred, const uint8_t* target, float* rows, float* values, int B, int C, int ci, int H, long long WD,
+                    float threshold, ltu_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,10 @@ SIGNATURES = {
     'ltu_linattn_splits': [I, I],
     'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],
     'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    'ltu_window_gather': [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_vote_accumulate': [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    'ltu_vote_finalize': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_seg_metrics': [P, P, P, P, I, I, I, I, L, F, P],
     'ltu_norm_ws_floats': [],
     'ltu_instnorm_stats': [P, P, P, I, L, I, I, P],
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],

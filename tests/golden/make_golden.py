@@ -34,6 +34,7 @@ from oracle import roi as O_roi                  # noqa: E402
 from oracle import losses as O_loss              # noqa: E402
 from oracle import step as O_step                # noqa: E402
 from oracle import seedgen                       # noqa: E402
+from oracle import infer as O_infer              # noqa: E402
 
 TOL = 1e-5
 
@@ -194,6 +195,39 @@ def fx_losses():
 
 # ----------------------------------------------------------------------------- whole model
 
+
+def fx_metrics():
+    """evaluation metrics of the inference driver (inference_embed_attn.py:147-151) on a thresholded prediction"""
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    for tag, shape in (('a', (1, 2, 24, 10, 6)), ('b', (2, 2, 17, 5, 4))):
+        B, C, H, W, D = shape
+        blob = torch.zeros(B, 1, H, W, D)
+        blob[:, :, H // 4: H // 4 + H // 2, 1:W - 1, 1:D - 1] = 1.0
+        target = ((torch.rand(B, 1, H, W, D, generator=g) < 0.85).float() * blob).long()
+        noise = (torch.rand(B, 1, H, W, D, generator=g) < 0.15).float()
+        fg = torch.clamp(target.float() * (torch.rand(B, 1, H, W, D, generator=g) < 0.8).float() + noise, 0, 1)
+        predict = torch.cat((1 - fg, fg), 1)
+        ref = {
+            'DiceClassLoss': R_loss.DiceClassLoss()(predict, target),
+            'Recall': R_loss.Recall()(predict, target),
+            'Precision': R_loss.Precision()(predict, target),
+            'LocalizationLoss': R_loss.LocalizationLoss()(predict, target),
+        }
+        ora = {
+            'DiceClassLoss': O_loss.dice_class(predict, target),
+            'Recall': O_infer.recall(predict, target),
+            'Precision': O_infer.precision(predict, target),
+            'LocalizationLoss': O_infer.localization_loss(predict, target.float()),
+        }
+        for k in ref:
+            close(ora[k], ref[k], f'metrics {tag} {k}')
+        out[f'{tag}_predict'] = predict.numpy().astype(np.float32)
+        out[f'{tag}_target'] = target.numpy().astype(np.uint8)
+        out[f'{tag}_values'] = np.array([ref[k].item() for k in ('DiceClassLoss', 'Recall', 'Precision', 'LocalizationLoss')], np.float64)
+    np.savez(os.path.join(HERE, 'metrics.npz'), **out)
+    print('metrics.npz written')
+
 def run_reference_model(cfg: O_net.NetConfig, P, x, label, weights):
     Model = get_model_dict('MaskTransUnet')
     model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
@@ -298,6 +332,10 @@ def fx_model(tag, cfg, size, batch, wseed, full_arrays):
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':      # only the inference-driver metrics fixture
+        fx_metrics()
+        return
+    fx_metrics()
     fx_linattn()
     fx_attn_layer()
     fx_roi()

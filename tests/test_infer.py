@@ -1,0 +1,105 @@
+"""Sliding-window inference driver: oracle pinned by golden metrics; HIP path vs oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import infer as O  # noqa: E402
+from oracle import losses as OL  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------- CPU: oracle
+def test_oracle_metrics_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    for tag in ('a', 'b'):
+        p, t = torch.from_numpy(G[f'{tag}_predict']), torch.from_numpy(G[f'{tag}_target']).long()
+        got = [OL.dice_class(p, t), O.recall(p, t), O.precision(p, t), O.localization_loss(p, t.float())]
+        for v, ref in zip(got, G[f'{tag}_values']):
+            assert abs(v.item() - ref) <= 1e-6 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize('img,roi,overlap', [((512, 512, 40), (512, 512, 32), 0.6), ((70, 33, 16), (32, 32, 16), 0.6),
+                                              ((20, 20, 8), (32, 16, 8), 0.25), ((9, 9, 9), (4, 4, 4), 0.0)])
+def test_oracle_window_schedule(img, roi, overlap):
+    """every voxel of the (padded) image is covered, windows stay inside, the last window touches the end"""
+    pimg = tuple(max(i, r) for i, r in zip(img, roi))
+    starts = O.patch_starts(pimg, roi, O.scan_interval(pimg, roi, overlap))
+    cover = np.zeros(pimg, dtype=np.int32)
+    for s in starts:
+        assert all(0 <= a and a + r <= i for a, r, i in zip(s, roi, pimg))
+        cover[s[0]:s[0] + roi[0], s[1]:s[1] + roi[1], s[2]:s[2] + roi[2]] += 1
+    assert cover.min() >= 1
+    assert len(set(starts)) == len(starts)
+    if img == (512, 512, 40):          # the reference configuration: 1 x 1 x 2 windows of depth 32 over a 40-slice scan
+        assert starts == [(0, 0, 0), (0, 0, 8)]
+
+
+def test_oracle_sliding_window_identity():
+    """with an identity-like predictor the blended output equals the input (constant weights average equal values)"""
+    x = torch.randn(2, 1, 19, 11, 7)
+    out = O.sliding_window_inference(x, (8, 8, 4), 3, lambda w: torch.cat((w, -w), 1), overlap=0.5)
+    assert torch.allclose(out[:, :1], x, atol=1e-6) and torch.allclose(out[:, 1:], -x, atol=1e-6)
+    small = torch.randn(1, 1, 5, 6, 3)      # smaller than the window: symmetric zero padding, cropped again
+    out = O.sliding_window_inference(small, (8, 8, 4), 2, lambda w: torch.cat((w, 2 * w), 1), overlap=0.6)
+    assert out.shape == (1, 2, 5, 6, 3) and torch.allclose(out[:, :1], small, atol=1e-6)
+
+
+def test_host_schedule_matches_oracle():
+    from lintransunet_amd import infer as P
+    for img, roi, ov in [((512, 512, 40), (512, 512, 32), 0.6), ((70, 33, 16), (32, 32, 16), 0.6), ((9, 9, 9), (4, 4, 4), 0.1)]:
+        assert P.scan_interval(img, roi, ov) == O.scan_interval(img, roi, ov)
+        assert P.patch_starts(img, roi, P.scan_interval(img, roi, ov)) == O.patch_starts(img, roi, O.scan_interval(img, roi, ov))
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+DEV = 'cuda'
+
+
+def _onehot_predictor(w):
+    """a deterministic stand-in model: 3 classes from thresholds of the window intensities, one-hot, channels-last memory"""
+    cls = (w[:, 0] > 0.3).long() + (w[:, 0] > 1.0).long()
+    oh = torch.nn.functional.one_hot(cls, 3).to(torch.float32)       # [n, h, w, d, C]
+    return oh.permute(0, 4, 1, 2, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,roi,sw,overlap', [((2, 1, 37, 21, 12), (16, 16, 8), 4, 0.6), ((1, 1, 10, 40, 6), (16, 16, 8), 3, 0.6),
+                                                   ((1, 1, 33, 33, 9), (32, 32, 8), 2, 0.25)])
+def test_sliding_window_matches_oracle(shape, roi, sw, overlap):
+    from lintransunet_amd import infer as P
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g)
+    ref = O.sliding_window_inference(x, roi, sw, _onehot_predictor, overlap=overlap)
+    got = P.sliding_window_inference(x.to(DEV), roi, sw, _onehot_predictor, overlap=overlap)
+    assert got.shape == ref.shape
+    assert torch.equal(got.cpu(), ref)          # votes and counts are small integers: exact
+
+
+@pytest.mark.gpu
+def test_metrics_golden(golden_dir):
+    from lintransunet_amd import infer as P
+    G = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    for tag in ('a', 'b'):
+        p, t = torch.from_numpy(G[f'{tag}_predict']).to(DEV), torch.from_numpy(G[f'{tag}_target']).to(DEV)
+        vals = P.evaluate(p, t, threshold=0.5)
+        for name, ref in zip(P.METRIC_NAMES, G[f'{tag}_values']):
+            assert abs(vals[name].item() - ref) <= 1e-5 * max(1.0, abs(ref)), name
+
+
+@pytest.mark.gpu
+def test_infer_volume_with_model():
+    """the real eval-mode network as the predictor: output is a per-voxel average of one-hot votes"""
+    from lintransunet_amd import infer as P
+    from lintransunet_amd.model import get_model_dict
+    torch.manual_seed(3)
+    model = get_model_dict('MaskTransUnet')([8, 8, 8, 16, 32], [20, 12, 9, 10, 6], [False, True, True, True, True], 1, 2).to(DEV)
+    x = torch.randn(1, 1, 48, 32, 40, device=DEV)
+    out = P.infer_volume(model, x, depth_size=32, roi_xy=32, sw_batch_size=2, overlap=0.6)
+    assert out.shape == (1, 2, 48, 32, 40)
+    assert torch.allclose(out.sum(1), torch.ones_like(out[:, 0]), atol=1e-6)      # votes of a one-hot predictor sum to 1
+    vals = P.evaluate(out, (torch.rand(1, 1, 48, 32, 40, device=DEV) > 0.5))
+    assert all(torch.isfinite(v) for v in vals.values())
+    assert model.training                                                         # mode restored
