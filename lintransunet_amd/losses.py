@@ -32,7 +32,8 @@ class LevelCriterion(nn.Module):
     """Weighted sum of CE / balanced Dice / per-class Dice on one prediction, one kernel pass.
 
     spec: {'CrossEntroLoss': w, 'BalanceDiceLoss': w, 'DiceClassLoss': w (class 1), 'DiceClassLoss2': w (class 2),
-           'DiceClassLoss0c': w (class 0)}.  Returns (total, {name: value}) with values detached.
+           'DiceClassLoss0c': w (class 0)}.  Returns (total, {name: w * value}) with values detached: what the reference
+    scripts log (`criterions_w * l(...)`, utils_3D_multi_class.py:85; all weights are 1 in the single-class script).
     """
     _DICE = {'DiceClassLoss': 1, 'DiceClassLoss2': 2, 'DiceClassLoss0c': 0}
 
@@ -56,13 +57,14 @@ class LevelCriterion(nn.Module):
         total, values = ops.level_loss(p, lab, self.spec.get('CrossEntroLoss', 0.0) * sc,
                                        self.spec.get('BalanceDiceLoss', 0.0) * sc, wd)
         named = {}
-        for name in self.spec:
+        for name, w in self.spec.items():
             if name == 'CrossEntroLoss':
-                named[name] = values[1]
+                v = values[1]
             elif name == 'BalanceDiceLoss':
-                named[name] = values[2]
+                v = values[2]
             else:
-                named[name] = values[3 + self._DICE[name]]
+                v = values[3 + self._DICE[name]]
+            named[name] = v if w == 1.0 else v * w
         return total, named
 
 

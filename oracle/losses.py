@@ -69,6 +69,32 @@ BINARY = {
 }
 
 
+def _multi_ce(predict, onehot):
+    return weighted_ce(predict, None, onehot=onehot)
+
+
+def dice_class0_onehot(predict, onehot, eps=1e-9):
+    """multi_criterions.py:30-56 (DiceClassLoss0): Dice of the foreground union, 1 - class 0 on both sides."""
+    p = 1 - _rows(predict)[:, :, 0]
+    t = 1 - _rows(onehot)[:, :, 0]
+    inter = 2 * torch.sum(p * t, dim=-1) + eps
+    denom = torch.sum(p + t, dim=-1) + eps
+    return 1 - torch.mean(inter / denom)
+
+
+# loss/multi_criterions.py registry (704-): callables (predict [N,C,...], one-hot target [N,C,...])
+MULTI = {
+    'CrossEntroLoss': _multi_ce,
+    'DiceClassLoss': lambda p, t: dice_class_onehot(p, t, 1),
+    'DiceClassLoss2': lambda p, t: dice_class_onehot(p, t, 2),
+    'DiceClassLoss0': dice_class0_onehot,
+}
+
+
+def get_multi_criterions(names):
+    return {n: MULTI[n] for n in names}
+
+
 def get_criterions(names):
     """Same contract as loss/criterions.py:773-782: dict name -> callable(predict, target) -> 0-dim tensor."""
     return {n: BINARY[n] for n in names}

@@ -67,6 +67,22 @@ def total_loss(predict, masks, label, weights, criterions=None):
     return total, per_level
 
 
+def total_loss_multi(predict, masks, label, weights, num_classes=3,
+                     criterion_list=('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'), criterion_weight=(10, 1, 2)):
+    """Multi-class step (utils/utils_3D_multi_class.py:68-102, train3D_multi_class.py:85-90,139-155): the same criterion list
+    at every level, each loss scaled by `criterion_weight`, targets = one-hot of the (max-pooled) integer labels."""
+    crit = _losses.get_multi_criterions(list(criterion_list))
+    pyramid = label_pyramid(label, len(weights))
+    per_level = []
+    for lvl in range(len(weights)):
+        pred = predict if lvl == 0 else masks[-lvl]
+        tgt = pyramid[lvl].long().squeeze(1)                                   # [N, ...]
+        onehot = F.one_hot(tgt, num_classes).movedim(-1, 1).float()            # [N, C, ...]
+        per_level.append([w * fn(pred, onehot) for fn, w in zip(crit.values(), criterion_weight)])
+    total = sum(sum(vals) * w for vals, w in zip(per_level, weights))
+    return total, per_level
+
+
 def train_step(P, cfg: _net.NetConfig, x, label, weights, step_times=1):
     """Forward + loss + backward on a dict of leaf parameters; grads land in P[k].grad."""
     predict, masks = _net.forward(P, cfg, x, training=True)

@@ -329,12 +329,80 @@ def fx_model(tag, cfg, size, batch, wseed, full_arrays):
     np.savez_compressed(os.path.join(HERE, f'model_{tag}.npz'), **out)
 
 
+
+def fx_model_multi(tag, cfg, size, batch, wseed):
+    """multi-class step: reference model with dim_output = 3 + loss/multi_criterions.py, replay of
+    utils/utils_3D_multi_class.py:68-102 with the defaults of train3D_multi_class.py:85-90"""
+    shapes = O_net.param_shapes(cfg)
+    P = seedgen.seeded_params(shapes, wseed)
+    x = seedgen.seeded_volume((batch, 1) + size, wseed + 1)
+    label = seedgen.seeded_label((batch, 1) + size, wseed + 2, n_classes=3)
+    assert int(label.max()) == 2
+    weights = O_step.dynamic_weights(0)
+    names, cw, C = ['CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'], [10, 1, 2], cfg.dim_output
+    Model = get_model_dict('MaskTransUnet')
+    model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
+                  dim_input=cfg.dim_input, dim_output=C, kernel_size=3)
+    model.load_state_dict(P, strict=True)
+    kill_dropout(model)
+    model.train()
+    predict, masks = model(x)
+    crit = R_mloss.get_criterions(names)
+    Fn = torch.nn.functional
+
+    def onehot(lab):
+        n, c, h, w, d = lab.shape
+        t = Fn.one_hot(lab.flatten(2).transpose(1, 2).squeeze(2).long(), num_classes=C).transpose_(1, 2)
+        return torch.reshape(t, (n, C, h, w, d))
+
+    temp = Fn.max_pool3d(label.float(), kernel_size=(2, 2, 1), stride=(2, 2, 1))
+    loss_list = []
+    for lvl in range(len(weights)):
+        if lvl == 0:
+            vals = [w * l(predict, onehot(label)) for l, w in zip(crit.values(), cw)]
+        else:
+            vals = [w * l(masks[-lvl], onehot(temp)) for l, w in zip(crit.values(), cw)]
+            k = 2 if lvl % 2 == 0 else (2, 2, 1)
+            temp = Fn.max_pool3d(temp, kernel_size=k, stride=k)
+        loss_list.append(vals)
+    total = sum(sum(v) * w for v, w in zip(loss_list, weights))
+    total.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+
+    Pq = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    o_pred, o_masks = O_net.forward(Pq, cfg, x, True, [])
+    o_total, o_levels = O_step.total_loss_multi(o_pred, o_masks, label, weights, C, names, cw)
+    o_total.backward()
+    close(o_pred, predict, tag + '.out')
+    close(o_total, total, tag + '.total')
+    gerr = 0.0
+    for k, gr in grads.items():
+        if gr is not None:
+            gerr = max(gerr, close(Pq[k].grad, gr, f'{tag}.grad[{k}]', 2e-4))
+    # eval metric of the multi-class script (utils_3D_multi_class.py:201-204): Dice_1 + Dice_2 losses of the eval forward
+    d1 = R_mloss.DiceClassLoss()(predict, onehot(label))
+    d2 = R_mloss.DiceClassLoss2()(predict, onehot(label))
+    print(f'[{tag}] total {total.item():.6f}, grad err {gerr:.2e}, dice1 {d1.item():.6f}, dice2 {d2.item():.6f}')
+    keys = sorted(k for k, v in grads.items() if v is not None)
+    out = dict(total=np32(total), dice1=np32(d1), dice2=np32(d2), out=np32(predict),
+               level_losses=np.array([[v.item() for v in vals] for vals in loss_list], dtype=np.float64),
+               weights=np.array(weights, dtype=np.float64),
+               grad_keys=np.array(keys), grad_norms=np.array([grads[k].double().norm().item() for k in keys]))
+    for i, m in enumerate(masks):
+        out[f'mask{i}'] = np32(m)
+    np.savez_compressed(os.path.join(HERE, f'model_{tag}.npz'), **out)
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':      # only the inference-driver metrics fixture
         fx_metrics()
         return
+    small3 = O_net.NetConfig(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6], dim_output=3)
+    if len(sys.argv) > 1 and sys.argv[1] == 'multi':        # only the multi-class fixture
+        fx_model_multi('multi_small', small3, (32, 32, 32), 2, 400)
+        return
+    fx_model_multi('multi_small', small3, (32, 32, 32), 2, 400)
     fx_metrics()
     fx_linattn()
     fx_attn_layer()

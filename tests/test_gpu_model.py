@@ -207,3 +207,42 @@ def test_graphed_step_matches_eager():
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_model_multiclass_fp32(golden_dir):
+    """dim_output = 3, the multi-class step of utils/utils_3D_multi_class.py:68-102 (one-hot targets from the
+    max-pooled integer labels, criterion weights 10 / 1 / 2) against vectors from the reference's own model + multi_criterions."""
+    from lintransunet_amd import train
+    from lintransunet_amd import losses as L
+    G = np.load(os.path.join(golden_dir, 'model_multi_small.npz'))
+    cfg = O_net.NetConfig(dim_output=3, **SMALL)
+    model = build(cfg, 400)
+    x = seedgen.seeded_volume((2, 1, 32, 32, 32), 401).to(DEV)
+    label = seedgen.seeded_label((2, 1, 32, 32, 32), 402, n_classes=3).to(DEV)
+    predict, masks = model(x)
+    assert predict.shape == (2, 3, 32, 32, 32)
+    specs = train.level_specs(5, ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'), criterion_weight=[10, 1, 2])
+    totals, named = train.deep_supervision_loss(predict, masks, label, O_step.dynamic_weights(0), specs=specs)
+    torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    torch.cuda.synchronize()
+    assert rel_err(predict, G['out']) <= 1e-3
+    for i, m in enumerate(masks):
+        assert rel_err(m, G[f'mask{i}']) <= 1e-3, f'mask{i}'
+    total = sum(t.item() for t in totals)
+    assert abs(total - float(G['total'])) <= 1e-4 * max(1.0, abs(float(G['total'])))
+    lv = G['level_losses']
+    for lvl, vals in enumerate(named):
+        got = [vals[n].item() for n in ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2')]
+        assert np.allclose(got, lv[lvl], rtol=1e-4, atol=1e-5), (lvl, got, lv[lvl])
+    assert abs(L.DiceClassLoss()(predict.detach(), label).item() - float(G['dice1'])) <= 1e-4
+    assert abs(L.DiceClassLoss2()(predict.detach(), label).item() - float(G['dice2'])) <= 1e-4
+    norms = dict(zip(G['grad_keys'], G['grad_norms']))
+    sd = dict(model.named_parameters())
+    worst = 0.0
+    for k, n in norms.items():
+        got = sd[k].grad.double().norm().item()
+        if exact_zero_grad(k):
+            assert got <= 1e-2, k
+            continue
+        worst = max(worst, abs(got - n) / max(n, 1e-3))
+    assert worst <= 1e-2, worst

@@ -145,3 +145,18 @@ def test_label_pyramid_and_weights():
     w = O_step.dynamic_weights(0)
     assert np.allclose(w, [0.15, 0.25, 0.4, 0.5, 1.0])
     assert O_step.dynamic_weights(799)[0] == 2.0
+
+
+def test_multiclass_losses_golden(golden_dir):
+    """the oracle's multi-class deep-supervision loss reproduces the reference's level losses and total on the
+    reference's own predictions (tests/golden/model_multi_small.npz)"""
+    from oracle import step as O_step
+    from oracle import seedgen
+    G = np.load(os.path.join(golden_dir, 'model_multi_small.npz'))
+    predict = torch.from_numpy(G['out'])
+    masks = [torch.from_numpy(G[f'mask{i}']) for i in range(4)]
+    label = seedgen.seeded_label((2, 1, 32, 32, 32), 402, n_classes=3)
+    total, per_level = O_step.total_loss_multi(predict, masks, label, tuple(G['weights']))
+    assert abs(total.item() - float(G['total'])) <= 1e-5 * max(1.0, abs(float(G['total'])))
+    got = np.array([[v.item() for v in vals] for vals in per_level])
+    assert np.allclose(got, G['level_losses'], rtol=1e-5, atol=1e-6)
