@@ -241,6 +241,12 @@ int ltu_vote_finalize(const float* votes, const float* count, float* out, int B,
 int ltu_seg_metrics(const float* pred, const uint8_t* target, float* rows, float* values, int B, int C, int ci, int H, long long WD,
                     float threshold, ltu_stream_t s);
 
+/* ---- optimizer (train3D.py:193: torch.optim.AdamW(lr=1e-4)) -----------------------------------------------------
+ * One AdamW step on flat, 16-byte aligned fp32 buffers (a gradient bucket and the parameters / moments laid out the same way):
+ * decoupled weight decay, bias correction with `step` (>= 1), gradient multiplied by grad_scale on load. */
+int ltu_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, long long step, float grad_scale, ltu_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

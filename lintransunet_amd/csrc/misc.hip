@@ -1,4 +1,6 @@
 // Library version + the batched weight-operand preparation (one launch per step for the whole model).
+#include <math.h>
+
 #include "common.h"
 
 extern "C" int ltu_version(void) { return 2; }
@@ -76,5 +78,50 @@ extern "C" int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stre
   LTU_DISPATCH_T(out_dtype, {
     hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(256, n), dim3(256), 0, (hipStream_t)s, (const WPrep*)table);
   });
+  return ltu_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+// AdamW step of train3D.py:193 (torch.optim.AdamW, decoupled weight decay, bias-corrected moments) on flat fp32 buffers:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// `gscale` multiplies the gradient on load (1 / accumulation count or loss-scale inverse).  One launch per bucket.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+  const long long nv = n >> 2;
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = f4at(gv, k) * gscale;
+      const float mm = b1 * f4at(mv, k) + (1.f - b1) * gg;
+      const float v2 = b2 * f4at(vv, k) + (1.f - b2) * gg * gg;
+      f4at(mv, k) = mm; f4at(vv, k) = v2;
+      f4at(pv, k) = f4at(pv, k) * decay - step_size * mm / (sqrtf(v2) * inv_sqrt_bc2 + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {        // tail
+    const long long i = (nv << 2) + threadIdx.x;
+    const float gg = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float v2 = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = v2;
+    p[i] = p[i] * decay - step_size * mm / (sqrtf(v2) * inv_sqrt_bc2 + eps);
+  }
+}
+
+extern "C" int ltu_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, long long step, float grad_scale, ltu_stream_t s) {
+  if (n <= 0) return LTU_OK;
+  if (step < 1) return LTU_E_ARG;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return LTU_E_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  long long blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, grad_scale);
   return ltu_check_launch();
 }
