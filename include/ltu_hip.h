@@ -247,6 +247,15 @@ int ltu_seg_metrics(const float* pred, const uint8_t* target, float* rows, float
 int ltu_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, long long step, float grad_scale, ltu_stream_t s);
 
+/* ---- data side (dataset/CT_pancreas_ids.py:143-173): raw scan f32 [D][H][W] -> img f32 [H][W][D] = (clamp(raw, lo, hi) - mean) / std,
+ * raw label u8 [D][H][W] -> lab u8 [H][W][D] (either pair may be NULL); reference constants lo -91, hi 250, mean 86.9, std 39.4 */
+int ltu_ct_preprocess(const float* raw, float* img, const uint8_t* rawlab, uint8_t* lab, int D, int H, int W, float lo, float hi,
+                      float mean, float std, ltu_stream_t s);
+/* patches out [n][h][w][d] cut from vol [H][W][D] (elem_bytes 4 = f32, 1 = u8) at desc int32 [n][5] = (h0, w0, d0, flip_h, flip_w):
+ * the crop of monai RandCropByPosNegLabeld at host-chosen centres followed by RandFlipd over the first two spatial axes */
+int ltu_crop_flip(const void* vol, void* out, const int* desc, int n, int H, int W, int D, int h, int w, int d, int elem_bytes,
+                  ltu_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,8 @@ SIGNATURES = {
     'ltu_vote_accumulate': [P, P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_vote_finalize': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_seg_metrics': [P, P, P, P, I, I, I, I, L, F, P],
+    'ltu_ct_preprocess': [P, P, P, P, I, I, I, F, F, F, F, P],
+    'ltu_crop_flip': [P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_adamw': [P, P, P, P, L, F, F, F, F, F, L, F, P],
     'ltu_norm_ws_floats': [],
     'ltu_instnorm_stats': [P, P, P, I, L, I, I, P],
