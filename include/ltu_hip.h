@@ -241,6 +241,14 @@ int ltu_vote_finalize(const float* votes, const float* count, float* out, int B,
 int ltu_seg_metrics(const float* pred, const uint8_t* target, float* rows, float* values, int B, int C, int ci, int H, long long WD,
                     float threshold, ltu_stream_t s);
 
+/* post-processing of inference_multi_classes.py:104,148-151 = monai KeepLargestConnectedComponent(applied_labels = all foreground
+ * channels, independent=False, connectivity=3): pred f32 [C][H][W][D] (rounded one-hot) is modified in place.  Scratch:
+ * labels int32 [S], counts int32 [S+1] (zero), best u64 [1] (zero), changed int32 [1];  step 0 = initialise, step 1 = one label
+ * propagation sweep (sets *changed), repeat until it stays 0, step 2 = keep the largest 26-connected component of the foreground
+ * union, clear the rest, channel 0 = 1 - sum of the other channels. */
+int ltu_keep_largest_component(float* pred, int* labels, int* counts, unsigned long long* best, int* changed, int C, int H, int W,
+                               int D, int step, ltu_stream_t s);
+
 /* ---- optimizer (train3D.py:193: torch.optim.AdamW(lr=1e-4)) -----------------------------------------------------
  * One AdamW step on flat, 16-byte aligned fp32 buffers (a gradient bucket and the parameters / moments laid out the same way):
  * decoupled weight decay, bias correction with `step` (>= 1), gradient multiplied by grad_scale on load. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     'ltu_window_gather': [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_vote_accumulate': [P, P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_vote_finalize': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_keep_largest_component': [P, P, P, P, P, I, I, I, I, I, P],
     'ltu_seg_metrics': [P, P, P, P, I, I, I, I, L, F, P],
     'ltu_ct_preprocess': [P, P, P, P, I, I, I, F, F, F, F, P],
     'ltu_crop_flip': [P, P, P, I, I, I, I, I, I, I, I, P],

@@ -167,3 +167,87 @@ extern "C" int ltu_seg_metrics(const float* pred, const uint8_t* target, float* 
   hipLaunchKernelGGL(seg_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, rows, values, B, H);
   return ltu_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------ largest connected component
+// Post-processing of inference_multi_classes.py:104,148-151: monai KeepLargestConnectedComponent(applied_labels=[1, 2],
+// independent=False, connectivity=3) on the rounded one-hot prediction -- the union of the foreground channels is labelled
+// with 26-connectivity, every foreground voxel outside the largest component is cleared, channel 0 = 1 - sum of the others.
+// Labels are (smallest voxel index of the component) + 1, found by min-propagation over the 3x3x3 neighbourhood with
+// pointer jumping; ties between equally large components go to the smaller label = first in raster order, as
+// skimage.measure.label + bincount/argmax decide them.
+__global__ void cc_init_kernel(const float* __restrict__ pred, int* __restrict__ labels, int C, long long S) {
+  GRID_STRIDE(i, S) {
+    float fg = 0.f;
+    for (int c = 1; c < C; ++c) fg += pred[(long long)c * S + i];
+    labels[i] = fg > 0.f ? (int)i + 1 : 0;
+  }
+}
+__global__ void cc_sweep_kernel(int* __restrict__ labels, int* __restrict__ changed, int H, int W, int D) {
+  const long long S = (long long)H * W * D;
+  GRID_STRIDE(i, S) {
+    int l = labels[i];
+    if (l == 0) continue;
+    const int z = (int)(i % D), y = (int)((i / D) % W), x = (int)(i / ((long long)D * W));
+    int m = l;
+    for (int dx = -1; dx <= 1; ++dx)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dz = -1; dz <= 1; ++dz) {
+          const int xx = x + dx, yy = y + dy, zz = z + dz;
+          if ((unsigned)xx >= (unsigned)H || (unsigned)yy >= (unsigned)W || (unsigned)zz >= (unsigned)D) continue;
+          const int n = labels[((long long)xx * W + yy) * D + zz];
+          if (n != 0 && n < m) m = n;
+        }
+    const int j = labels[m - 1];                 // pointer jumping: the representative's own label (never larger)
+    if (j != 0 && j < m) m = j;
+    if (m < l) { atomicMin(labels + i, m); *changed = 1; }
+  }
+}
+__global__ void cc_count_kernel(const int* __restrict__ labels, int* __restrict__ counts, long long S) {
+  GRID_STRIDE(i, S) {
+    const int l = labels[i];
+    if (l != 0) atomicAdd(counts + l, 1);
+  }
+}
+__global__ void cc_best_kernel(const int* __restrict__ counts, unsigned long long* __restrict__ best, long long S) {
+  GRID_STRIDE(i, S) {
+    const int c = counts[i + 1];
+    if (c > 0) atomicMax(best, ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(i + 1)));
+  }
+}
+__global__ void cc_apply_kernel(float* __restrict__ pred, const int* __restrict__ labels, const unsigned long long* __restrict__ best,
+                                int C, long long S) {
+  const int keep = (int)(0xFFFFFFFFu - (unsigned)(*best & 0xFFFFFFFFull));
+  const bool any = (*best >> 32) != 0;
+  GRID_STRIDE(i, S) {
+    const int l = labels[i];
+    float rest = 0.f;
+    for (int c = 1; c < C; ++c) {
+      float v = pred[(long long)c * S + i];
+      if (l != 0 && any && l != keep) { v = 0.f; pred[(long long)c * S + i] = 0.f; }
+      rest += v;
+    }
+    pred[i] = 1.f - rest;
+  }
+}
+
+/* pred f32 [C][H][W][D] (rounded one-hot, modified in place); labels int32 [S], counts int32 [S+1] and best u64[1] scratch,
+ * changed int32[1].  step 0: initialise labels; step 1: one propagation sweep (sets *changed when a label moved);
+ * step 2: count, pick the largest component, clear the rest and rewrite channel 0. */
+extern "C" int ltu_keep_largest_component(float* pred, int* labels, int* counts, unsigned long long* best, int* changed, int C, int H,
+                                          int W, int D, int step, ltu_stream_t s) {
+  const long long S = (long long)H * W * D;
+  if (S <= 0 || S >= (1LL << 31) - 1 || C < 2) return LTU_E_SHAPE;
+  hipStream_t st = (hipStream_t)s;
+  if (step == 0) {
+    hipLaunchKernelGGL(cc_init_kernel, dim3(sgrid(S)), dim3(256), 0, st, pred, labels, C, S);
+  } else if (step == 1) {
+    hipLaunchKernelGGL(cc_sweep_kernel, dim3(sgrid(S)), dim3(256), 0, st, labels, changed, H, W, D);
+  } else if (step == 2) {
+    hipLaunchKernelGGL(cc_count_kernel, dim3(sgrid(S)), dim3(256), 0, st, labels, counts, S);
+    hipLaunchKernelGGL(cc_best_kernel, dim3(sgrid(S)), dim3(256), 0, st, counts, best, S);
+    hipLaunchKernelGGL(cc_apply_kernel, dim3(sgrid(S)), dim3(256), 0, st, pred, labels, best, C, S);
+  } else {
+    return LTU_E_ARG;
+  }
+  return ltu_check_launch();
+}

@@ -105,6 +105,33 @@ def evaluate(predict, masks, threshold=0.5, class_index=1):
     return {name: values[i] for i, name in enumerate(METRIC_NAMES)}
 
 
+def keep_largest_component(predict, sweeps_per_check=8):
+    """inference_multi_classes.py:146-151 on predict [B, C, H, W, D] (the blended votes): round, keep the largest 26-connected
+    component of the foreground union (monai KeepLargestConnectedComponent(applied_labels=[1, 2], independent=False,
+    connectivity=3)), channel 0 = 1 - the rest.  Returns a new tensor."""
+    if not predict.is_cuda:
+        raise _lib.LtuError('keep_largest_component runs on the GPU only (no CPU fallback)')
+    B, C, H, W, D = predict.shape
+    S = H * W * D
+    out = torch.round(predict.to(torch.float32)).contiguous()
+    dev = out.device
+    labels = torch.empty(S, device=dev, dtype=torch.int32)
+    for b in range(B):
+        counts = torch.zeros(S + 1, device=dev, dtype=torch.int32)
+        best = torch.zeros(1, device=dev, dtype=torch.int64)
+        changed = torch.zeros(1, device=dev, dtype=torch.int32)
+        args = (_p(out[b]), _p(labels), _p(counts), _p(best), _p(changed), C, H, W, D)
+        _lib.call('ltu_keep_largest_component', *args, 0, _s())
+        while True:
+            changed.zero_()
+            for _ in range(sweeps_per_check):
+                _lib.call('ltu_keep_largest_component', *args, 1, _s())
+            if changed.item() == 0:          # host check: an evaluation-time post-processing step, not on the training path
+                break
+        _lib.call('ltu_keep_largest_component', *args, 2, _s())
+    return out
+
+
 def infer_volume(model, images, depth_size=32, roi_xy=512, sw_batch_size=4, overlap=0.6):
     """one patient of inference_embed_attn.py:main: eval-mode model, (roi_xy, roi_xy, depth_size) windows, overlap 0.6"""
     was_training = model.training

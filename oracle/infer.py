@@ -132,3 +132,23 @@ def localization_loss(predict, target, class_index=1, eps=1e-6, mask_threshold=1
         term = 8 * torch.mean(torch.abs(cp - ct))
         total = term if total is None else total + term
     return total / n_dim
+
+
+def keep_largest_component(predict):
+    """inference_multi_classes.py:146-151: round, monai 0.7.0 KeepLargestConnectedComponent(applied_labels=[1, 2],
+    independent=False, connectivity=3) (= skimage.measure.label(connectivity=3) on the union of the foreground channels, largest
+    label by bincount/argmax, everything else cleared in those channels), then channel 0 = 1 - the rest.  scipy's labelling with a
+    full 3x3x3 structure numbers components in the same raster order as skimage.  predict [B, C, H, W, D] torch tensor."""
+    import numpy as np
+    from scipy import ndimage
+    out = torch.round(predict.float()).clone()
+    for b in range(out.shape[0]):
+        fg = (out[b, 1:].sum(0) > 0).numpy()
+        lab, n = ndimage.label(fg, structure=np.ones((3, 3, 3), dtype=bool))
+        if n > 0:
+            keep = np.argmax(np.bincount(lab.ravel())[1:]) + 1
+            drop = torch.from_numpy(fg & (lab != keep))
+            for c in range(1, out.shape[1]):
+                out[b, c][drop] = 0
+        out[b, 0] = 1 - out[b, 1:].sum(0)
+    return out

@@ -103,3 +103,35 @@ def test_infer_volume_with_model():
     vals = P.evaluate(out, (torch.rand(1, 1, 48, 32, 40, device=DEV) > 0.5))
     assert all(torch.isfinite(v) for v in vals.values())
     assert model.training                                                         # mode restored
+
+
+def _blobs(seed, shape=(2, 3, 20, 18, 14)):
+    g = torch.Generator().manual_seed(seed)
+    B, C, H, W, D = shape
+    p = torch.zeros(shape)
+    for b in range(B):
+        for k in range(5):                     # a few boxes of either foreground class, some touching only diagonally
+            h0, w0, d0 = [int(torch.randint(0, n - 5, (1,), generator=g)) for n in (H, W, D)]
+            c = 1 + k % 2
+            p[b, c, h0:h0 + 2 + k, w0:w0 + 3, d0:d0 + 2 + k % 3] = 1.0
+        p[b, 2] *= (1 - p[b, 1])
+    p[:, 0] = 1 - p[:, 1] - p[:, 2]
+    return p * 0.9 + 0.04                      # blended votes: rounding recovers the one-hot
+
+
+def test_oracle_keep_largest_component():
+    p = _blobs(1)
+    out = O.keep_largest_component(p)
+    assert torch.all(out.sum(1) == 1)
+    fg_in, fg_out = torch.round(p)[:, 1:].sum(1) > 0, out[:, 1:].sum(1) > 0
+    assert torch.all(fg_in | ~fg_out) and 0 < fg_out.sum() < fg_in.sum()
+
+
+@pytest.mark.gpu
+def test_keep_largest_component_matches_oracle():
+    from lintransunet_amd import infer as P
+    for seed in (1, 2, 3):
+        p = _blobs(seed)
+        assert torch.equal(P.keep_largest_component(p.to(DEV)).cpu(), O.keep_largest_component(p))
+    empty = torch.zeros(1, 3, 6, 5, 4); empty[:, 0] = 1
+    assert torch.equal(P.keep_largest_component(empty.to(DEV)).cpu(), empty)
