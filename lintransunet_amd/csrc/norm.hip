@@ -248,66 +248,81 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
 
 // dz = rstd*(g*gamma - mean_d(g*gamma) - xhat*mean_d(g*gamma*xhat));  dr = dz*dropmask;
 // dgamma += sum_rows g*xhat, dbeta += sum_rows g   (block partials through LDS, then fp32 atomics)
-template <typename T, int G>
+// V = 4-element vectors per lane (a lane owns 4V consecutive elements of the row): V = 2 halves the cross-lane reduction
+// steps and the instruction count per byte for d >= 128.
+template <typename T, int V>
+__device__ __forceinline__ void ln_load(const T* p, float (&o)[4 * V]) {
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const float4 t = Vec4<T>::load(p + 4 * v);
+    o[4 * v] = t.x; o[4 * v + 1] = t.y; o[4 * v + 2] = t.z; o[4 * v + 3] = t.w;
+  }
+}
+template <typename T, int G, int V>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ z, const float* __restrict__ stat,
                                      const float* __restrict__ gamma, T* __restrict__ dz, T* __restrict__ dr,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, long long M,
                                      int rows_per_block, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];   // [rowgroups][d][2]
-  const int d = G * 4;
+  constexpr int E = 4 * V, d = G * E;
   const int gl = threadIdx.x % G, rg = threadIdx.x / G, nrg = blockDim.x / G;
   const DropCfg dc = make_drop(p, seed, step);
-  const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
-  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  float gm[E], ag[E], ab[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) { gm[k] = gamma[gl * E + k]; ag[k] = 0.f; ab[k] = 0.f; }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
   // software pipeline: the next row's operands are in flight while this row goes through its two cross-lane reductions
-  float4 gn = make_float4(0.f, 0.f, 0.f, 0.f), zn = gn;
+  float gn[E], zn[E];
   float2 stn = make_float2(0.f, 0.f);
-  {
-    const long long row = r0 + rg;
+  auto fetch = [&](long long row) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) { gn[k] = 0.f; zn[k] = 0.f; }
     if (row < r1) {
-      gn = Vec4<T>::load(dy + row * d + gl * 4);
-      if (dy2 != nullptr) { const float4 t2 = Vec4<T>::load(dy2 + row * d + gl * 4); gn.x += t2.x; gn.y += t2.y; gn.z += t2.z; gn.w += t2.w; }
-      zn = Vec4<T>::load(z + row * d + gl * 4);
+      ln_load<T, V>(dy + row * d + gl * E, gn);
+      if (dy2 != nullptr) {
+        float t2[E];
+        ln_load<T, V>(dy2 + row * d + gl * E, t2);
+#pragma unroll
+        for (int k = 0; k < E; ++k) gn[k] += t2[k];
+      }
+      ln_load<T, V>(z + row * d + gl * E, zn);
       stn = *reinterpret_cast<const float2*>(stat + row * 2);
     }
-  }
+  };
+  fetch(r0 + rg);
   for (long long rb = r0; rb < r1; rb += nrg) {
     const long long row = rb + rg;
     const bool ok = row < r1;
-    const float4 g = gn, zv = zn;
+    float g[E], h[E];
     const float mean = stn.x, rstd = ok ? stn.y : 0.f;
-    {
-      const long long nrow = row + nrg;
-      gn = make_float4(0.f, 0.f, 0.f, 0.f); zn = gn;
-      if (nrow < r1) {
-        gn = Vec4<T>::load(dy + nrow * d + gl * 4);
-        if (dy2 != nullptr) { const float4 t2 = Vec4<T>::load(dy2 + nrow * d + gl * 4); gn.x += t2.x; gn.y += t2.y; gn.z += t2.z; gn.w += t2.w; }
-        zn = Vec4<T>::load(z + nrow * d + gl * 4);
-        stn = *reinterpret_cast<const float2*>(stat + nrow * 2);
+#pragma unroll
+    for (int k = 0; k < E; ++k) { g[k] = gn[k]; h[k] = ok ? (zn[k] - mean) * rstd : 0.f; }
+    fetch(row + nrg);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if (ok) { ab[k] += g[k]; ag[k] += g[k] * h[k]; }
+      g[k] *= gm[k];                       // g * gamma from here on
+      s1 += g[k]; s2 += g[k] * h[k];
+    }
+    const float m1 = group_sum<G>(s1) / (float)d;
+    const float m2 = group_sum<G>(s2) / (float)d;
+    if (ok) {
+      const long long e = row * d + gl * E;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float4 o = make_float4(rstd * (g[4 * v] - m1 - h[4 * v] * m2), rstd * (g[4 * v + 1] - m1 - h[4 * v + 1] * m2),
+                                     rstd * (g[4 * v + 2] - m1 - h[4 * v + 2] * m2), rstd * (g[4 * v + 3] - m1 - h[4 * v + 3] * m2));
+        Vec4<T>::store(dz + e + 4 * v, o);
+        if (dr != dz) Vec4<T>::store(dr + e + 4 * v, drop4(dc, (uint64_t)((e + 4 * v) >> 2), o));
       }
     }
-    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) {
-      h = make_float4((zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd);
-      ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
-      ag.x += g.x * h.x; ag.y += g.y * h.y; ag.z += g.z * h.z; ag.w += g.w * h.w;
-    }
-    const float4 gg = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
-    const float m1 = group_sum<G>(gg.x + gg.y + gg.z + gg.w) / (float)d;
-    const float m2 = group_sum<G>(gg.x * h.x + gg.y * h.y + gg.z * h.z + gg.w * h.w) / (float)d;
-    if (ok) {
-      const long long e = row * d + gl * 4;
-      float4 o = make_float4(rstd * (gg.x - m1 - h.x * m2), rstd * (gg.y - m1 - h.y * m2), rstd * (gg.z - m1 - h.z * m2),
-                             rstd * (gg.w - m1 - h.w * m2));
-      Vec4<T>::store(dz + e, o);
-      if (dr != dz) Vec4<T>::store(dr + e, drop4(dc, (uint64_t)(e >> 2), o));
-    }
   }
-  float* dst = red + ((long long)rg * d + gl * 4) * 2;
-  dst[0] = ag.x; dst[1] = ab.x; dst[2] = ag.y; dst[3] = ab.y; dst[4] = ag.z; dst[5] = ab.z; dst[6] = ag.w; dst[7] = ab.w;
+  float* dst = red + ((long long)rg * d + gl * E) * 2;
+#pragma unroll
+  for (int k = 0; k < E; ++k) { dst[2 * k] = ag[k]; dst[2 * k + 1] = ab[k]; }
   __syncthreads();
   for (int i = threadIdx.x; i < d * 2; i += blockDim.x) {
     float acc = 0.f;
@@ -392,6 +407,16 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
     else return LTU_E_SHAPE;                                 \
   } while (0)
 
+// backward: 8 elements per lane from d = 128 up
+#define LN_DISPATCH_GV(d, ...)                                                  \
+  do {                                                                          \
+    if ((d) == 32) { constexpr int G = 8, V = 1; __VA_ARGS__ }                  \
+    else if ((d) == 64) { constexpr int G = 16, V = 1; __VA_ARGS__ }            \
+    else if ((d) == 128) { constexpr int G = 16, V = 2; __VA_ARGS__ }           \
+    else if ((d) == 256) { constexpr int G = 32, V = 2; __VA_ARGS__ }           \
+    else return LTU_E_SHAPE;                                                    \
+  } while (0)
+
 extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat,
                                  long long M, int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   LTU_DISPATCH_T(dtype, {
@@ -409,7 +434,7 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z,
                                  uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (defer != nullptr) defer->part = nullptr;
   LTU_DISPATCH_T(dtype, {
-    LN_DISPATCH_G(d, {
+    LN_DISPATCH_GV(d, {
       const int nrg = 256 / G;
       long long rows = (M + 1023) / 1024;
       if (rows < nrg) rows = nrg;
@@ -417,7 +442,7 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z,
       const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
       const int nblk = cdiv(M, rows);
       if ((long long)nblk * d * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy, (const T*)dy2,
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, G, V>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy, (const T*)dy2,
                          (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, ws, M, (int)rows, p, seed, step);
       if (ws != nullptr && defer != nullptr) {
         defer->part = ws; defer->nsplit = nblk; defer->n = d * 2; defer->k = 1; defer->nseg = 1; defer->mode = 1;
