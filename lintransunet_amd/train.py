@@ -159,6 +159,7 @@ class GradReducer:
                 f.div_(self.world)
 
     def finish(self):
+        ops.flush_deferred()                # safety net for callers that ran backward without train_step
         self.active = False
         if self.world > 1:
             launched = {bi for bi, _ in self.handles}
