@@ -93,6 +93,16 @@ def _reducer_worker(rank, world, port, out):
         loss = ((net[:5](x[shard]) - y[shard]) ** 2).mean()      # per-sample loss, mean over the shard
         loss.backward()
         red.finish()
+    # the path bench.py takes at N > 1: backward without hooks (as inside a replayed graph), then reduce_all()
+    red.zero_grad()
+    ((net[:5](x[shard]) - y[shard]) ** 2).mean().backward()
+    red.reduce_all()
+    after_replay = [p.grad.clone() for p in list(net.parameters())[:6]]
+    red.zero_grad()
+    red.prepare()
+    ((net[:5](x[shard]) - y[shard]) ** 2).mean().backward()
+    red.finish()
+    assert all(torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(after_replay, list(net.parameters())[:6]))
     if rank == 0:
         ref = torch.nn.Sequential(*[m for m in list(net.children())[:5]])
         grads = [p.grad.clone() for p in list(net.parameters())[:6]]
