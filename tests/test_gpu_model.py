@@ -246,3 +246,51 @@ def test_model_multiclass_fp32(golden_dir):
             continue
         worst = max(worst, abs(got - n) / max(n, 1e-3))
     assert worst <= 1e-2, worst
+
+
+def test_full_size_properties():
+    """BASELINE size (128^3, 2 patches, the reference's channel / ROI configuration, bf16 storage) is out of the oracle's reach, so
+    check what must hold at any size: class probabilities sum to 1 everywhere, every op is per-sample (swapping the two patches
+    swaps outputs, masks and ROI boxes), and the gradient is linear in the loss scale."""
+    from lintransunet_amd import train
+    from lintransunet_amd.model import get_model_dict
+    torch.manual_seed(7)
+    model = get_model_dict('MaskTransUnet')([16, 32, 64, 128, 256], [100, 65, 40, 25, 10], [False, True, True, True, True], 1, 2,
+                                            dropout=0.0, act_dtype=torch.bfloat16).to(DEV).train()
+    x = seedgen.seeded_volume((2, 1, 128, 128, 128), 31).to(DEV)
+    label = seedgen.seeded_label((2, 1, 128, 128, 128), 32).to(DEV)
+    weights = O_step.dynamic_weights(0)
+
+    def step(xx, ll, scale):
+        for p in model.parameters():
+            p.grad = None
+        predict, masks = model(xx)
+        boxes = [b.clone() for b in model.last_boxes]
+        totals, _ = train.deep_supervision_loss(predict, masks, ll, weights, scale=scale)
+        torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+        return predict.detach(), [m.detach() for m in masks], boxes, sum(t.item() for t in totals)
+
+    p0, m0, b0, l0 = step(x, label, 1.0)
+    g0 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert p0.shape == (2, 2, 128, 128, 128) and torch.isfinite(p0).all()
+    assert (p0.sum(1) - 1).abs().max().item() <= 1e-5
+    for m in m0:
+        assert (m.sum(1) - 1).abs().max().item() <= 1e-5
+    # per-sample structure
+    p1, m1, b1, l1 = step(x.flip(0), label.flip(0), 1.0)
+    assert (p1.flip(0) - p0).abs().max().item() <= 2e-3
+    for a, b in zip(m1, m0):
+        assert (a.flip(0) - b).abs().max().item() <= 2e-3
+    for a, b in zip(b1, b0):
+        assert torch.equal(a.flip(0), b)
+    assert abs(l1 - l0) <= 1e-3 * abs(l0)
+    # linearity in the loss scale
+    _, _, _, l2 = step(x, label, 0.5)
+    assert abs(l2 - 0.5 * l0) <= 1e-3 * abs(l0)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if p.grad is None or exact_zero_grad(k):
+            continue
+        n0 = g0[k].double().norm().item()
+        worst = max(worst, (p.grad.double() - 0.5 * g0[k].double()).norm().item() / max(n0, 1e-9))
+    assert worst <= 2e-2, worst
