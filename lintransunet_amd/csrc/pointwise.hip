@@ -495,13 +495,9 @@ extern "C" int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, co
 // x [B,H,W,D,C]; the reference runs the conv on a [B,C,D,H,W] view, so weight w[c][kd][kh][kw] multiplies the
 // neighbour at offset (kh-1, kw-1, kd-1) of the (H,W,D) lattice.  Channel dropout (nn.Dropout3d) draws one
 // keep/drop per (sample, channel).
-__device__ __forceinline__ void dw_tap(int t, int& dh, int& dw, int& dd) {
-  dd = t / 9 - 1;
-  dh = (t / 3) % 3 - 1;
-  dw = t % 3 - 1;
-}
+// tap t = kd*9 + kh*3 + kw of the reference weight reads the neighbour (kh-1, kw-1, kd-1).
 
-// LDS-halo versions.  A workgroup walks 4x4x8 bricks of output voxels for one 128-byte channel chunk (64 bf16 / 32 fp32
+// A workgroup walks 4x4x8 bricks of output voxels for one 128-byte channel chunk (64 bf16 / 32 fp32
 // channels): the 6x6x10 halo brick is staged in LDS once and the 27 taps are LDS reads at constant offsets (27x fewer
 // vector-memory requests than gathering from global, no per-tap address arithmetic).  A thread owns one channel quad and
 // every NV-th voxel of the brick; its 27 x 4 weights (or weight-gradient accumulators) stay in registers across bricks.
