@@ -132,12 +132,47 @@ def keep_largest_component(predict, sweeps_per_check=8):
     return out
 
 
-def infer_volume(model, images, depth_size=32, roi_xy=512, sw_batch_size=4, overlap=0.6):
-    """one patient of inference_embed_attn.py:main: eval-mode model, (roi_xy, roi_xy, depth_size) windows, overlap 0.6"""
+class GraphedPredictor:
+    """The eval-mode forward for a fixed window batch captured once into a HIP graph and replayed per window batch: an eager
+    forward is ~500 launches of ~35 us host time each, several times what the kernels need.  A short last batch is padded with
+    copies of its first window (their outputs are dropped)."""
+
+    def __init__(self, model, batch, roi, device):
+        self.model, self.n = model, batch
+        self.x = torch.zeros((batch, 1) + tuple(roi), device=device, dtype=torch.float32)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                model(self.x)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'), torch.no_grad():
+            self.y = model(self.x)
+
+    def __call__(self, win):
+        n = win.shape[0]
+        self.x[:n].copy_(win)
+        if n < self.n:
+            self.x[n:].copy_(win[:1].expand(self.n - n, *win.shape[1:]))
+        self.graph.replay()
+        return self.y[:n]
+
+
+def infer_volume(model, images, depth_size=32, roi_xy=512, sw_batch_size=4, overlap=0.6, graph=False):
+    """one patient of inference_embed_attn.py:main: eval-mode model, (roi_xy, roi_xy, depth_size) windows, overlap 0.6.
+    graph=True (or a GraphedPredictor built earlier) replays the forward from a captured HIP graph."""
     was_training = model.training
     model.eval()
     try:
         with torch.no_grad():
-            return sliding_window_inference(images, (roi_xy, roi_xy, depth_size), sw_batch_size, model, overlap=overlap)
+            predictor = model
+            if isinstance(graph, GraphedPredictor):
+                predictor = graph
+            elif graph:
+                roi = tuple(r if r and r > 0 else i for r, i in zip((roi_xy, roi_xy, depth_size), images.shape[2:]))
+                predictor = GraphedPredictor(model, sw_batch_size, roi, images.device)
+            return sliding_window_inference(images, (roi_xy, roi_xy, depth_size), sw_batch_size, predictor, overlap=overlap)
     finally:
         model.train(was_training)

@@ -103,6 +103,8 @@ def test_infer_volume_with_model():
     vals = P.evaluate(out, (torch.rand(1, 1, 48, 32, 40, device=DEV) > 0.5))
     assert all(torch.isfinite(v) for v in vals.values())
     assert model.training                                                         # mode restored
+    out_g = P.infer_volume(model, x, depth_size=32, roi_xy=32, sw_batch_size=2, overlap=0.6, graph=True)
+    assert torch.equal(out_g, out)                                                # graph replay of the same kernels
 
 
 def _blobs(seed, shape=(2, 3, 20, 18, 14)):

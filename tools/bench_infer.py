@@ -14,14 +14,16 @@ x = torch.randn(1, 1, 512, 512, D, device='cuda')
 mask = (torch.rand(1, 1, 512, 512, D, device='cuda') > 0.97)
 img = (512, 512, D)
 nwin = len(infer.patch_starts(img, (512, 512, 32), infer.scan_interval(img, (512, 512, 32), 0.6)))
-out = infer.infer_volume(model, x)           # warm-up
+use_graph = os.environ.get('INFER_GRAPH', '1') != '0'
+pred = infer.GraphedPredictor(model.eval(), 4, (512, 512, 32), x.device) if use_graph else False
+out = infer.infer_volume(model, x, graph=pred)           # warm-up
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 reps = 3
 for _ in range(reps):
-    out = infer.infer_volume(model, x)
+    out = infer.infer_volume(model, x, graph=pred)
     vals = infer.evaluate(out, mask)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-print(f'512x512x{D} scan, {nwin} windows of 512x512x32, {act}: {dt * 1e3:.1f} ms per scan = {nwin / dt:.1f} windows/s; '
+print(f'512x512x{D} scan, {nwin} windows of 512x512x32, {act}, {"graph replay" if use_graph else "eager"}: {dt * 1e3:.1f} ms per scan = {nwin / dt:.1f} windows/s; '
       + ', '.join(f'{k} {v.item():.4f}' for k, v in vals.items()), flush=True)
