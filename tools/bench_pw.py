@@ -20,7 +20,7 @@ def ln(M, d):
     b = lambda: _lib.call('ltu_layernorm_bwd', _p(g), 0, _p(r), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(WS), 0, M, d, 0.3, 1, 0, 1, _s())
     tf, tb = timed(f), timed(b)
     mb = M * d * 2 / 1e6
-    print(f'LN   M={M:7d} d={d:4d}: fwd {tf:6.1f} us ({4 * mb / tf / 1e0:.0f} GB/s)  bwd {tb:6.1f} us ({4 * mb / tb:.0f} GB/s)', flush=True)
+    print(f'LN   M={M:7d} d={d:4d}: fwd {tf:6.1f} us ({4 * mb / tf:.1f} TB/s)  bwd {tb:6.1f} us ({4 * mb / tb:.1f} TB/s)', flush=True)
 
 def gelu(n):
     u, h, dh, du = bf(n), bf(n), bf(n), bf(n)
@@ -28,7 +28,7 @@ def gelu(n):
     b = lambda: _lib.call('ltu_gelu_dropout_bwd', _p(dh), _p(u), _p(du), n, 0.3, 1, 0, 1, _s())
     tf, tb = timed(f), timed(b)
     mb = n * 2 / 1e6
-    print(f'GELU n={n:10d}: fwd {tf:6.1f} us ({2 * mb / tf:.0f} GB/s)  bwd {tb:6.1f} us ({3 * mb / tb:.0f} GB/s)', flush=True)
+    print(f'GELU n={n:10d}: fwd {tf:6.1f} us ({2 * mb / tf:.1f} TB/s)  bwd {tb:6.1f} us ({3 * mb / tb:.1f} TB/s)', flush=True)
 
 def inorm(B, S, C):
     x, y, dy, dx = bf(B, S, C), bf(B, S, C), bf(B, S, C), bf(B, S, C)
@@ -38,8 +38,8 @@ def inorm(B, S, C):
     bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
     t1, t2, t3 = timed(st), timed(ap), timed(bw)
     mb = B * S * C * 2 / 1e6
-    print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.0f} GB/s)  apply {t2:6.1f} us ({2 * mb / t2:.0f} GB/s)  '
-          f'bwd(stats+apply) {t3:6.1f} us ({5 * mb / t3:.0f} GB/s)', flush=True)
+    print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.1f} TB/s)  apply {t2:6.1f} us ({2 * mb / t2:.1f} TB/s)  '
+          f'bwd(stats+apply) {t3:6.1f} us ({5 * mb / t3:.1f} TB/s)', flush=True)
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
