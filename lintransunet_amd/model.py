@@ -294,6 +294,9 @@ class MaskTransUnet(nn.Module):
         if H % 2 or W % 2:
             raise ValueError('H and W must be even')
         enc, dec = self.encode, self.decode
+        if not torch.is_grad_enabled():
+            ops.begin_step(x.device)         # inference: nothing of an earlier forward is needed any more -> recycle (and re-zero) the
+                                             # scratch arena; with autograd on, train.train_step does this once per step
         store = self._weights(x.device)
         store.refresh()                      # one launch: every cast / transposed / repacked weight of this step
 

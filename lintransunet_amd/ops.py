@@ -106,7 +106,8 @@ _ARENA = _Arena()
 
 
 def begin_step(device):
-    """Called by the model at the start of a training forward: recycles and clears the scratch arena."""
+    """Recycles and clears the scratch arena.  Called once per training step (train.train_step, inside the captured graph too)
+    and at the start of every no-grad forward; never between a forward and its backward (saved statistics live in the arena)."""
     _ARENA.begin_step(device)
 
 
