@@ -182,8 +182,8 @@ int ltu_gate_fwd(const void* u1, const void* u2, const float* sums1, const float
 /* -> dskip (direct path), du1, du2, dpsi_w[C] +=, dpsi_b[1] +=; ds_ws f32 [B*S], bs1/bs2 [B][C][2] zero-filled scratch */
 int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* sums1, const float* sums2,
                  const float* psi_w, const void* skip, const float* a_in, void* dskip, float* ds_ws, float* dpsi_w,
-                 float* dpsi_b, float* bs1, float* bs2, void* du1, void* du2, int B, long long S, int C, int dtype,
-                 ltu_stream_t s);
+                 float* dpsi_b, float* bs1, float* bs2, float* ws, void* du1, void* du2, int B, long long S, int C,
+                 int dtype, ltu_stream_t s);   /* ws: ltu_norm_ws_floats() floats (two-stage reduction) or NULL (atomics) */
 
 /* ---- positional depthwise conv: model/trans_block.py:86-96 on the grid of Unet_3Dblock.py:267-270 ----
  * y = chan_dropout(x + dwconv3x3x3(x) + bias), x [B,H,W,D,C]; w [C,1,3,3,3] with the reference's kernel

@@ -65,7 +65,7 @@ SIGNATURES = {
     'ltu_final_softmax_bwd': [P, P, P, I, I, I, I, I, I, P],
     'ltu_onehot_argmax': [P, P, L, I, P],
     'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
-    'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, P, I, P],
     'ltu_dwconv_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
     'ltu_roi_plan_size': [I, I, I, I, P, P],

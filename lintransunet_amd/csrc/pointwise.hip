@@ -337,8 +337,8 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dout, const T* __re
                                        const float* __restrict__ sums1, const float* __restrict__ sums2,
                                        const float* __restrict__ psi_w, const T* __restrict__ skip, const float* __restrict__ a_in,
                                        T* __restrict__ dskip, float* __restrict__ ds_out, float* __restrict__ dpsi_w,
-                                       float* __restrict__ dpsi_b, float* __restrict__ bs1, float* __restrict__ bs2, int B,
-                                       long long S, int rows_per_block) {
+                                       float* __restrict__ dpsi_b, float* __restrict__ bs1, float* __restrict__ bs2,
+                                       float* __restrict__ ws, int B, long long S, int rows_per_block) {
   extern __shared__ float red[];   // [rowgroups][C][5]
   const int C = G * 4;
   const int gl = threadIdx.x % G, rg = threadIdx.x / G, nrg = blockDim.x / G;
@@ -401,6 +401,10 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dout, const T* __re
   for (int i = threadIdx.x; i < C * 5; i += blockDim.x) {
     float v = 0.f;
     for (int q = 0; q < nrg; ++q) v += red[(long long)q * C * 5 + i];
+    if (ws != nullptr) {      // two-stage: plain store of the block's partial, folded by gate_fold_kernel
+      ws[((long long)b * gridDim.x + blockIdx.x) * (C * 5) + i] = v;
+      continue;
+    }
     const int c = i / 5, which = i % 5;
     if (which == 0) atomicAdd(dpsi_w + c, v);
     else if (which == 1) { atomicAdd(bs1 + ((long long)b * C + c) * 2, v); atomicAdd(bs2 + ((long long)b * C + c) * 2, v); }
@@ -408,6 +412,36 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dout, const T* __re
     else if (which == 3) atomicAdd(bs2 + ((long long)b * C + c) * 2 + 1, v);
     else if (c == 0) atomicAdd(dpsi_b, v);
   }
+}
+
+// folds the per-block partials ws[b][part][C*5] of gate_bwd_reduce_kernel (a few thousand blocks adding to the same handful of
+// addresses with atomics is a serial chain at the memory side).  grid (cdiv(C*5,32), B), 1024 threads.
+__global__ void __launch_bounds__(1024) gate_fold_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ dpsi_w,
+                                                         float* __restrict__ dpsi_b, float* __restrict__ bs1,
+                                                         float* __restrict__ bs2) {
+  __shared__ float red[32][33];
+  const int n = C * 5;
+  const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + el, b = blockIdx.y;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    const float* p = ws + (long long)b * nparts * n + i;
+    int z = zq;
+    for (; z + 32 < nparts; z += 64) { a0 += p[(long long)z * n]; a1 += p[(long long)(z + 32) * n]; }
+    for (; z < nparts; z += 32) a0 += p[(long long)z * n];
+  }
+  red[zq][el] = a0 + a1;
+  __syncthreads();
+  if (zq != 0 || i >= n) return;
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) v += red[q][el];
+  const int c = i / 5, which = i % 5;
+  if (which == 0) atomicAdd(dpsi_w + c, v);
+  else if (which == 1) { bs1[((long long)b * C + c) * 2] += v; bs2[((long long)b * C + c) * 2] += v; }
+  else if (which == 2) bs1[((long long)b * C + c) * 2 + 1] += v;
+  else if (which == 3) bs2[((long long)b * C + c) * 2 + 1] += v;
+  else if (c == 0) atomicAdd(dpsi_b, v);
 }
 
 // backward stage 2: du1 = rstd1 (dr - bs1[0]/S - h1 bs1[1]/S), du2 likewise
@@ -469,12 +503,15 @@ extern "C" int ltu_gate_fwd(const void* u1, const void* u2, const float* sums1, 
 
 extern "C" int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* sums1, const float* sums2,
                             const float* psi_w, const void* skip, const float* a_in, void* dskip, float* ds_ws, float* dpsi_w,
-                            float* dpsi_b, float* bs1, float* bs2, void* du1, void* du2, int B, long long S, int C, int dtype,
-                            ltu_stream_t s) {
+                            float* dpsi_b, float* bs1, float* bs2, float* ws, void* du1, void* du2, int B, long long S, int C,
+                            int dtype, ltu_stream_t s) {
+  // ws: ltu_norm_ws_floats() floats of workspace for the two-stage reduction, or NULL (atomics)
   LTU_DISPATCH_T(dtype, {
     GATE_DISPATCH_G(C, {
       const int nrg = 256 / G;
-      long long want = 2048 / (B > 0 ? B : 1);
+      long long cap = (1 << 20) / (C * 5);
+      if (cap > 2048) cap = 2048;
+      long long want = cap / (B > 0 ? B : 1);
       if (want < 1) want = 1;
       long long rows = (S + want - 1) / want;
       if (rows < nrg) rows = nrg;
@@ -482,7 +519,10 @@ extern "C" int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, co
       const size_t lds = (size_t)nrg * C * 5 * sizeof(float);
       hipLaunchKernelGGL((gate_bwd_reduce_kernel<T, G>), dim3(cdiv(S, rows), B), dim3(256), lds, (hipStream_t)s, (const T*)dout,
                          (const T*)u1, (const T*)u2, sums1, sums2, psi_w, (const T*)skip, a_in, (T*)dskip, ds_ws, dpsi_w, dpsi_b,
-                         bs1, bs2, B, S, (int)rows);
+                         bs1, bs2, ws, B, S, (int)rows);
+      if (ws != nullptr)
+        hipLaunchKernelGGL(gate_fold_kernel, dim3(cdiv(C * 5, 32), B), dim3(1024), 0, (hipStream_t)s, ws, (int)cdiv(S, rows), C,
+                           dpsi_w, dpsi_b, bs1, bs2);
       hipLaunchKernelGGL((gate_bwd_apply_kernel<T, G>), dim3(sgrid((long long)B * S * G)), dim3(256), 0, (hipStream_t)s,
                          (const T*)u1, (const T*)u2, sums1, sums2, psi_w, ds_ws, bs1, bs2, (T*)du1, (T*)du2, B, S);
     });

@@ -134,21 +134,42 @@ __device__ void build_axis(const AxisPlan& p, int b, bool forward, float x0, flo
   __syncthreads();
 }
 
-__global__ void roi_plan_kernel(const RoiArgs a) {
+// foreground histograms over h and w: grid (nblk, B); hist [B][2][ROI_MAX_LEN] zero on entry.  A block counts a contiguous
+// range of voxels in LDS and flushes its non-zero bins (a range touches few h rows) with integer atomics.
+__global__ void __launch_bounds__(256) roi_hist_kernel(const float* __restrict__ prob, int H, int W, int D, int C, float thr,
+                                                       int* __restrict__ hist) {
+  __shared__ int hx[ROI_MAX_LEN], hy[ROI_MAX_LEN];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < ROI_MAX_LEN; i += blockDim.x) { hx[i] = 0; hy[i] = 0; }
+  __syncthreads();
+  const long long n = (long long)H * W * D;
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  const long long i0 = (long long)blockIdx.x * per;
+  const long long i1 = i0 + per < n ? i0 + per : n;
+  const float* pb = prob + (long long)b * n * C;
+  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float fg = fsub(1.f, pb[i * C]);
+    if (fg >= thr) {
+      const long long hw = i / D;
+      atomicAdd(&hx[(int)(hw / W)], 1);
+      atomicAdd(&hy[(int)(hw % W)], 1);
+    }
+  }
+  __syncthreads();
+  int* hb = hist + (long long)b * 2 * ROI_MAX_LEN;
+  for (int i = threadIdx.x; i < ROI_MAX_LEN; i += blockDim.x) {
+    if (hx[i]) atomicAdd(hb + i, hx[i]);
+    if (hy[i]) atomicAdd(hb + ROI_MAX_LEN + i, hy[i]);
+  }
+}
+
+__global__ void roi_plan_kernel(const RoiArgs a, const int* __restrict__ hist) {
   __shared__ int hx[ROI_MAX_LEN], hy[ROI_MAX_LEN];
   __shared__ float bx[4];
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < ROI_MAX_LEN; i += blockDim.x) { hx[i] = 0; hy[i] = 0; }
-  __syncthreads();
-  const long long n = (long long)a.H * a.W * a.D;
-  const float* pb = a.prob + (long long)b * n * a.C;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-    const float fg = fsub(1.f, pb[i * a.C]);
-    if (fg >= a.thr) {
-      const long long hw = i / a.D;
-      atomicAdd(&hx[(int)(hw / a.W)], 1);
-      atomicAdd(&hy[(int)(hw % a.W)], 1);
-    }
+  for (int i = threadIdx.x; i < ROI_MAX_LEN; i += blockDim.x) {
+    hx[i] = hist[(long long)b * 2 * ROI_MAX_LEN + i];
+    hy[i] = hist[(long long)b * 2 * ROI_MAX_LEN + ROI_MAX_LEN + i];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -192,6 +213,7 @@ extern "C" int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n
   RoiArgs a;
   const int eval_h = (int)(1.2 * roi_size), eval_w = (int)(eval_h * 0.6);
   carve_all(a, B, H, W, eval_h, eval_w, nullptr, nullptr, n_int, n_float);
+  *n_int += (long long)B * 2 * ROI_MAX_LEN;      // foreground histograms (tail of the int buffer)
   return LTU_OK;
 }
 
@@ -208,7 +230,13 @@ extern "C" int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C
   a.min_w = a.eval_w / 2;
   long long ni, nf;
   carve_all(a, B, H, W, a.eval_h, a.eval_w, plan_i, plan_f, &ni, &nf);
-  hipLaunchKernelGGL(roi_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  int* hist = plan_i + ni;
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)B * 2 * ROI_MAX_LEN * sizeof(int), (hipStream_t)s);
+  if (e != hipSuccess) return (int)e;
+  const long long n = (long long)H * W * D;
+  const int nblk = (int)(n / 4096 < 1 ? 1 : (n / 4096 > 256 ? 256 : n / 4096));
+  hipLaunchKernelGGL(roi_hist_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)s, prob, H, W, D, C, thr, hist);
+  hipLaunchKernelGGL(roi_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a, (const int*)hist);
   return ltu_check_launch();
 }
 

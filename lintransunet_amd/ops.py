@@ -813,7 +813,7 @@ class _Gate(torch.autograd.Function):
         du1 = torch.empty_like(u1)
         du2 = torch.empty_like(u2)
         _lib.call('ltu_gate_bwd', _p(g), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
-                  _p(dpb), _p(bs1), _p(bs2), _p(du1), _p(du2), B, S, C, dt, _s())
+                  _p(dpb), _p(bs1), _p(bs2), _p(_norm_ws(dev)), _p(du1), _p(du2), B, S, C, dt, _s())
         # through the two 1x1x1 convs
         wxt = px.wt if px is not None else _w_transposed([wx], C, C, skip.dtype)
         wgt = pg.wt if pg is not None else _w_transposed([wg], C, Cg, skip.dtype)
