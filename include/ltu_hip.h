@@ -56,6 +56,11 @@ int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_str
  * 3 = pack wd (-> [p1=CiP][27][p0=CoP]), 4 = fp32 copy of R*C elements (padded biases), 5 / 6 = the sub-pixel
  * operands of ltu_upconv_* ([8][CoP][8][CiP] and [CiP][64][CoP]). */
 int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
+/* The same with the work dealt out in chunks of LTU_WPREP_CHUNK destination elements: chunks = nchunks device-resident
+ * { int record; int first_element / LTU_WPREP_CHUNK } pairs, one workgroup each (a model has hundreds of records of very
+ * different sizes).  Destination element counts per kind: 0/1/4: R*C; 2/3: p0*27*p1; 5/6: 64*p0*p1. */
+#define LTU_WPREP_CHUNK 4096
+int ltu_weight_prep_chunks(const void* table, const int* chunks, int nchunks, int out_dtype, ltu_stream_t s);
 
 /* ---- dense projections: nn.Linear (model/trans_block.py:144,156,166,187,189) and 1x1x1 convs
  *      (model/Unet_3Dblock.py:200-215).  y[M,N] (+)= a[M,K] . w[N,K]^T + bias;  w in the activation dtype, bias fp32.

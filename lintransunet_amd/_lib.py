@@ -36,6 +36,7 @@ SIGNATURES = {
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_weight_prep': [P, I, I, P],
+    'ltu_weight_prep_chunks': [P, P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],
     'ltu_upconv_fwd': [P, P, P, P, I, I, I, I, I, I, I, P],
     'ltu_upconv_dgrad': [P, P, P, I, I, I, I, I, I, I, P],

@@ -93,26 +93,22 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------
-// Philox4x32-7 keyed by (seed, stream id); counter = index of the 4-element group.  The backward
-// kernels regenerate the same mask from (seed, stream, index) instead of storing it.
-__device__ __forceinline__ uint4 philox4(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
-  uint32_t c2 = 0x243F6A88u, c3 = 0x85A308D3u;
-#pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return make_uint4(c0, c1, c2, c3);
+// Stateless: the keep bits of the 4-element group g4 are a hash of (seed, step counter, g4), so the backward kernels
+// regenerate the forward mask instead of storing it.  Two chained murmur3 finalizers give 64 bits per group, 16 per element
+// (keep iff bits >= p * 65536).  A first version ran Philox4x32-7 per group: its 28 quarter-rate 32-bit multiplies made
+// every dropout site VALU-bound (GELU + dropout ran at 37 % of the HBM rate); this mixer needs 4.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
 }
 
 struct DropCfg {       // p == 0 disables
   float p;
   float scale;         // 1/(1-p)
-  uint32_t thresh;     // keep iff r >= thresh, thresh = p * 2^32
-  uint32_t seed_lo, seed_hi;
+  uint32_t thresh;     // keep iff 16 random bits >= thresh, thresh = p * 2^16
+  uint32_t ka, kb;     // per-site keys
 };
 
 // `step` (nullable) points at a device-resident step counter mixed into the seed, so that a HIP-graph replay
@@ -122,20 +118,23 @@ __device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed, const uint6
   if (step != nullptr && p > 0.f) seed += *step * 0x9E3779B97F4A7C15ull;
   d.p = p;
   d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  d.thresh = p > 0.f ? (uint32_t)fminf(p * 4294967296.f, 4294967295.f) : 0u;
-  d.seed_lo = (uint32_t)seed;
-  d.seed_hi = (uint32_t)(seed >> 32);
+  d.thresh = p > 0.f ? (uint32_t)fminf(p * 65536.f + 0.5f, 65535.f) : 0u;
+  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+  d.ka = fmix32(lo ^ 0x243F6A88u) + fmix32(hi ^ 0x85A308D3u) * 0x9E3779B1u;
+  d.kb = fmix32(d.ka ^ hi ^ 0x13198A2Eu) | 1u;
   return d;
 }
 
 // multiplies the 4 values of group `g4` (a 64-bit element index / 4) by their keep-mask * scale
 __device__ __forceinline__ float4 drop4(const DropCfg& d, uint64_t g4, float4 v) {
   if (d.p <= 0.f) return v;
-  uint4 r = philox4((uint32_t)g4, (uint32_t)(g4 >> 32), d.seed_lo, d.seed_hi);
-  v.x = r.x >= d.thresh ? v.x * d.scale : 0.f;
-  v.y = r.y >= d.thresh ? v.y * d.scale : 0.f;
-  v.z = r.z >= d.thresh ? v.z * d.scale : 0.f;
-  v.w = r.w >= d.thresh ? v.w * d.scale : 0.f;
+  const uint32_t c1 = (uint32_t)(g4 >> 32);
+  const uint32_t h1 = fmix32(((uint32_t)g4 ^ d.ka) + ((c1 << 16) | (c1 >> 16)));
+  const uint32_t h2 = fmix32(h1 + d.kb);
+  v.x = (h1 & 0xFFFFu) >= d.thresh ? v.x * d.scale : 0.f;
+  v.y = (h1 >> 16) >= d.thresh ? v.y * d.scale : 0.f;
+  v.z = (h2 & 0xFFFFu) >= d.thresh ? v.z * d.scale : 0.f;
+  v.w = (h2 >> 16) >= d.thresh ? v.w * d.scale : 0.f;
   return v;
 }
 // keep-mask*scale factors only (used by backward kernels)
@@ -144,11 +143,25 @@ __device__ __forceinline__ float4 dropmask4(const DropCfg& d, uint64_t g4) {
 }
 
 // ---- misc ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU(x) = x Phi(x) with Phi through the Abramowitz-Stegun 7.1.26 form of erfc (|error| < 1.5e-7 on erf): one v_rcp, one
+// v_exp and 5 fmas, branch-free; libm's erff is ~70 instructions with divergent ranges and made the GELU kernels VALU-bound.
+// The negative side uses erfc directly (no 1 - erf cancellation); exp(-x^2/2) is shared with the density in the derivative.
+__device__ __forceinline__ float gelu_cdf(float x, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));      // raw v_rcp_f32 (1 ulp); __frcp_rn expands to a full division
+  e = __expf(-z * z);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float half_erfc = 0.5f * poly * e;
+  return x >= 0.f ? 1.f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float e;
+  return x * gelu_cdf(x, e);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;
+  const float cdf = gelu_cdf(x, e);
+  return cdf + x * 0.39894228040143267794f * e;
 }
 
 static inline int ltu_check_launch() {

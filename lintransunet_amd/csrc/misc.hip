@@ -19,33 +19,40 @@ struct WPrep {
   int kind, R, C, p0, p1, pad;
 };
 
+// Destination elements [t0, t1) of record d, `stride` apart per thread.  All index arithmetic is 32-bit (a record has < 2^31
+// destination elements): the 64-bit divisions of a first version cost more than the memory traffic.
 template <typename TW>
-__global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
-  const WPrep d = table[blockIdx.y];
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void weight_prep_range(const WPrep& d, unsigned t0, unsigned t1, unsigned stride) {
   TW* dst = reinterpret_cast<TW*>(d.dst);
   if (d.kind == 0) {
-    const long long n = (long long)d.R * d.C;
-    for (long long i = t0; i < n; i += stride) st1<TW>(dst + i, d.src[i]);
+    const unsigned n = (unsigned)d.R * (unsigned)d.C;
+    if (t1 > n) t1 = n;
+    for (unsigned i = t0; i < t1; i += stride) st1<TW>(dst + i, d.src[i]);
   } else if (d.kind == 4) {
-    const long long n = (long long)d.R * d.C;
-    for (long long i = t0; i < n; i += stride) reinterpret_cast<float*>(d.dst)[i] = d.src[i];
+    const unsigned n = (unsigned)d.R * (unsigned)d.C;
+    if (t1 > n) t1 = n;
+    for (unsigned i = t0; i < t1; i += stride) reinterpret_cast<float*>(d.dst)[i] = d.src[i];
   } else if (d.kind == 1) {
-    const long long n = (long long)d.R * d.C;
-    for (long long i = t0; i < n; i += stride) {       // i enumerates the DESTINATION (coalesced writes; sources are L2-resident)
-      const int r = (int)(i % d.R), c = (int)(i / d.R);
-      st1<TW>(dst + (long long)c * d.p0 + d.p1 + r, d.src[(long long)r * d.C + c]);
+    const unsigned n = (unsigned)d.R * (unsigned)d.C, R = (unsigned)d.R, C = (unsigned)d.C;
+    if (t1 > n) t1 = n;
+    // i enumerates the DESTINATION (coalesced writes; sources are L2-resident); (r, c) advance incrementally
+    unsigned r = t0 % R, c = t0 / R;
+    const unsigned dr = stride % R, dc = stride / R;
+    for (unsigned i = t0; i < t1; i += stride) {
+      st1<TW>(dst + (size_t)c * d.p0 + d.p1 + r, d.src[(size_t)r * C + c]);
+      r += dr; c += dc;
+      if (r >= R) { r -= R; ++c; }
     }
   } else if (d.kind == 5 || d.kind == 6) {
-    const int CoP = d.p0, CiP = d.p1;
-    const long long n = 64LL * CoP * CiP;
-    for (long long i = t0; i < n; i += stride) {
-      int cls, sl, co, ci;
-      if (d.kind == 5) { ci = (int)(i % CiP); sl = (int)((i / CiP) % 8); co = (int)((i / (8LL * CiP)) % CoP); cls = (int)(i / (8LL * CiP * CoP)); }
-      else { co = (int)(i % CoP); const int cs = (int)((i / CoP) % 64); ci = (int)(i / (64LL * CoP)); cls = cs >> 3; sl = cs & 7; }
+    const unsigned CoP = (unsigned)d.p0, CiP = (unsigned)d.p1;
+    const unsigned n = 64u * CoP * CiP;
+    if (t1 > n) t1 = n;
+    for (unsigned i = t0; i < t1; i += stride) {
+      unsigned cls, sl, co, ci;
+      if (d.kind == 5) { ci = i % CiP; const unsigned q = i / CiP; sl = q & 7; co = (q >> 3) % CoP; cls = (q >> 3) / CoP; }
+      else { co = i % CoP; const unsigned q = i / CoP; const unsigned cs = q & 63; ci = q >> 6; cls = cs >> 3; sl = cs & 7; }
       float v = 0.f;
-      if (co < d.R && ci < d.C) {
+      if (co < (unsigned)d.R && ci < (unsigned)d.C) {
         // per axis: class p, slot a -> taps {0} | {1,2} (p = 0) or {0,1} | {2} (p = 1)
         int lo[3], hi[3];
         for (int a = 0; a < 3; ++a) {
@@ -53,7 +60,7 @@ __global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
           if (p == 0) { lo[a] = sa == 0 ? 0 : 1; hi[a] = sa == 0 ? 0 : 2; }
           else { lo[a] = sa == 0 ? 0 : 2; hi[a] = sa == 0 ? 1 : 2; }
         }
-        const float* w = d.src + ((long long)co * d.C + ci) * 27;
+        const float* w = d.src + ((size_t)co * d.C + ci) * 27;
         for (int th = lo[0]; th <= hi[0]; ++th)
           for (int tw = lo[1]; tw <= hi[1]; ++tw)
             for (int td = lo[2]; td <= hi[2]; ++td) v += w[(th * 3 + tw) * 3 + td];
@@ -61,22 +68,54 @@ __global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
       st1<TW>(dst + i, v);
     }
   } else {
-    const int CoP = d.p0, CiP = d.p1;
-    const long long n = (long long)CoP * 27 * CiP;
-    for (long long i = t0; i < n; i += stride) {
-      int co, ci, t;
-      if (d.kind == 2) { ci = (int)(i % CiP); t = (int)((i / CiP) % 27); co = (int)(i / ((long long)CiP * 27)); }
-      else { co = (int)(i % CoP); t = (int)((i / CoP) % 27); ci = (int)(i / ((long long)CoP * 27)); }
-      const float v = (co < d.R && ci < d.C) ? d.src[((long long)co * d.C + ci) * 27 + t] : 0.f;
+    const unsigned CoP = (unsigned)d.p0, CiP = (unsigned)d.p1;
+    const unsigned n = CoP * 27u * CiP;
+    if (t1 > n) t1 = n;
+    // destination digits (fast .. slow): kind 2 (ci, t, co), kind 3 (co, t, ci); advanced incrementally
+    const unsigned R0 = d.kind == 2 ? CiP : CoP;
+    unsigned x0 = t0 % R0, q = t0 / R0, x1 = q % 27u, x2 = q / 27u;
+    const unsigned s0 = stride % R0, sq = stride / R0, s1 = sq % 27u, s2 = sq / 27u;
+    for (unsigned i = t0; i < t1; i += stride) {
+      const unsigned co = d.kind == 2 ? x2 : x0, ci = d.kind == 2 ? x0 : x2;
+      const float v = (co < (unsigned)d.R && ci < (unsigned)d.C) ? d.src[((size_t)co * d.C + ci) * 27 + x1] : 0.f;
       st1<TW>(dst + i, v);
+      x0 += s0; x1 += s1; x2 += s2;
+      if (x0 >= R0) { x0 -= R0; ++x1; }
+      if (x1 >= 27u) { x1 -= 27u; ++x2; }
     }
   }
+}
+
+// grid (256, n): every record spread over 256 workgroups (fine for a handful of records)
+template <typename TW>
+__global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
+  const WPrep d = table[blockIdx.y];
+  weight_prep_range<TW>(d, blockIdx.x * blockDim.x + threadIdx.x, 0x7fffffffu, gridDim.x * blockDim.x);
+}
+
+// grid (nchunks): chunk c = {record, first destination element / LTU_WPREP_CHUNK}.  A model has hundreds of records of
+// very different sizes; a fixed grid per record costs more in workgroup dispatch than in memory traffic.
+template <typename TW>
+__global__ void weight_prep_chunk_kernel(const WPrep* __restrict__ table, const int2* __restrict__ chunks) {
+  const int2 c = chunks[blockIdx.x];
+  const WPrep d = table[c.x];
+  const unsigned t0 = (unsigned)c.y * LTU_WPREP_CHUNK;
+  weight_prep_range<TW>(d, t0 + threadIdx.x, t0 + LTU_WPREP_CHUNK, blockDim.x);
 }
 
 extern "C" int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s) {
   if (n <= 0) return LTU_OK;
   LTU_DISPATCH_T(out_dtype, {
     hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(256, n), dim3(256), 0, (hipStream_t)s, (const WPrep*)table);
+  });
+  return ltu_check_launch();
+}
+
+extern "C" int ltu_weight_prep_chunks(const void* table, const int* chunks, int nchunks, int out_dtype, ltu_stream_t s) {
+  if (nchunks <= 0) return LTU_OK;
+  LTU_DISPATCH_T(out_dtype, {
+    hipLaunchKernelGGL((weight_prep_chunk_kernel<T>), dim3(nchunks), dim3(256), 0, (hipStream_t)s, (const WPrep*)table,
+                       (const int2*)chunks);
   });
   return ltu_check_launch();
 }

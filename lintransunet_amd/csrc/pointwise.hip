@@ -159,14 +159,73 @@ __global__ void gelu_drop_bwd_kernel(const T* __restrict__ dh, const T* __restri
                                            g.z * m.z * gelu_erf_grad(v.z), g.w * m.w * gelu_erf_grad(v.w)));
   }
 }
+// bf16 fast path: 16-byte accesses (8 elements), two independent loads in flight per thread.  The dropout groups are the same
+// 4-element groups as above (2i and 2i+1), so either kernel regenerates the other's mask.
+__device__ __forceinline__ void unpack8(const uint4& r, float4& a, float4& b) {
+  a = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  b = make_float4(__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u));
+}
+__device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
+  return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+template <bool BWD>
+__device__ __forceinline__ uint4 gelu8(const DropCfg& dc, long long i, const uint4& ur, const uint4& gr) {
+  float4 a, b;
+  unpack8(ur, a, b);
+  if (!BWD) {
+    a = make_float4(gelu_erf(a.x), gelu_erf(a.y), gelu_erf(a.z), gelu_erf(a.w));
+    b = make_float4(gelu_erf(b.x), gelu_erf(b.y), gelu_erf(b.z), gelu_erf(b.w));
+    return pack8(drop4(dc, (uint64_t)(2 * i), a), drop4(dc, (uint64_t)(2 * i + 1), b));
+  }
+  float4 ga, gb;
+  unpack8(gr, ga, gb);
+  const float4 ma = dropmask4(dc, (uint64_t)(2 * i)), mb = dropmask4(dc, (uint64_t)(2 * i + 1));
+  a = make_float4(ga.x * ma.x * gelu_erf_grad(a.x), ga.y * ma.y * gelu_erf_grad(a.y), ga.z * ma.z * gelu_erf_grad(a.z),
+                  ga.w * ma.w * gelu_erf_grad(a.w));
+  b = make_float4(gb.x * mb.x * gelu_erf_grad(b.x), gb.y * mb.y * gelu_erf_grad(b.y), gb.z * mb.z * gelu_erf_grad(b.z),
+                  gb.w * mb.w * gelu_erf_grad(b.w));
+  return pack8(a, b);
+}
+template <bool BWD>
+__global__ void __launch_bounds__(256) gelu_drop_bf16x8_kernel(const uint4* __restrict__ u, const uint4* __restrict__ dh,
+                                                               uint4* __restrict__ out, long long n8, float p, uint64_t seed,
+                                                               const uint64_t* step) {
+  const DropCfg dc = make_drop(p, seed, step);
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (; i + stride < n8; i += 2 * stride) {
+    const uint4 u0 = u[i], u1 = u[i + stride];
+    const uint4 g0 = BWD ? dh[i] : z, g1 = BWD ? dh[i + stride] : z;
+    out[i] = gelu8<BWD>(dc, i, u0, g0);
+    out[i + stride] = gelu8<BWD>(dc, i + stride, u1, g1);
+  }
+  if (i < n8) out[i] = gelu8<BWD>(dc, i, u[i], BWD ? dh[i] : z);
+}
+static unsigned gelu8_grid(long long n8) {
+  long long blocks = (n8 + 511) / 512;          // two 16-byte pieces per thread
+  if (blocks > 16384) blocks = 16384;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
 extern "C" int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (n % 4) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && n % 8 == 0 && (((uintptr_t)u | (uintptr_t)h) & 15) == 0) {
+    hipLaunchKernelGGL((gelu_drop_bf16x8_kernel<false>), dim3(gelu8_grid(n / 8)), dim3(256), 0, (hipStream_t)s, (const uint4*)u,
+                       (const uint4*)u, (uint4*)h, n / 8, p, seed, step);
+    return ltu_check_launch();
+  }
   LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((gelu_drop_fwd_kernel<T>), dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)s, (const T*)u, (T*)h, n / 4, p, seed, step); });
   return ltu_check_launch();
 }
 extern "C" int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, float p, uint64_t seed, const uint64_t* step, int dtype,
                                     ltu_stream_t s) {
   if (n % 4) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && n % 8 == 0 && (((uintptr_t)u | (uintptr_t)dh | (uintptr_t)du) & 15) == 0) {
+    hipLaunchKernelGGL((gelu_drop_bf16x8_kernel<true>), dim3(gelu8_grid(n / 8)), dim3(256), 0, (hipStream_t)s, (const uint4*)u,
+                       (const uint4*)dh, (uint4*)du, n / 8, p, seed, step);
+    return ltu_check_launch();
+  }
   LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((gelu_drop_bwd_kernel<T>), dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)s, (const T*)dh, (const T*)u, (T*)du, n / 4, p, seed, step); });
   return ltu_check_launch();
 }

@@ -61,6 +61,9 @@ class _SeedStream:
         return (self.base << 20) + self.n
 
 
+WPREP_CHUNK = 4096          # LTU_WPREP_CHUNK of include/ltu_hip.h
+
+
 class _WeightStore:
     """Every GEMM weight operand of the model in the activation dtype, refreshed by ONE kernel launch per step.
 
@@ -121,14 +124,21 @@ class _WeightStore:
             rec[i] = (src.data_ptr(), dst.data_ptr(), kind, R, C, p0, p1, 0)
         self.ptrs = [(src.data_ptr(), dst.data_ptr()) for src, dst, *_ in self.recs]
         self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+        # work list: (record, chunk) pairs of WPREP_CHUNK destination elements, one workgroup each
+        chunks = []
+        for i, (src, dst, kind, R, C, p0, p1) in enumerate(self.recs):
+            n = R * C if kind in (0, 1, 4) else (p0 * 27 * p1 if kind in (2, 3) else 64 * p0 * p1)
+            chunks += [(i, c) for c in range((n + WPREP_CHUNK - 1) // WPREP_CHUNK)]
+        self.nchunks = len(chunks)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(self.device)
 
     def stale(self):
         """parameter storage moved (e.g. .to(), load with assign): the table must be rebuilt"""
         return any(src.data_ptr() != p0 for (src, *_), (p0, _) in zip(self.recs, self.ptrs))
 
     def refresh(self):
-        ops._lib.call('ltu_weight_prep', self.table.data_ptr(), len(self.recs), ops.F32 if self.dtype == torch.float32 else ops.BF16,
-                      torch.cuda.current_stream().cuda_stream)
+        ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks,
+                      ops.F32 if self.dtype == torch.float32 else ops.BF16, torch.cuda.current_stream().cuda_stream)
 
 
 class MaskTransUnet(nn.Module):
