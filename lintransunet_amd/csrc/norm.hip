@@ -134,6 +134,82 @@ __global__ void instnorm_apply_kernel(const T* __restrict__ x, const float* __re
   }
 }
 
+// The same with the channel statistics hoisted out of the loop: grid (blocks, B) and a loop stride that is a multiple of the
+// channel count (C | 1024), so a thread meets one channel quad only.  The kernel above recomputes 4 in_stat()s (12 loads, 4
+// rsqrt) and two 64-bit divisions per 4 elements, which made it VALU-bound at 3 TB/s.
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_apply_fixedc_kernel(const T* __restrict__ x, const float* __restrict__ sums,
+                                                                    const T* __restrict__ res, T* __restrict__ y, long long S,
+                                                                    int C, int act, float slope, float p, uint64_t seed,
+                                                                    const uint64_t* step) {
+  const int b = blockIdx.y;
+  const long long per_b = S * C / 4;
+  const float invS = 1.f / (float)S;
+  const DropCfg dc = make_drop(p, seed, step);
+  const int c = (threadIdx.x * 4) % C;
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
+    mean[k] = st.mean; rstd[k] = st.rstd;
+  }
+  const long long base = (long long)b * per_b;
+  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < per_b; j += (long long)gridDim.x * 256) {
+    const long long i = base + j;
+    const float4 v = Vec4<T>::load(x + i * 4);
+    float4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float h = (f4at(v, k) - mean[k]) * rstd[k];
+      if (act == LTU_ACT_LRELU) h = h > 0.f ? h : h * slope;
+      f4at(o, k) = h;
+    }
+    o = drop4(dc, (uint64_t)i, o);
+    if (res) {
+      const float4 r = Vec4<T>::load(res + i * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    Vec4<T>::store(y + i * 4, o);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_bwd_apply_fixedc_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                        const float* __restrict__ sums,
+                                                                        const float* __restrict__ bsums, T* __restrict__ dx,
+                                                                        long long S, int C, int act, float slope, float p,
+                                                                        uint64_t seed, const uint64_t* step) {
+  const int b = blockIdx.y;
+  const long long per_b = S * C / 4;
+  const float invS = 1.f / (float)S;
+  const DropCfg dc = make_drop(p, seed, step);
+  const int c = (threadIdx.x * 4) % C;
+  float mean[4], rstd[4], b0[4], b1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
+    mean[k] = st.mean; rstd[k] = st.rstd;
+    b0[k] = bsums[((long long)b * C + c + k) * 2] * invS;
+    b1[k] = bsums[((long long)b * C + c + k) * 2 + 1] * invS;
+  }
+  const long long base = (long long)b * per_b;
+  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < per_b; j += (long long)gridDim.x * 256) {
+    const long long i = base + j;
+    const float4 xv = Vec4<T>::load(x + i * 4);
+    const float4 g = Vec4<T>::load(dy + i * 4);
+    const float4 mk = dropmask4(dc, (uint64_t)i);
+    float4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float h = (f4at(xv, k) - mean[k]) * rstd[k];
+      float gg = f4at(g, k) * f4at(mk, k);
+      if (act == LTU_ACT_LRELU && h <= 0.f) gg *= slope;
+      f4at(o, k) = rstd[k] * (gg - b0[k] - h * b1[k]);
+    }
+    Vec4<T>::store(dx + i * 4, o);
+  }
+}
+
 // backward reductions: bsums[b][c][2] += { sum g, sum g*xhat },  g = dy*mask*act'(xhat)
 template <typename T>
 __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
@@ -365,13 +441,26 @@ static unsigned stream_grid(long long nvec) {
   return (unsigned)blocks;
 }
 
+static unsigned per_sample_grid(long long nvec_per_sample, int B) {
+  long long blocks = (nvec_per_sample + 255) / 256;
+  const long long cap = 4096 / (B > 0 ? B : 1) > 1 ? 4096 / (B > 0 ? B : 1) : 1;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
 extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C,
                                   int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 != 0) return LTU_E_SHAPE;
   const long long nvec = (long long)B * S * C / 4;
+  const bool fixedc = 1024 % C == 0;           // the loop stride (256 vectors) is then a multiple of the channel count
   LTU_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((instnorm_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)x, sums,
-                       (const T*)res, (T*)y, S, C, B, act, slope, p, seed, step);
+    if (fixedc)
+      hipLaunchKernelGGL((instnorm_apply_fixedc_kernel<T>), dim3(per_sample_grid(S * C / 4, B), B), dim3(256), 0, (hipStream_t)s,
+                         (const T*)x, sums, (const T*)res, (T*)y, S, C, act, slope, p, seed, step);
+    else
+      hipLaunchKernelGGL((instnorm_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)x, sums,
+                         (const T*)res, (T*)y, S, C, B, act, slope, p, seed, step);
   });
   return ltu_check_launch();
 }
@@ -392,8 +481,12 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
     hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)dy,
                        (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
     if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, bsums, nullptr, 0, (hipStream_t)s);
-    hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
-                       (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
+    if (1024 % C == 0)
+      hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T>), dim3(per_sample_grid(S * C / 4, B), B), dim3(256), 0,
+                         (hipStream_t)s, (const T*)dy, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope, p, seed, step);
+    else
+      hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
+                         (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
   });
   return ltu_check_launch();
 }

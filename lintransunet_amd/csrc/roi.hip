@@ -336,9 +336,9 @@ extern "C" int ltu_roi_resample(const void* in, void* out, int* plan_i, float* p
 // ------------------------------------------------------------------------------------------------ trilinear x2
 // nn.Upsample(scale (2,2,2) | (2,2,1), trilinear, align_corners=True)  (model/Unet_3Dblock.py:1341-1345)
 // src coordinate of output o along an axis: o * (in-1)/(out-1) in fp32, taps floor and floor+1 (clamped).
-__device__ __forceinline__ void tri_tap(int o, int in, int out, int* i0, int* i1, float* l0, float* l1) {
+// `scale` = (float)(in-1)/(float)(out-1) (0 when out == 1), computed once on the host with the same fp32 division.
+__device__ __forceinline__ void tri_tap(int o, int in, int out, float scale, int* i0, int* i1, float* l0, float* l1) {
   if (in == out) { *i0 = o; *i1 = o; *l0 = 1.f; *l1 = 0.f; return; }
-  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
   const float src = scale * (float)o;
   int a = (int)src;
   if (a > in - 1) a = in - 1;
@@ -346,27 +346,27 @@ __device__ __forceinline__ void tri_tap(int o, int in, int out, int* i0, int* i1
   const float lam = src - (float)a;
   *i0 = a; *i1 = a + p; *l1 = lam; *l0 = 1.f - lam;
 }
+struct TriScale { float h, w, d, ih, iw, id; };      // forward scales and their inverses (out-1)/(in-1) per axis
 
+// grid (blocks, B*Ho): the (b, h) plane comes from blockIdx.y, threads walk (w, d, channel quad) with 32-bit arithmetic
+// (a first version decomposed a 64-bit linear index and divided floats per output vector: VALU-bound).
 template <typename T>
-__global__ void trilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int D, int C, int Ho, int Wo,
-                                     int Do) {
-  const int cv = C / 4;
-  const long long n = (long long)B * Ho * Wo * Do * cv;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(t % cv);
-    long long r = t / cv;
-    const int d = (int)(r % Do); r /= Do;
-    const int w = (int)(r % Wo); r /= Wo;
-    const int h = (int)(r % Ho);
-    const int b = (int)(r / Ho);
-    int h0, h1, w0, w1, d0, d1;
-    float lh0, lh1, lw0, lw1, ld0, ld1;
-    tri_tap(h, H, Ho, &h0, &h1, &lh0, &lh1);
-    tri_tap(w, W, Wo, &w0, &w1, &lw0, &lw1);
-    tri_tap(d, D, Do, &d0, &d1, &ld0, &ld1);
+__global__ void __launch_bounds__(256) trilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int D,
+                                                            int C, int Ho, int Wo, int Do, TriScale sc) {
+  const unsigned cv = C / 4;
+  const unsigned b = blockIdx.y / (unsigned)Ho, h = blockIdx.y - b * (unsigned)Ho;
+  int hs[2], ws[2], dsv[2];
+  float lh[2], lw[2], ld[2];
+  tri_tap((int)h, H, Ho, sc.h, &hs[0], &hs[1], &lh[0], &lh[1]);
+  const unsigned n = (unsigned)Wo * Do * cv;
+  const T* xb = x + (long long)b * H * W * D * C;
+  T* yb = y + ((long long)b * Ho + h) * n * 4;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const unsigned r = t / cv, v = t - r * cv;
+    const unsigned w = r / (unsigned)Do, d = r - w * (unsigned)Do;
+    tri_tap((int)w, W, Wo, sc.w, &ws[0], &ws[1], &lw[0], &lw[1]);
+    tri_tap((int)d, D, Do, sc.d, &dsv[0], &dsv[1], &ld[0], &ld[1]);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int hs[2] = {h0, h1}, ws[2] = {w0, w1}, dsv[2] = {d0, d1};
-    const float lh[2] = {lh0, lh1}, lw[2] = {lw0, lw1}, ld[2] = {ld0, ld1};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -375,24 +375,23 @@ __global__ void trilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
         for (int f = 0; f < 2; ++f) {
           const float wgt = lh[a] * lw[e] * ld[f];
           if (wgt == 0.f) continue;
-          const float4 q = Vec4<T>::load(x + ((((long long)b * H + hs[a]) * W + ws[e]) * D + dsv[f]) * C + v * 4);
+          const float4 q = Vec4<T>::load(xb + (((long long)hs[a] * W + ws[e]) * D + dsv[f]) * C + v * 4);
           acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
         }
-    Vec4<T>::store(y + t * 4, acc);
+    Vec4<T>::store(yb + (long long)t * 4, acc);
   }
 }
 
 // adjoint in gather form: candidates o with src(o) in (i-1, i+1), tested with the forward's own tap function
-__device__ __forceinline__ int tri_cands(int i, int in, int out, int* os, float* wsum) {
+__device__ __forceinline__ int tri_cands(int i, int in, int out, float scale, float inv, int* os, float* wsum) {
   if (in == out) { os[0] = i; wsum[0] = 1.f; return 1; }
   int n = 0;
-  const float inv = (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1);
   int lo = (int)floorf((float)(i - 1) * inv) - 1, hi = (int)ceilf((float)(i + 1) * inv) + 1;
   if (lo < 0) lo = 0;
   if (hi > out - 1) hi = out - 1;
   for (int o = lo; o <= hi && n < 8; ++o) {
     int i0, i1; float l0, l1;
-    tri_tap(o, in, out, &i0, &i1, &l0, &l1);
+    tri_tap(o, in, out, scale, &i0, &i1, &l0, &l1);
     float w = 0.f;
     if (i0 == i) w += l0;
     if (i1 == i) w += l1;
@@ -401,44 +400,56 @@ __device__ __forceinline__ int tri_cands(int i, int in, int out, int* os, float*
   return n;
 }
 
+// grid (blocks, B*H)
 template <typename T>
-__global__ void trilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int D, int C, int Ho, int Wo,
-                                     int Do) {
-  const int cv = C / 4;
-  const long long n = (long long)B * H * W * D * cv;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(t % cv);
-    long long r = t / cv;
-    const int d = (int)(r % D); r /= D;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H);
-    const int b = (int)(r / H);
-    int oh[8], ow[8], od[8];
-    float wh[8], ww[8], wd[8];
-    const int nh = tri_cands(h, H, Ho, oh, wh), nw = tri_cands(w, W, Wo, ow, ww), nd = tri_cands(d, D, Do, od, wd);
+__global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int D,
+                                                            int C, int Ho, int Wo, int Do, TriScale sc) {
+  const unsigned cv = C / 4;
+  const unsigned b = blockIdx.y / (unsigned)H, h = blockIdx.y - b * (unsigned)H;
+  int oh[8], ow[8], od[8];
+  float wh[8], ww[8], wd[8];
+  const int nh = tri_cands((int)h, H, Ho, sc.h, sc.ih, oh, wh);
+  const unsigned n = (unsigned)W * D * cv;
+  const T* gb = dy + (long long)b * Ho * Wo * Do * C;
+  T* xb = dx + ((long long)b * H + h) * n * 4;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const unsigned r = t / cv, v = t - r * cv;
+    const unsigned w = r / (unsigned)D, d = r - w * (unsigned)D;
+    const int nw = tri_cands((int)w, W, Wo, sc.w, sc.iw, ow, ww), nd = tri_cands((int)d, D, Do, sc.d, sc.id, od, wd);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = 0; a < nh; ++a)
       for (int e = 0; e < nw; ++e)
         for (int f = 0; f < nd; ++f) {
           const float wgt = wh[a] * ww[e] * wd[f];
-          const float4 q = Vec4<T>::load(dy + ((((long long)b * Ho + oh[a]) * Wo + ow[e]) * Do + od[f]) * C + v * 4);
+          const float4 q = Vec4<T>::load(gb + (((long long)oh[a] * Wo + ow[e]) * Do + od[f]) * C + v * 4);
           acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
         }
-    Vec4<T>::store(dx + t * 4, acc);
+    Vec4<T>::store(xb + (long long)t * 4, acc);
   }
 }
+
+static float tri_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+static float tri_inv(int in, int out) { return (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1); }
 
 extern "C" int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
                                 ltu_stream_t s) {
   if (C % 4 || (sd != 1 && sd != 2)) return LTU_E_SHAPE;
   const int Ho = 2 * H, Wo = 2 * W, Do = sd * D;
+  if ((long long)Wo * Do * (C / 4) >= (1LL << 31) || (long long)B * Ho >= 65536) return LTU_E_SHAPE;
+  TriScale sc;
+  sc.h = tri_scale(H, Ho); sc.w = tri_scale(W, Wo); sc.d = tri_scale(D, Do);
+  sc.ih = tri_inv(H, Ho); sc.iw = tri_inv(W, Wo); sc.id = tri_inv(D, Do);
   LTU_DISPATCH_T(dtype, {
     if (!adjoint) {
-      const long long n = (long long)B * Ho * Wo * Do * (C / 4);
-      hipLaunchKernelGGL((trilinear_fwd_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W, D, C, Ho, Wo, Do);
+      const long long n = (long long)Wo * Do * (C / 4);
+      const unsigned gx = (unsigned)((n + 511) / 512 < 1 ? 1 : (n + 511) / 512);
+      hipLaunchKernelGGL((trilinear_fwd_kernel<T>), dim3(gx, B * Ho), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W,
+                         D, C, Ho, Wo, Do, sc);
     } else {
-      const long long n = (long long)B * H * W * D * (C / 4);
-      hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W, D, C, Ho, Wo, Do);
+      const long long n = (long long)W * D * (C / 4);
+      const unsigned gx = (unsigned)((n + 511) / 512 < 1 ? 1 : (n + 511) / 512);
+      hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W,
+                         D, C, Ho, Wo, Do, sc);
     }
   });
   return ltu_check_launch();
