@@ -33,6 +33,21 @@
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
+// bf16 storage: the 32x32 products run on v_mfma_f32_32x32x16_bf16 (2 instructions of 8 passes per product instead of 16
+// fp32 instructions of 16 passes, which had made the per-token kernels matrix-core-bound).  Lane (li, lh) supplies the 8
+// k-elements 16*lh + 8*u + e of k-step u, i.e. elements 8u..8u+7 of the same per-lane arrays the fp32 path walks with s.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+  return r;
+}
+template <typename T>
+struct IsBf16 { static constexpr bool value = false; };
+template <>
+struct IsBf16<bf16_t> { static constexpr bool value = true; };
+
 // ---- 16-byte global vector <-> fp32 LDS --------------------------------------------------------------------
 template <typename T>
 struct GVec;
@@ -140,16 +155,34 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= alpha;
     // accT[j][i] += sum_t v[t][j] * p[t][i];  MFMA k-step = 2 tokens (lane half picks the token)
+    if constexpr (IsBf16<T>::value) {
 #pragma unroll
-    for (int t0 = 0; t0 < TOK; t0 += 2) {
-      const int t = t0 + lh;
-      float p = 0.f, vv = 0.f;
-      if (t < ntok) {
-        p = __expf(ks[t * ROW + li] - m_new);
-        vv = vs[t * ROW + li];
+      for (int u = 0; u < 2; ++u) {             // k-step = 16 tokens: lane half lh takes tokens 16u + 8lh + e
+        float pe[8], ve[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int t = 16 * u + 8 * lh + e;
+          pe[e] = 0.f; ve[e] = 0.f;
+          if (t < ntok) {
+            pe[e] = __expf(ks[t * ROW + li] - m_new);
+            ve[e] = vs[t * ROW + li];
+          }
+          s_run += pe[e];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ve), pack8(pe), acc, 0, 0, 0);
       }
-      s_run += p;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int t0 = 0; t0 < TOK; t0 += 2) {
+        const int t = t0 + lh;
+        float p = 0.f, vv = 0.f;
+        if (t < ntok) {
+          p = __expf(ks[t * ROW + li] - m_new);
+          vv = vs[t * ROW + li];
+        }
+        s_run += p;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p, acc, 0, 0, 0);
+      }
     }
   }
   const float s_tot = s_run + xhalf(s_run);
@@ -224,6 +257,7 @@ __global__ void __launch_bounds__(2 * D) linattn_apply(const T* __restrict__ qkv
   const float* cx = ctx + ((long long)b * H + wave) * 1024;
 #pragma unroll
   for (int s = 0; s < 16; ++s) cb[s] = cx[(16 * lh + s) * 32 + li];
+  const bf16x8 cbb[2] = {pack8(cb), pack8(cb + 8)};
   const float rs = 0.17677669529663688110f;      // 1/sqrt(32)
   const T* base = qkv + (long long)b * N * 3 * D;
 
@@ -263,8 +297,15 @@ __global__ void __launch_bounds__(2 * D) linattn_apply(const T* __restrict__ qkv
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (IsBf16<T>::value) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] * inv, cb[s], acc, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) a[s] *= inv;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a), cbb[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a + 8), cbb[1], acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] * inv, cb[s], acc, 0, 0, 0);
+    }
     __syncthreads();   // everyone is done reading the q tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -318,15 +359,32 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
       tg.load(gb, D, 0, n0 + TOK, n_end, tid);
     }
     const int ntok = min(TOK, n_end - n0);
+    if constexpr (IsBf16<T>::value) {
 #pragma unroll
-    for (int t0 = 0; t0 < TOK; t0 += 2) {
-      const int t = t0 + lh;
-      float qv = 0.f, gv = 0.f;
-      if (t < ntok) {
-        qv = __expf(sq[t * D + wave * DK + li] - st[(t * H + wave) * 2]) * st[(t * H + wave) * 2 + 1];
-        gv = sg[t * D + wave * DK + li];
+      for (int u = 0; u < 2; ++u) {
+        float qe[8], ge[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int t = 16 * u + 8 * lh + e;
+          qe[e] = 0.f; ge[e] = 0.f;
+          if (t < ntok) {
+            qe[e] = __expf(sq[t * D + wave * DK + li] - st[(t * H + wave) * 2]) * st[(t * H + wave) * 2 + 1];
+            ge[e] = sg[t * D + wave * DK + li];
+          }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ge), pack8(qe), acc, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, qv, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int t0 = 0; t0 < TOK; t0 += 2) {
+        const int t = t0 + lh;
+        float qv = 0.f, gv = 0.f;
+        if (t < ntok) {
+          qv = __expf(sq[t * D + wave * DK + li] - st[(t * H + wave) * 2]) * st[(t * H + wave) * 2 + 1];
+          gv = sg[t * D + wave * DK + li];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, qv, acc, 0, 0, 0);
+      }
     }
   }
   float* out = part + (((long long)b * nsplit + sp) * H + wave) * 1024;
@@ -392,6 +450,21 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
     dcA[s] = dctx[bh * 1024 + li * 32 + 16 * lh + s];
     dcT[s] = dctx[bh * 1024 + (16 * lh + s) * 32 + li];
   }
+  const bf16x8 ctxB[2] = {pack8(ctxA), pack8(ctxA + 8)}, dcTB[2] = {pack8(dcT), pack8(dcT + 8)};
+  // dk = P (dP - tvec) cancels almost completely (the key gradients are ~1e-3 of the others), and tvec comes from the fp32
+  // dctx: dP must use the same values.  dctx is therefore split into three bf16 pieces (8 + 8 + 8 mantissa bits = exact), v is
+  // exact in bf16 already, so the three products accumulate to the fp32 result at 6 bf16 instructions instead of 16 fp32 ones.
+  bf16x8 dcAB[3][2];
+  {
+    float r1[16], r2[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      r1[s] = dcA[s] - (float)(__bf16)dcA[s];
+      r2[s] = r1[s] - (float)(__bf16)r1[s];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { dcAB[0][u] = pack8(dcA + 8 * u); dcAB[1][u] = pack8(r1 + 8 * u); dcAB[2][u] = pack8(r2 + 8 * u); }
+  }
   const T* qb = qkv + (long long)b * N * 3 * D;
   const T* gb = dout + (long long)b * N * D;
 
@@ -436,13 +509,26 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
     f32x16 aq, av, ak;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { aq[r] = 0.f; av[r] = 0.f; ak[r] = 0.f; }
+    if constexpr (IsBf16<T>::value) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int ch = 16 * lh + s;
-      const float pk = __expf(kk[s] - cs[ch]) * cs[32 + ch];                  // P[t][i=ch]
-      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(ctxA[s], gj[s], aq, 0, 0, 0);  // dqsT[i][t]
-      av = __builtin_amdgcn_mfma_f32_32x32x2f32(dcT[s], pk, av, 0, 0, 0);      // dvT[j][t]   (A[row=j][kk=i] = dctx[i][j])
-      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(dcA[s], vj[s], ak, 0, 0, 0);   // dPT[i][t]
+      for (int s = 0; s < 16; ++s) kk[s] = __expf(kk[s] - cs[16 * lh + s]) * cs[32 + 16 * lh + s];      // P[t][i=ch]
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ctxB[u], pack8(gj + 8 * u), aq, 0, 0, 0);
+        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dcTB[u], pack8(kk + 8 * u), av, 0, 0, 0);
+        const bf16x8 vb = pack8(vj + 8 * u);
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dcAB[pc][u], vb, ak, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int ch = 16 * lh + s;
+        const float pk = __expf(kk[s] - cs[ch]) * cs[32 + ch];                  // P[t][i=ch]
+        aq = __builtin_amdgcn_mfma_f32_32x32x2f32(ctxA[s], gj[s], aq, 0, 0, 0);  // dqsT[i][t]
+        av = __builtin_amdgcn_mfma_f32_32x32x2f32(dcT[s], pk, av, 0, 0, 0);      // dvT[j][t]   (A[row=j][kk=i] = dctx[i][j])
+        ak = __builtin_amdgcn_mfma_f32_32x32x2f32(dcA[s], vj[s], ak, 0, 0, 0);   // dPT[i][t]
+      }
     }
     // registers hold rows idx(r) = (r&3) + 8*(r>>2) + 4*half of token li: 4 groups of 4 contiguous channels
     float dot = 0.f;

@@ -362,6 +362,28 @@ def test_linattn_sizes(ops, B, h, N):
         assert rel_err(qkv.grad[:, s * d:(s + 1) * d], dref[:, s * d:(s + 1) * d]) < 3e-4
 
 
+@pytest.mark.parametrize('B,h,N', [(2, 4, 1000), (1, 8, 2500), (2, 8, 517)])
+def test_linattn_bf16(ops, B, h, N):
+    """bf16 storage: the 32x32 products run on the bf16 matrix cores (fp32 accumulation); compared with the fp32 oracle on
+    bf16-rounded inputs, error relative to each tensor's max (bf16 rounding of the outputs alone is 4e-3)"""
+    g = G(9)
+    bf = lambda t: t.bfloat16().float()
+    q, k, v, go = (bf(torch.randn(B, h, N, 32, generator=g)) for _ in range(4))
+    k[:, :, N // 3] += 8.0
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = O_net.linear_attention(qr, kr, vr)
+    ref.backward(go)
+    d = h * 32
+    qkv = _qkv_pack(q, k, v).to(DEV, torch.bfloat16).requires_grad_(True)
+    out = ops.linear_attention(qkv, B, N, d)
+    assert out.dtype == torch.bfloat16
+    out.backward(go.transpose(1, 2).reshape(B * N, d).to(DEV, torch.bfloat16))
+    assert rel_err(out.float(), ref.transpose(1, 2).reshape(B * N, d)) < 1.5e-2
+    dref = _qkv_pack(qr.grad, kr.grad, vr.grad)
+    for s in range(3):
+        assert rel_err(qkv.grad[:, s * d:(s + 1) * d].float(), dref[:, s * d:(s + 1) * d]) < 2e-2
+
+
 def test_attn_layer_golden(ops, golden_dir):
     """one whole post-norm layer (qkv GEMM, attention core, out-proj, LN, FFN, LN) vs the reference's vectors"""
     Gd = np.load(os.path.join(golden_dir, 'attn_layer.npz'))
