@@ -346,17 +346,25 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   RowTile<T, D, D, D> tq, tg;
+  // the row statistics travel with the tile (one float per thread): a load issued after the prefetch below would have to wait
+  // for the whole prefetch as well (vector-memory loads retire in order)
+  static_assert(TOK * H * 2 <= 2 * D, "one statistics float per thread");
+  auto load_stat = [&](int n0) {
+    return (tid < TOK * H * 2 && n0 + tid / (H * 2) < n_end) ? qstat[((long long)b * N + n0) * H * 2 + tid] : 0.f;
+  };
   tq.load(qb, 3 * D, 0, n_begin, n_end, tid);
   tg.load(gb, D, 0, n_begin, n_end, tid);
+  float stn = load_stat(n_begin);
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
     __syncthreads();
     tq.store(sq, tid);
     tg.store(sg, tid);
-    if (tid < TOK * H * 2) st[tid] = (n0 + tid / (H * 2) < n_end) ? qstat[((long long)b * N + n0) * H * 2 + tid] : 0.f;
+    if (tid < TOK * H * 2) st[tid] = stn;
     __syncthreads();
     if (n0 + TOK < n_end) {
       tq.load(qb, 3 * D, 0, n0 + TOK, n_end, tid);
       tg.load(gb, D, 0, n0 + TOK, n_end, tid);
+      stn = load_stat(n0 + TOK);
     }
     const int ntok = min(TOK, n_end - n0);
     if constexpr (IsBf16<T>::value) {
@@ -472,23 +480,24 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
   const int n_end = min(N, n_begin + tokb);
   RowTile<T, D, 3 * D, LD3> tq;
   RowTile<T, D, D, LD1> tg;
+  // (row max, scaled inverse sum) of token n0 + li travel with the tile prefetch: loaded after it they would wait for it
+  auto load_qs = [&](int n0) {
+    return n0 + li < n_end ? *reinterpret_cast<const float2*>(qstat + (((long long)b * N + n0 + li) * H + wave) * 2)
+                           : make_float2(0.f, 0.f);
+  };
   tq.load(qb, 3 * D, 0, n_begin, n_end, tid);
   tg.load(gb, D, 0, n_begin, n_end, tid);
+  float2 qsn = load_qs(n_begin);
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
     __syncthreads();
     tq.store(smem, tid);
     tg.store(gt, tid);
+    const float rmax = qsn.x, rinv = qsn.y;
     __syncthreads();
     if (n0 + TOK < n_end) {
       tq.load(qb, 3 * D, 0, n0 + TOK, n_end, tid);
       tg.load(gb, D, 0, n0 + TOK, n_end, tid);
-    }
-    const bool tok_ok = n0 + li < n_end;
-    float rmax = 0.f, rinv = 0.f;
-    if (tok_ok) {
-      const float* qs = qstat + (((long long)b * N + n0 + li) * H + wave) * 2;
-      rmax = qs[0];
-      rinv = qs[1];
+      qsn = load_qs(n0 + TOK);
     }
     const float* qrow = &smem[li * LD3 + wave * DK];
     const float* krow = qrow + D;
