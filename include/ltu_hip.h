@@ -99,11 +99,15 @@ long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci);
  * nearest-neighbour x2 upsampling of x0 (nn.Upsample of Unet_3Dblock.py:421), (Hi,Wi,Di) are then
  * the physical dims.  y [B,Ho,Wo,Do,Co]. */
 int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* bias, void* y, int B, int Hi, int Wi,
-                   int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype, ltu_stream_t s);
+                   int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, float* ws, int dtype, ltu_stream_t s);
+/* ws of ltu_conv3d_fwd / ltu_conv3d_dgrad (optional, bf16 stride-1 convs only): floats of workspace that let a conv over a
+ * small grid (the deep U-Net levels) split its input channels over several workgroups per tile; 0 when the shape does not
+ * split.  (B,H,W,D) = the conv's output grid, C = input channels of the call (Co for the data gradient), Co = its outputs. */
+long long ltu_conv3d_ws_floats(int B, int H, int W, int D, int C, int Co);
 /* data gradient: g [B,Ho,Wo,Do,Co], wd [C0+C1][27][Co] -> dx0 [B,Hl,Wl,Dl,C0] (+ dx1 [..,C1]); (Hl,Wl,Dl)
  * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
 int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,
-                     int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s);
+                     int C1, int Co, int sh, int sw, int sd, float* ws, int dtype, ltu_stream_t s);
 /* weight gradient (+=, the caller zero-fills): torch_co == 0: into the packed layout dwf [Co][27][C0+C1];
  * torch_co != 0: straight into a PyTorch-layout gradient [torch_co][torch_ci][3][3][3] (padded rows/channels dropped).
  * db[Co] += column sums of g.

@@ -32,8 +32,9 @@ SIGNATURES = {
     'ltu_upconv_wgrad_ws_floats': [L, I, I],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
     'ltu_reduce_batch': [P, I, P],
-    'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
-    'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
+    'ltu_conv3d_ws_floats': [I, I, I, I, I, I],
+    'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_weight_prep': [P, I, I, P],
     'ltu_weight_prep_chunks': [P, P, I, I, P],

@@ -122,14 +122,16 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
   };
 
   const int ksteps = a.CC / 16;
-  load_halo(0);
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
+  const int c_lo = a.part != nullptr ? (int)blockIdx.z * a.cps : 0;
+  const int c_hi = a.part != nullptr ? (c_lo + a.cps < nchunk ? c_lo + a.cps : nchunk) : nchunk;
+  load_halo(c_lo);
+  for (int chunk = c_lo; chunk < c_hi; ++chunk) {
     __syncthreads();                       // previous chunk fully consumed (halo and both weight buffers)
     store_halo();
     load_b(chunk, 0);
     store_b(0);
     __syncthreads();
-    if (chunk + 1 < nchunk) load_halo(chunk + 1);     // in flight during the 27 taps below
+    if (chunk + 1 < c_hi) load_halo(chunk + 1);       // in flight during the 27 taps below
     for (int s = 0; s < NSTAGE; ++s) {
       const int buf = s & 1;
       if (s + 1 < NSTAGE) load_b(chunk, s + 1);
@@ -157,6 +159,23 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
     }
   }
 
+  if (a.part != nullptr) {                  // split over chunks: fp32 partial tile, folded by conv_halo_fold_kernel
+    float* pz = a.part + (long long)blockIdx.z * ((long long)a.B * a.H * a.W * a.D) * a.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n_blk + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int h = h0 + (ml >> 5), w = w0 + ((ml >> 3) & 3), d = d0 + (ml & 7);
+          if (n < a.N && h < a.H && w < a.W && d < a.D)
+            pz[((((long long)b * a.H + h) * a.W + w) * a.D + d) * a.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   // epilogue: bias, convert, stage the 128 x BN tile in LDS, 16-byte stores
   uint16_t* Cs = smem;
 #pragma unroll
@@ -344,6 +363,50 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
 }
 
 // returns LTU_OK after launching, or 1 when the shape is not handled here (the caller falls back to the implicit GEMM)
+// out[v][n] = bf16(sum_z part[z][v][n] + bias[n]); 4 columns per thread (N, n0 are multiples of 4)
+__global__ void __launch_bounds__(256) conv_halo_fold_kernel(const HaloArgs a, long long M) {
+  const int nq = a.N / 4;
+  const long long total = M * nq;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long v = t / nq;
+    const int n = (int)(t - v * nq) * 4;
+    float4 acc = a.bias != nullptr ? make_float4(a.bias[n], a.bias[n + 1], a.bias[n + 2], a.bias[n + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < a.ksplit; ++z) {
+      const float4 q = *reinterpret_cast<const float4*>(a.part + ((long long)z * M + v) * a.N + n);
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+    }
+    uint2 pk;
+    pk.x = pack_bf16x2(acc.x, acc.y);
+    pk.y = pack_bf16x2(acc.z, acc.w);
+    uint16_t* dst = n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + v * a.ldo0 + n
+                             : reinterpret_cast<uint16_t*>(a.o1) + v * a.ldo1 + (n - a.n0);
+    *reinterpret_cast<uint2*>(dst) = pk;
+  }
+}
+
+// split geometry: only for grids that leave most of the chip idle
+static int halo_split(long long bricks, int N, int C, int CC, int* cps) {
+  if (N <= 32 && C <= 32) return 1;                      // weight-stationary kernel
+  const int ntn = (N > 64 && bricks * cdiv(N, 128) >= 256) ? cdiv(N, 128) : (N > 32 ? cdiv(N, 64) : 1);
+  const long long blocks = bricks * ntn;
+  const int nchunk = (C + CC - 1) / CC;
+  if (blocks >= 200 || nchunk < 2) return 1;
+  int want = (int)((512 + blocks - 1) / blocks);
+  if (want > 8) want = 8;
+  if (want > nchunk) want = nchunk;
+  if (want < 2) return 1;
+  *cps = (nchunk + want - 1) / want;
+  return (nchunk + *cps - 1) / *cps;
+}
+static int halo_cc(int C, int c0) { return (C % 32 == 0 && c0 % 32 == 0) ? 32 : 16; }
+long long conv_halo_ws_floats(int B, int H, int W, int D, int C, int N) {
+  const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
+  int cps = 0;
+  const int ks = halo_split(bricks, N, C, halo_cc(C, C), &cps);
+  // c0 may lower CC to 16 (more chunks, never more than 8 splits): bound by 8
+  return (ks > 1 || halo_split(bricks, N, C, 16, &cps) > 1) ? 8LL * B * H * W * D * N : 0;
+}
+
 int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   if (a.C % 8 || a.c0 % 8 || a.lda0 % 8 || a.lda1 % 8 || a.N % 4 || a.n0 % 4 || a.ldo0 % 4 || a.ldo1 % 4) return 1;
   if (a.H < 2 || a.W < 2 || a.D < 4) return 1;
@@ -358,15 +421,26 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
     else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     return ltu_check_launch();
   }
+  int cps = 0;
+  a.ksplit = a.part != nullptr && !getenv("LTU_NO_HALO_SPLIT") ? halo_split(bricks, a.N, a.C, a.CC, &cps) : 1;
+  a.cps = cps;
+  if (a.ksplit < 2) a.part = nullptr;
+  const unsigned gz = (unsigned)a.ksplit;
   if (a.N > 64 && bricks * cdiv(a.N, 128) >= 256) {
-    dim3 grid((unsigned)bricks, cdiv(a.N, 128));
+    dim3 grid((unsigned)bricks, cdiv(a.N, 128), gz);
     hipLaunchKernelGGL((conv3_halo_bf16_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, a);
   } else if (a.N > 32) {                    // also wide outputs on small grids: 64-column tiles double the workgroup count
-    dim3 grid((unsigned)bricks, cdiv(a.N, 64));
+    dim3 grid((unsigned)bricks, cdiv(a.N, 64), gz);
     hipLaunchKernelGGL((conv3_halo_bf16_kernel<4, 1, 1, 2, 3>), grid, dim3(256), 0, st, a);
   } else {
-    dim3 grid((unsigned)bricks, 1);
+    dim3 grid((unsigned)bricks, 1, gz);
     hipLaunchKernelGGL((conv3_halo_bf16_kernel<4, 1, 1, 1, 3>), grid, dim3(256), 0, st, a);
+  }
+  if (a.part != nullptr) {
+    const long long M = (long long)a.B * a.H * a.W * a.D;
+    long long blocks = (M * (a.N / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_halo_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, M);
   }
   return ltu_check_launch();
 }

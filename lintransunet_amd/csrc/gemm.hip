@@ -453,7 +453,7 @@ static int conv_fwd_desc(IGemmArgs& g, int B, int Hi, int Wi, int Di, int C0, in
 }
 
 extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* bias, void* y, int B, int Hi,
-                              int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int dtype,
+                              int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, float* ws, int dtype,
                               ltu_stream_t s) {
   IGemmArgs g;
   int Ho, Wo, Do;
@@ -470,6 +470,7 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
       a.B = B; a.H = Hi; a.W = Wi; a.D = Di;
       a.C = C0 + C1; a.c0 = C0; a.lda0 = C0; a.lda1 = C1 > 0 ? C1 : C0;
       a.N = Co; a.n0 = Co; a.ldo0 = Co; a.ldo1 = Co;
+      a.part = ws;
       const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
       if (hr != 1) return hr;
     }
@@ -477,6 +478,10 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
   }
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_nt<float, float>(g, (hipStream_t)s);
+}
+
+extern "C" long long ltu_conv3d_ws_floats(int B, int H, int W, int D, int C, int Co) {
+  return conv_halo_ws_floats(B, H, W, D, C, Co);
 }
 
 extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi,
@@ -516,7 +521,7 @@ extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1
 // For a dim of stride 2 the input positions split into parity classes:  even i receives only from
 // tap 1 (at o = i/2), odd i from tap 0 (o = (i+1)/2) and tap 2 (o = (i-1)/2).
 extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl,
-                                int C0, int C1, int Co, int sh, int sw, int sd, int dtype, ltu_stream_t s) {
+                                int C0, int C1, int Co, int sh, int sw, int sd, float* ws, int dtype, ltu_stream_t s) {
   if ((sh != 1 && sh != 2) || (sw != 1 && sw != 2) || (sd != 1 && sd != 2)) return LTU_E_ARG;
   if (Co % 4 != 0) return LTU_E_SHAPE;
   if (dtype == LTU_BF16 && sh == 1 && sw == 1 && sd == 1 && use_halo()) {
@@ -527,6 +532,7 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
     a.C = Co; a.c0 = Co; a.lda0 = Co; a.lda1 = Co;
     a.N = C0 + C1; a.n0 = C0; a.ldo0 = C0; a.ldo1 = C1 > 0 ? C1 : C0;
     a.flip = 1;
+    a.part = ws;
     const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
     if (hr != 1) return hr;
   }

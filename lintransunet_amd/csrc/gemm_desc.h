@@ -105,7 +105,13 @@ struct HaloArgs {
   int N, n0, ldo0, ldo1;
   int flip;             // 1: data gradient (tap t reads halo offset 2 - t)
   int CC;               // channel chunk: 16 or 32 (chosen by the launcher)
+  // split over channel chunks for small grids (the deep U-Net levels: a few dozen bricks, thousands of input channels x taps):
+  // workgroup z accumulates chunks [z*cps, (z+1)*cps) and stores its fp32 tile to part[z][voxel][N]; conv_halo_fold_kernel
+  // adds the splits and the bias.  part == nullptr: one workgroup per tile walks all chunks.
+  float* part;
+  int ksplit, cps;
 };
+long long conv_halo_ws_floats(int B, int H, int W, int D, int C, int N);
 int launch_conv_halo_bf16(HaloArgs a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled (fall back)
 
 // LDS-halo weight gradient of the stride-1 3x3x3 convs (conv_halo.hip), two-stage through part / wgrad_reduce_kernel

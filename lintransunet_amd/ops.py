@@ -203,6 +203,14 @@ def _wgrad_ws(M, N, K, like):
     return torch.empty(n, device=like.device, dtype=torch.float32)
 
 
+def _conv_ws(B, H, W, D, C, N, like):
+    """workspace that lets a stride-1 bf16 conv over a small grid split its input channels (None: not needed)"""
+    if like.dtype != torch.bfloat16:
+        return None
+    n = _lib.load().ltu_conv3d_ws_floats(B, H, W, D, C, N)
+    return torch.empty(n, device=like.device, dtype=torch.float32) if n > 0 else None
+
+
 class ConvPrep:
     """prepared operands of one 3x3x3 conv: wf [CoP][27][CiP], wd [CiP][27][CoP] (activation dtype), bias [CoP] fp32"""
     __slots__ = ('wf', 'wd', 'bias')
@@ -289,8 +297,9 @@ class _Conv3d(torch.autograd.Function):
         Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
         Ho, Wo, Do = (Hl - 1) // sh + 1, (Wl - 1) // sw + 1, (Dl - 1) // sd + 1
         y = torch.empty((B, Ho, Wo, Do, cop), device=dev, dtype=x0.dtype)
+        ws = _conv_ws(B, Ho, Wo, Do, CiP, cop, x0) if (sh, sw, sd) == (1, 1, 1) and not ups else None
         _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias_p), _p(y), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
-                  int(ups), _dt(x0), _s())
+                  int(ups), _p(ws), _dt(x0), _s())
         ctx.save_for_backward(x0, x1)
         ctx.params = (weight, bias)
         ctx.cfg = (stride, ups, cop, C0, C1, prep)
@@ -319,7 +328,8 @@ class _Conv3d(torch.autograd.Function):
             Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
             d0 = torch.empty((B, Hl, Wl, Dl, C0), device=dev, dtype=x0.dtype)
             d1 = torch.empty((B, Hl, Wl, Dl, C1), device=dev, dtype=x0.dtype) if C1 else None
-            _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(d0), _p(d1), B, Hl, Wl, Dl, C0, C1, cop, sh, sw, sd, dt, _s())
+            ws = _conv_ws(B, Hl, Wl, Dl, cop, CiP, x0) if (sh, sw, sd) == (1, 1, 1) else None
+            _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(d0), _p(d1), B, Hl, Wl, Dl, C0, C1, cop, sh, sw, sd, _p(ws), dt, _s())
             if ups:
                 dx0 = torch.empty_like(x0)
                 _lib.call('ltu_sumpool2', _p(d0), _p(dx0), B, Hi, Wi, Di, C0, dt, _s())
