@@ -164,11 +164,17 @@ def main():
     ms_lin, n_lin = timer.measure(lambda c: ops.linear(c[0], list(c[2:2 + (len(c) - 2) // 2]), list(c[2 + (len(c) - 2) // 2:]), prep=c[1]))
     timer.calls = []
 
-    if args.no_graph:
-        step = eager_step
-    else:
-        graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer)
-        step = lambda i: graphed(*batches[i % 2])
+    launch = 'eager'
+    step = eager_step
+    if not args.no_graph:
+        try:
+            graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer)
+            step = lambda i: graphed(*batches[i % 2])
+            launch = 'hip-graph replay'
+        except Exception as e:                     # a failed capture must not cost the measurement: same kernels, launched eagerly
+            print(f'[bench] HIP-graph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
+            ops.set_step_counter(None)
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -201,7 +207,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights', 'global_batch': args.batch * world,
-                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': 'eager' if args.no_graph else 'hip-graph replay'},
+                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch},
             'roofline': {'bound': 'hbm', 'kernel': 'linear_ring_bf16_kernel (transformer projections, forward launches)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),
