@@ -588,7 +588,9 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
 // ------------------------------------------------------------------------------------------------ host side
 static int pick_splits(int B, int N, int* tokens_per_split) {
   // ~256..512 streaming workgroups in total, whole 32-token tiles each
-  int want = 512 / (B > 0 ? B : 1);
+  static int total = -1;
+  if (total < 0) { const char* e = getenv("LTU_LA_SPLITS"); total = (e && atoi(e) > 0) ? atoi(e) : 512; }
+  int want = total / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   int tps = (N + want - 1) / want;
   tps = (tps + 31) / 32 * 32;
