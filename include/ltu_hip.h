@@ -273,6 +273,18 @@ int ltu_ct_preprocess(const float* raw, float* img, const uint8_t* rawlab, uint8
 int ltu_crop_flip(const void* vol, void* out, const int* desc, int n, int H, int W, int D, int h, int w, int d, int elem_bytes,
                   ltu_stream_t s);
 
+/* ---- augmentations of the training dataset (dataset/CT_pancreas_ids.py:112-134; monai 0.7.0 RandRotated, RandAdjustContrastd,
+ * RandZoomd) on batches of patches [n][H][W][D] f32 (image and label alike: the reference interpolates both and casts the
+ * label back to uint8 at the end).  Random draws stay on the host; a sample that skips a transform gets the identity matrix /
+ * zoom 1 / gamma <= 0, all of which reproduce the input exactly.
+ * affine: out[k][p] = trilinear(in[k], M_k (p,1)), M_k = mats[k] (3x4 row-major, voxel coordinates), border padding.
+ * zoom:   interpolate to zsize[k] = floor(size * zoom_k) per axis (int32 [n][3], computed by the caller in double precision as
+ *         torch does; trilinear, align_corners) + centred edge pad / crop back to [H][W][D].
+ * contrast: ((x - min)/(max - min + 1e-7))^gamma[k] * (max - min) + min over each patch; minmax_ws: 2 n ints. */
+int ltu_affine_sample(const float* in, float* out, const float* mats, int n, int H, int W, int D, ltu_stream_t s);
+int ltu_zoom_sample(const float* in, float* out, const int* zsize, int n, int H, int W, int D, ltu_stream_t s);
+int ltu_adjust_contrast(const float* in, float* out, const float* gamma, int* minmax_ws, int n, long long per, ltu_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

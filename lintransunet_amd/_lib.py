@@ -36,6 +36,9 @@ SIGNATURES = {
     'ltu_conv3d_ws_floats': [I, I, I, I, I, I],
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
+    'ltu_affine_sample': [P, P, P, I, I, I, I, P],
+    'ltu_zoom_sample': [P, P, P, I, I, I, I, P],
+    'ltu_adjust_contrast': [P, P, P, P, I, L, P],
     'ltu_weight_prep': [P, I, I, P],
     'ltu_weight_prep_chunks': [P, P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],

@@ -4,7 +4,8 @@ dataset/CT_pancreas_ids.py:143-173: `.npy` scan [D,H,W] -> HU clip [-91, 250] ->
 then RandCropByPosNegLabeld(pos=0.7, neg=0.3, num_samples) and RandFlipd(prob=0.4, spatial_axis=(0, 1)) of monai 0.7.0.  A scan
 is uploaded once; preprocessing, cropping and flipping are HIP kernels (csrc/data.hip).  Crop centres are drawn on the host from
 the label's foreground / background index lists exactly as monai does (the label comes from disk, so it is host-resident anyway).
-The rotate / contrast / zoom augmentations of the reference are not implemented yet.
+`augment` applies the remaining augmentations of the reference (RandRotated, RandAdjustContrastd, RandZoomd, RandFlipd;
+CT_pancreas_ids.py:121-134) to a batch of patches on the device; the random draws stay on the host.
 """
 import numpy as np
 import torch
@@ -79,3 +80,100 @@ def sample_patches(img, lab, label_host, spatial_size, num_samples, rand_state, 
     centers = crop_centers(label_host, spatial_size, num_samples, rand_state=rand_state)
     flips = [rand_state.rand() < flip_prob for _ in range(num_samples)]
     return crop_flip(img, lab, centers, flips, spatial_size)
+
+
+# ---- augmentations (CT_pancreas_ids.py:121-134) -----------------------------------------------------------------------------
+
+def rotate_matrix(angles, shape):
+    """monai create_rotate (Rx @ Ry @ Rz) about the patch centre, as a 3x4 float32 pull matrix (output voxel -> input location)"""
+    ax, ay, az = (float(a) for a in angles)
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(ax), -np.sin(ax), 0], [0, np.sin(ax), np.cos(ax), 0], [0, 0, 0, 1]], dtype=np.float64)
+    ry = np.array([[np.cos(ay), 0, np.sin(ay), 0], [0, 1, 0, 0], [-np.sin(ay), 0, np.cos(ay), 0], [0, 0, 0, 1]], dtype=np.float64)
+    rz = np.array([[np.cos(az), -np.sin(az), 0, 0], [np.sin(az), np.cos(az), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    c = (np.asarray(shape, dtype=np.float64) - 1) / 2
+    sh, sh1 = np.eye(4), np.eye(4)
+    sh[:3, 3], sh1[:3, 3] = c, -c
+    return (sh @ rx @ ry @ rz @ sh1)[:3].astype(np.float32)
+
+
+_IDENTITY = np.eye(4, dtype=np.float32)[:3]
+
+
+def draw_augmentation(rs, rot_prob=0.1, rot_range=np.pi / 9, prob=0.4, zoom=(0.7, 1.3), gamma=(0.5, 4.5)):
+    """one sample's random parameters in the reference's transform order; every draw is made whether or not the transform fires"""
+    p = {}
+    p['rotate'] = rs.rand() < rot_prob
+    p['angles'] = [rs.uniform(-rot_range, rot_range) for _ in range(3)]
+    p['contrast'] = rs.rand() < prob
+    p['gamma'] = rs.uniform(*gamma)
+    p['zoom'] = rs.rand() < prob
+    p['zoom_factor'] = rs.uniform(*zoom)
+    p['flip'] = rs.rand() < prob
+    return p
+
+
+def _vol4(t):
+    if not t.is_cuda:
+        raise _lib.LtuError('data augmentations run on the GPU only (no CPU fallback)')
+    n = t.shape[0]
+    return t.reshape(n, *t.shape[-3:]).contiguous()
+
+
+def rotate(x, mats):
+    """x [n,(1,)H,W,D] f32, mats [n,3,4]: trilinear pull resampling with border padding (monai Rotate, keep_size)"""
+    v = _vol4(x)
+    n, H, W, D = v.shape
+    m = torch.as_tensor(np.ascontiguousarray(mats, dtype=np.float32).reshape(n, 12)).to(v.device)
+    out = torch.empty_like(v)
+    _lib.call('ltu_affine_sample', _p(v), _p(out), _p(m), n, H, W, D, _s())
+    return out.view(x.shape)
+
+
+def zoom(x, factors):
+    """monai Zoom(keep_size=True): trilinear align_corners interpolation to floor(size*f) + centred edge pad / crop"""
+    v = _vol4(x)
+    n, H, W, D = v.shape
+    # output size of F.interpolate(scale_factor=f): floor(size * f) in double precision
+    z = torch.tensor([[max(int(np.floor(float(sz) * float(f))), 1) for sz in (H, W, D)] for f in factors], dtype=torch.int32).to(v.device)
+    out = torch.empty_like(v)
+    _lib.call('ltu_zoom_sample', _p(v), _p(out), _p(z), n, H, W, D, _s())
+    return out.view(x.shape)
+
+
+def adjust_contrast(x, gammas):
+    """monai AdjustContrast per patch; gamma <= 0 leaves a patch untouched"""
+    v = _vol4(x)
+    n = v.shape[0]
+    g = torch.as_tensor(np.asarray(gammas, dtype=np.float32)).to(v.device)
+    ws = torch.empty(2 * n, device=v.device, dtype=torch.int32)
+    out = torch.empty_like(v)
+    _lib.call('ltu_adjust_contrast', _p(v), _p(out), _p(g), _p(ws), n, v.numel() // n, _s())
+    return out.view(x.shape)
+
+
+def augment(img, lab, params):
+    """img f32 [n,1,h,w,d], lab u8 [n,1,h,w,d], params: one draw_augmentation() dict per patch -> augmented (f32, u8).
+    The label is resampled in float and truncated back to uint8 as the reference does (CT_pancreas_ids.py:171)."""
+    n = img.shape[0]
+    shape = tuple(img.shape[-3:])
+    lf = lab.to(torch.float32)
+    if any(p['rotate'] for p in params):
+        mats = np.stack([rotate_matrix(p['angles'], shape) if p['rotate'] else _IDENTITY for p in params])
+        img, lf = rotate(img, mats), rotate(lf, mats)
+    if any(p['contrast'] for p in params):
+        img = adjust_contrast(img, [p['gamma'] if p['contrast'] else -1.0 for p in params])
+    if any(p['zoom'] for p in params):
+        f = [p['zoom_factor'] if p['zoom'] else 1.0 for p in params]
+        img, lf = zoom(img, f), zoom(lf, f)
+    lab8 = lf.to(torch.uint8)
+    if any(p['flip'] for p in params):
+        h, w, d = shape
+        flips = [p['flip'] for p in params]
+        oi = torch.empty_like(img)
+        ol = torch.empty_like(lab8)
+        desc = torch.tensor([[0, 0, 0, int(f), int(f)] for f in flips], dtype=torch.int32).to(img.device)
+        for k in range(n):                       # every patch is its own "volume" here: crop of the full extent, optional mirror
+            _lib.call('ltu_crop_flip', _p(img[k]), _p(oi[k]), _p(desc[k]), 1, h, w, d, h, w, d, 4, _s())
+            _lib.call('ltu_crop_flip', _p(lab8[k]), _p(ol[k]), _p(desc[k]), 1, h, w, d, h, w, d, 1, _s())
+        img, lab8 = oi, ol
+    return img, lab8
