@@ -328,7 +328,10 @@ int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st) {
   uintptr_t al = (uintptr_t)g.a0 | (uintptr_t)g.o0;
   for (int i = 0; i < g.nseg; ++i) al |= (uintptr_t)g.w[i];
   if (al & 15) return 1;
+  static int tnw1_below = -1;
+  if (tnw1_below < 0) { const char* e = getenv("LTU_NT_RING_TNW1_BELOW"); tnw1_below = e ? atoi(e) : 2048; }     // few row tiles: narrower column tiles spread them over more workgroups
   if (w8) {
+    if (g.K <= 256 && g.M < tnw1_below) return launch_lin_ring<4, 1, 4>(g, st);
     if (g.K <= 256) return launch_lin_ring<4, 2, 4>(g, st);
     if (g.K <= 384) return launch_lin_ring<4, 2, 3>(g, st);
     if (g.K <= 512) return launch_lin_ring<4, 1, 4>(g, st);
