@@ -237,29 +237,51 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
     *reinterpret_cast<uint4*>(&Wl[row * CC + slot * 8]) = v;
   }
 
-  uint4 hreg[NH];
-  auto load_halo = [&](int brick) {
+  // Index arithmetic is hoisted out of the brick loop: a thread always stages the same halo pieces and stores the same output
+  // pieces relative to the brick origin, and the brick coordinates advance incrementally (a first version re-derived all of
+  // it per brick: ~900 scalar / vector ALU instructions around 27 MFMAs).
+  struct BrickPos { int b, bh, bw, bd; };
+  auto decompose = [&](int brick) {
+    BrickPos q;
     int t = brick;
-    const int bd = t % nbd; t /= nbd;
-    const int bw = t % nbw; t /= nbw;
-    const int bh = t % nbh;
-    const int b = t / nbh;
+    q.bd = t % nbd; t /= nbd;
+    q.bw = t % nbw; t /= nbw;
+    q.bh = t % nbh;
+    q.b = t / nbh;
+    return q;
+  };
+  const BrickPos stepd = decompose((int)gridDim.x);
+  auto advance = [&](BrickPos& q) {
+    q.bd += stepd.bd; if (q.bd >= nbd) { q.bd -= nbd; ++q.bw; }
+    q.bw += stepd.bw; if (q.bw >= nbw) { q.bw -= nbw; ++q.bh; }
+    q.bh += stepd.bh; if (q.bh >= nbh) { q.bh -= nbh; ++q.b; }
+    q.b += stepd.b;
+  };
+  int p_hh[NH], p_hw[NH], p_hd[NH], p_ld[NH];
+  long long p_rel[NH];
+  const uint16_t* p_src[NH];
+  bool p_ok[NH];
+#pragma unroll
+  for (int p = 0; p < NH; ++p) {
+    const int idx = tid + p * 256;
+    const int hv = idx / VPV, part = idx - hv * VPV;
+    p_hd[p] = hv % HALO_D; p_hw[p] = (hv / HALO_D) % HALO_W; p_hh[p] = hv / (HALO_D * HALO_W);
+    const int c = part * 8;
+    p_ok[p] = idx < HALO_VOX * VPV && c < a.C;
+    p_src[p] = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + c : reinterpret_cast<const uint16_t*>(a.x1) + (c - a.c0);
+    p_ld[p] = c < a.c0 ? a.lda0 : a.lda1;
+    p_rel[p] = ((long long)(p_hh[p] - 1) * a.W + (p_hw[p] - 1)) * a.D + (p_hd[p] - 1);
+  }
+  uint4 hreg[NH];
+  auto load_halo = [&](const BrickPos& q) {
+    const int h0 = q.bh * 4, w0 = q.bw * 4, d0 = q.bd * 8;
+    const long long vox0 = (((long long)q.b * a.H + h0) * a.W + w0) * a.D + d0;
 #pragma unroll
     for (int p = 0; p < NH; ++p) {
-      const int idx = tid + p * 256;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (idx < HALO_VOX * VPV) {
-        const int hv = idx / VPV, part = idx - hv * VPV;
-        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
-        const int h = bh * 4 - 1 + hh, w = bw * 4 - 1 + hw, d = bd * 8 - 1 + hd;
-        const int c = part * 8;
-        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C) {
-          const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
-          const uint16_t* src = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + c
-                                         : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (c - a.c0);
-          v = *reinterpret_cast<const uint4*>(src);
-        }
-      }
+      const int h = h0 - 1 + p_hh[p], w = w0 - 1 + p_hw[p], d = d0 - 1 + p_hd[p];
+      if (p_ok[p] && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
+        v = *reinterpret_cast<const uint4*>(p_src[p] + (vox0 + p_rel[p]) * p_ld[p]);
       hreg[p] = v;
     }
   };
@@ -292,12 +314,18 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   uint16_t* Cs = halo;
 
   int brick = blockIdx.x;
-  if (brick < bricks) load_halo(brick);
+  BrickPos cur = decompose(brick), nxt = cur;
+  if (brick < bricks) load_halo(cur);
+  // output pieces of this thread: rows (tid >> 3) + 32 it, 4 channels from (tid & 7) * 4
+  const int o_w = tid >> 6, o_d = (tid >> 3) & 7, o_n = (tid & 7) * 4;
+  uint16_t* const o_base = o_n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + o_n : reinterpret_cast<uint16_t*>(a.o1) + (o_n - a.n0);
+  const int o_ld = o_n < a.n0 ? a.ldo0 : a.ldo1;
   for (; brick < bricks; brick += gridDim.x) {
     __syncthreads();                       // staging reads of the previous brick are done (and the weights are in place)
     store_halo();
     __syncthreads();
-    if (brick + (int)gridDim.x < bricks) load_halo(brick + gridDim.x);
+    advance(nxt);
+    if (brick + (int)gridDim.x < bricks) load_halo(nxt);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -344,21 +372,18 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
       *reinterpret_cast<uint2*>(&Cs[(wave * 32 + li) * LDC + 8 * rr + 4 * lh]) = pk;
     }
     __syncthreads();
-    int t = brick;
-    const int bd = t % nbd; t /= nbd;
-    const int bw = t % nbw; t /= nbw;
-    const int bh = t % nbh;
-    const int b = t / nbh;
-    for (int idx = tid; idx < 128 * 8; idx += 256) {
-      const int ml = idx >> 3, nl = (idx & 7) * 4;
-      const int h = bh * 4 + (ml >> 5), w = bw * 4 + ((ml >> 3) & 3), d = bd * 8 + (ml & 7);
-      if (nl >= a.N || h >= a.H || w >= a.W || d >= a.D) continue;
-      const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
-      const uint2 v = *reinterpret_cast<const uint2*>(&Cs[ml * LDC + nl]);
-      uint16_t* dst = nl < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + vox * a.ldo0 + nl
-                                : reinterpret_cast<uint16_t*>(a.o1) + vox * a.ldo1 + (nl - a.n0);
-      *reinterpret_cast<uint2*>(dst) = v;
+    {
+      const int h0 = cur.bh * 4, w = cur.bw * 4 + o_w, d = cur.bd * 8 + o_d;
+      const long long vox0 = (((long long)cur.b * a.H + h0) * a.W + w) * a.D + d;
+      const bool ok = o_n < a.N && w < a.W && d < a.D;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {     // row ml = (tid >> 3) + 32 it is brick voxel (h = it, w = o_w, d = o_d)
+        if (!ok || h0 + it >= a.H) continue;
+        const uint2 v = *reinterpret_cast<const uint2*>(&Cs[((tid >> 3) + 32 * it) * LDC + o_n]);
+        *reinterpret_cast<uint2*>(o_base + (vox0 + (long long)it * a.W * a.D) * o_ld) = v;
+      }
     }
+    cur = nxt;
   }
 }
 
@@ -416,7 +441,9 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
   if (a.N <= 32 && a.C <= 32 && !getenv("LTU_NO_HALO_WS")) {      // few channels: weights stationary, persistent over bricks
-    const unsigned nblk = (unsigned)(bricks < 512 ? bricks : 512);
+    static int wsb = -1;
+    if (wsb < 0) { const char* e = getenv("LTU_HALO_WS_BLOCKS"); wsb = (e && atoi(e) > 0) ? atoi(e) : 512; }
+    const unsigned nblk = (unsigned)(bricks < wsb ? bricks : wsb);
     if (a.C > 16) hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<32>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     return ltu_check_launch();
