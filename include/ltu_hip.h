@@ -54,11 +54,12 @@ int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_str
  * { const float* src; void* dst; int kind, R, C, p0, p1, pad; } with kind 0 = cast (R*C elements),
  * 1 = transpose ([R][C] -> dst[c*p0 + p1 + r]), 2 = pack wf ([R=Co][C=Ci][27] -> [p0=CoP][27][p1=CiP]),
  * 3 = pack wd (-> [p1=CiP][27][p0=CoP]), 4 = fp32 copy of R*C elements (padded biases), 5 / 6 = the sub-pixel
- * operands of ltu_upconv_* ([8][CoP][8][CiP] and [CiP][64][CoP]). */
+ * operands of ltu_upconv_* ([8][CoP][8][CiP] and [CiP][64][CoP]), 7 = pack wd of one member of a fused conv group: columns
+ * [off, off+cnt) of dst [p1=CiP][27][p0=stride], pad = off << 16 | cnt (its wf rows are a kind-2 record at a row offset). */
 int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
 /* The same with the work dealt out in chunks of LTU_WPREP_CHUNK destination elements: chunks = nchunks device-resident
  * { int record; int first_element / LTU_WPREP_CHUNK } pairs, one workgroup each (a model has hundreds of records of very
- * different sizes).  Destination element counts per kind: 0/1/4: R*C; 2/3: p0*27*p1; 5/6: 64*p0*p1. */
+ * different sizes).  Destination element counts per kind: 0/1/4: R*C; 2/3: p0*27*p1; 5/6: 64*p0*p1; 7: cnt*27*p1. */
 #define LTU_WPREP_CHUNK 4096
 int ltu_weight_prep_chunks(const void* table, const int* chunks, int nchunks, int out_dtype, ltu_stream_t s);
 
@@ -104,6 +105,14 @@ int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* 
  * small grid (the deep U-Net levels) split its input channels over several workgroups per tile; 0 when the shape does not
  * split.  (B,H,W,D) = the conv's output grid, C = input channels of the call (Co for the data gradient), Co = its outputs. */
 long long ltu_conv3d_ws_floats(int B, int H, int W, int D, int C, int Co);
+/* Two stride-1 convs over the same input in one pass (a decoder level's conv1 and its mask head read the same upsampled tensor:
+ * model/Unet_3Dblock.py:1353 + 1380): wf [N0+N1][27][C], bias [N0+N1]; columns [0,N0) -> y0 [..,N0], the rest -> y1 [..,N1].
+ * Data gradient of the pair: g0 [..,N0] and g1 [..,N1] read as one virtual concat against wd [C][27][N0+N1] -> dx [..,C]
+ * (no separate add of two input gradients).  ws as for ltu_conv3d_fwd with Co = N0+N1 (C = N0+N1, Co = C for the gradient). */
+int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* bias, void* y0, void* y1, int B, int H, int W, int D, int C,
+                        int N0, int N1, float* ws, int dtype, ltu_stream_t s);
+int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void* wd, void* dx, int B, int H, int W, int D, int C, int N0,
+                          int N1, float* ws, int dtype, ltu_stream_t s);
 /* data gradient: g [B,Ho,Wo,Do,Co], wd [C0+C1][27][Co] -> dx0 [B,Hl,Wl,Dl,C0] (+ dx1 [..,C1]); (Hl,Wl,Dl)
  * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
 int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,

@@ -630,6 +630,77 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
   return LTU_OK;
 }
 
+// ---- two stride-1 convs over the same input as one (a decoder level's conv1 and its mask head: Unet_3Dblock.py:1353 +
+// 1380).  Forward: output columns [0,N0) -> y0 [.., N0], the rest -> y1 [.., N1]; wf [N0+N1][27][C], bias [N0+N1].
+// Data gradient: the virtual concat of g0 [.., N0] and g1 [.., N1] against wd [C][27][N0+N1] -> dx [.., C] (no add pass).
+extern "C" int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* bias, void* y0, void* y1, int B, int H, int W,
+                                   int D, int C, int N0, int N1, float* ws, int dtype, ltu_stream_t s) {
+  if (N0 % 4 || N1 % 4 || N0 <= 0 || N1 <= 0) return LTU_E_SHAPE;
+  IGemmArgs g;
+  int Ho, Wo, Do;
+  int rc = conv_fwd_desc(g, B, H, W, D, C, 0, N0 + N1, 1, 1, 1, 0, &Ho, &Wo, &Do);
+  if (rc) return rc;
+  g.a0 = x; g.a1 = x;
+  g.w[0] = wf; g.bias[0] = bias;
+  g.o0 = y0; g.o1 = y1; g.n0 = N0; g.ldo0 = N0; g.ldo1 = N1;
+  if (dtype == LTU_BF16) {
+    if (use_halo()) {
+      HaloArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x0 = x; a.x1 = x; a.w = wf; a.bias = bias; a.o0 = y0; a.o1 = y1;
+      a.B = B; a.H = H; a.W = W; a.D = D;
+      a.C = C; a.c0 = C; a.lda0 = C; a.lda1 = C;
+      a.N = N0 + N1; a.n0 = N0; a.ldo0 = N0; a.ldo1 = N1;
+      a.part = ws;
+      const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
+      if (hr != 1) return hr;
+    }
+    return launch_nt_bf16(g, (hipStream_t)s);
+  }
+  if (dtype != LTU_F32) return LTU_E_DTYPE;
+  return launch_nt<float, float>(g, (hipStream_t)s);
+}
+
+extern "C" int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void* wd, void* dx, int B, int H, int W, int D, int C,
+                                     int N0, int N1, float* ws, int dtype, ltu_stream_t s) {
+  if (N0 % 4 || N1 % 4 || N0 <= 0 || N1 <= 0) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && use_halo()) {
+    HaloArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = g0; a.x1 = g1; a.w = wd; a.bias = nullptr; a.o0 = dx; a.o1 = dx;
+    a.B = B; a.H = H; a.W = W; a.D = D;
+    a.C = N0 + N1; a.c0 = N0; a.lda0 = N0; a.lda1 = N1;
+    a.N = C; a.n0 = C; a.ldo0 = C; a.ldo1 = C;
+    a.flip = 1;
+    a.part = ws;
+    const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
+  IGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  int nt = 0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int c = 0; c < 3; ++c) g.tap[nt++] = Tap{(int8_t)(1 - a), (int8_t)(1 - b), (int8_t)(1 - c), (int8_t)((a * 3 + b) * 3 + c)};
+  g.ntaps = 27;
+  g.nb = B; g.rh = H; g.rw = W; g.rd = D;
+  g.M = (long long)B * H * W * D;
+  g.N = C; g.C = N0 + N1; g.c0 = N0; g.K = 27 * (N0 + N1);
+  g.lda0 = N0; g.lda1 = N1;
+  g.nseg = 1; g.wrow = 27 * (N0 + N1);
+  g.sh = H; g.sw = W; g.sd = D; g.ups = 0;
+  g.mh = g.mw = g.md = 1;
+  g.a0 = g0; g.a1 = g1;
+  g.w[0] = wd;
+  g.out_identity = 1;
+  g.omh = g.omw = g.omd = 1;
+  g.oh = H; g.ow = W; g.od = D;
+  g.n0 = C; g.o0 = dx; g.o1 = dx; g.ldo0 = C; g.ldo1 = C;
+  if (dtype == LTU_F32) return launch_nt<float, float>(g, (hipStream_t)s);
+  if (dtype == LTU_BF16) return launch_nt_bf16(g, (hipStream_t)s);
+  return LTU_E_DTYPE;
+}
+
 // fp32 launchers for the other translation units (upconv.hip)
 int launch_nt_f32(const IGemmArgs& g, hipStream_t st) { return launch_nt<float, float>(g, st); }
 int launch_tn_f32(WGradArgs& wa, hipStream_t st) { return launch_tn<float>(wa, st); }

@@ -67,6 +67,16 @@ __device__ __forceinline__ void weight_prep_range(const WPrep& d, unsigned t0, u
       }
       st1<TW>(dst + i, v);
     }
+  } else if (d.kind == 7) {
+    // pack wd of one member of a fused conv group: columns [off, off+cnt) of dst [CiP][27][stride]; pad = off << 16 | cnt
+    const unsigned stride_c = (unsigned)d.p0, CiP = (unsigned)d.p1, off = (unsigned)d.pad >> 16, cnt = (unsigned)d.pad & 0xffffu;
+    const unsigned n = cnt * 27u * CiP;
+    if (t1 > n) t1 = n;
+    for (unsigned i = t0; i < t1; i += stride) {
+      const unsigned co = i % cnt, q = i / cnt, t = q % 27u, ci = q / 27u;
+      const float v = (co < (unsigned)d.R && ci < (unsigned)d.C) ? d.src[((size_t)co * d.C + ci) * 27 + t] : 0.f;
+      st1<TW>(dst + ((size_t)ci * 27 + t) * stride_c + off + co, v);
+    }
   } else {
     const unsigned CoP = (unsigned)d.p0, CiP = (unsigned)d.p1;
     const unsigned n = CoP * 27u * CiP;

@@ -73,7 +73,9 @@ class _WeightStore:
 
     def __init__(self, device, dtype):
         self.device, self.dtype = device, dtype
-        self.recs = []          # (src, dst, kind, R, C, p0, p1)
+        self.recs = []          # (src, dst, kind, R, C, p0, p1) of whole tensors; raw = the same with pointers and a pad field
+        self.raw = []
+        self.pair = {}
         self.conv, self.lin = {}, {}
         self.table = None
 
@@ -100,6 +102,16 @@ class _WeightStore:
         self.recs.append((w, wd, 6, Co, Ci, Co, Ci))
         self.conv[id(conv)] = ops.UpConvPrep(wf, wd)
 
+    def add_conv_pair(self, key, conv_a, conv_b, n1):
+        """conv_a and conv_b (3x3x3, stride 1, same input) fused: conv_b's outputs are zero-padded to n1 channels"""
+        wa, wb = conv_a.weight, conv_b.weight
+        Ca, Ci = wa.shape[0], wa.shape[1]
+        wf = torch.empty((Ca + n1, 27, Ci), device=self.device, dtype=self.dtype)
+        wd = torch.empty((Ci, 27, Ca + n1), device=self.device, dtype=self.dtype)
+        bias = torch.zeros(Ca + n1, device=self.device, dtype=torch.float32)
+        self.raw.append((conv_a, conv_b, n1, wf, wd, bias))
+        self.pair[key] = ops.PairPrep(wf, wd, bias, Ca, n1)
+
     def add_linear(self, key, weights):
         """weights: list of [N,K(,1,1,1)] parameters sharing K (a fused q,k,v group or a single projection)"""
         N, K = weights[0].shape[0], weights[0].shape[1]
@@ -118,23 +130,34 @@ class _WeightStore:
 
     def finalize(self):
         import numpy as np
-        rec = np.zeros(len(self.recs), dtype=[('src', '<u8'), ('dst', '<u8'), ('kind', '<i4'), ('R', '<i4'), ('C', '<i4'),
-                                              ('p0', '<i4'), ('p1', '<i4'), ('pad', '<i4')])
-        for i, (src, dst, kind, R, C, p0, p1) in enumerate(self.recs):
-            rec[i] = (src.data_ptr(), dst.data_ptr(), kind, R, C, p0, p1, 0)
-        self.ptrs = [(src.data_ptr(), dst.data_ptr()) for src, dst, *_ in self.recs]
+        rows = [(src.data_ptr(), dst.data_ptr(), kind, R, C, p0, p1, 0) for src, dst, kind, R, C, p0, p1 in self.recs]
+        for conv_a, conv_b, n1, wf, wd, bias in self.raw:
+            rows += ops.pair_records(conv_a.weight, conv_a.bias, conv_b.weight, conv_b.bias, n1, wf, wd, bias)
+        rec = np.zeros(len(rows), dtype=ops.WPREP_DTYPE)
+        for i, r in enumerate(rows):
+            rec[i] = r
+        self.ptrs = [r[0] for r in rows]
+        self.srcs = [src for src, *_ in self.recs] + [t for conv_a, conv_b, *_ in self.raw
+                                                      for t in (conv_a.weight, conv_b.weight, conv_a.weight, conv_b.weight, conv_a.bias, conv_b.bias)]
         self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
         # work list: (record, chunk) pairs of WPREP_CHUNK destination elements, one workgroup each
         chunks = []
-        for i, (src, dst, kind, R, C, p0, p1) in enumerate(self.recs):
-            n = R * C if kind in (0, 1, 4) else (p0 * 27 * p1 if kind in (2, 3) else 64 * p0 * p1)
+        for i, (_, _, kind, R, C, p0, p1, pad) in enumerate(rows):
+            if kind in (0, 1, 4):
+                n = R * C
+            elif kind in (2, 3):
+                n = p0 * 27 * p1
+            elif kind == 7:
+                n = (pad & 0xffff) * 27 * p1
+            else:
+                n = 64 * p0 * p1
             chunks += [(i, c) for c in range((n + WPREP_CHUNK - 1) // WPREP_CHUNK)]
         self.nchunks = len(chunks)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(self.device)
 
     def stale(self):
         """parameter storage moved (e.g. .to(), load with assign): the table must be rebuilt"""
-        return any(src.data_ptr() != p0 for (src, *_), (p0, _) in zip(self.recs, self.ptrs))
+        return any(src.data_ptr() != p0 for src, p0 in zip(self.srcs, self.ptrs))
 
     def refresh(self):
         ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks,
@@ -213,11 +236,12 @@ class MaskTransUnet(nn.Module):
         for blk in enc.block_list:
             st.add_conv(blk.conv1)
             st.add_conv(blk.conv2)
-        head_pad = 4 if self.act_dtype == torch.float32 else 8
-        for mc in dec.mask_conv_list:
-            st.add_conv(mc, cop=head_pad)
-        for blk in dec.block_list:
-            st.add_conv(blk.conv1)
+        # a decoder level's conv1 and its mask head read the same upsampled tensor: one fused conv (head padded to 16 / 32 columns
+        # so that the pair's data gradient keeps 32-channel chunks)
+        nl = len(self.num_layers)
+        for i, blk in enumerate(dec.block_list):
+            lvl = nl - 2 - i
+            st.add_conv_pair(lvl, blk.conv1, dec.mask_conv_list[lvl], 16 if lvl == 0 else 32)
             st.add_conv(blk.conv2)
         st.add_conv(dec.final_block)
         for ag in dec.att_conv_list:
@@ -325,16 +349,16 @@ class MaskTransUnet(nn.Module):
             lvl = nl - 1 - i
             t = ops.trilinear_up(t, 2 if (nl - i) % 2 == 0 else 1)
             mc = dec.mask_conv_list[lvl]
-            m = ops.head_softmax(ops.conv3d(t, mc.weight, mc.bias, cop=4 if self.act_dtype == torch.float32 else 8,
-                                            prep=store.conv[id(mc)]), C)
+            blk = dec.block_list[i - 1]
+            t1, zm = ops.conv3d_pair(t, blk.conv1.weight, blk.conv1.bias, mc.weight, mc.bias, store.pair[lvl])
+            m = ops.head_softmax(zm, C)
             masks.append(m)
             ag = dec.att_conv_list[lvl]
             skip = ops.attention_gate(skips[-i], t, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,
                                       ag.psi[0].weight, ag.psi[0].bias, store.lin[id(ag.W_x[0])], store.lin[id(ag.W_g[0])])
             if self.is_roi_list[lvl]:
                 skip = self._roi_bridge(dec.bridge_list[lvl], skip, m.detach(), self.roi_size_list[lvl], p, seeds)
-            blk = dec.block_list[i - 1]
-            t = self._conv_in_act(t, blk.conv1, seeds=seeds)
+            t = ops.instnorm_act(t1, act=ops.ACT_LRELU)
             t = self._conv_in_act(t, blk.conv2, x1=skip, p=p, seeds=seeds)
         z = ops.conv3d(t, dec.final_block.weight, dec.final_block.bias, prep=store.conv[id(dec.final_block)])
         out = ops.final_softmax(z, C)

@@ -345,6 +345,98 @@ class _Conv3d(torch.autograd.Function):
         return dx0, dx1, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None, None, None, None
 
 
+class PairPrep:
+    """operands of two stride-1 convs fused over one input: wf [N0+N1][27][C], wd [C][27][N0+N1], bias [N0+N1] fp32"""
+    __slots__ = ('wf', 'wd', 'bias', 'n0', 'n1', 'table')
+
+    def __init__(self, wf, wd, bias, n0, n1, table=None):
+        self.wf, self.wd, self.bias, self.n0, self.n1, self.table = wf, wd, bias, n0, n1, table
+
+
+WPREP_DTYPE = [('src', '<u8'), ('dst', '<u8'), ('kind', '<i4'), ('R', '<i4'), ('C', '<i4'), ('p0', '<i4'), ('p1', '<i4'), ('pad', '<i4')]
+
+
+def pair_records(wa, ba, wb, bb, n1, wf, wd, bias):
+    """ltu_weight_prep records (src, dst, kind, R, C, p0, p1, pad) that fill the operands of a conv pair"""
+    Ca, Ci = wa.shape[0], wa.shape[1]
+    Cb = wb.shape[0]
+    n0 = Ca
+    esz = wf.element_size()
+    return [
+        (wa.data_ptr(), wf.data_ptr(), 2, Ca, Ci, n0, Ci, 0),
+        (wb.data_ptr(), wf.data_ptr() + n0 * 27 * Ci * esz, 2, Cb, Ci, n1, Ci, 0),
+        (wa.data_ptr(), wd.data_ptr(), 7, Ca, Ci, n0 + n1, Ci, (0 << 16) | n0),
+        (wb.data_ptr(), wd.data_ptr(), 7, Cb, Ci, n0 + n1, Ci, (n0 << 16) | n1),
+        (ba.data_ptr(), bias.data_ptr(), 4, 1, Ca, 0, 0, 0),
+        (bb.data_ptr(), bias.data_ptr() + n0 * 4, 4, 1, Cb, 0, 0, 0),
+    ]
+
+
+def conv_pair_prep(wa, ba, wb, bb, n1, dtype):
+    """stand-alone operand preparation of a conv pair (the model does this inside its one-launch weight store)"""
+    import numpy as np
+    Ca, Ci = wa.shape[0], wa.shape[1]
+    dev = wa.device
+    wf = torch.empty((Ca + n1, 27, Ci), device=dev, dtype=dtype)
+    wd = torch.empty((Ci, 27, Ca + n1), device=dev, dtype=dtype)
+    bias = torch.zeros(Ca + n1, device=dev, dtype=torch.float32)
+    recs = pair_records(wa, ba, wb, bb, n1, wf, wd, bias)
+    rec = np.zeros(len(recs), dtype=WPREP_DTYPE)
+    for i, r in enumerate(recs):
+        rec[i] = r
+    table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    _lib.call('ltu_weight_prep', table.data_ptr(), len(recs), F32 if dtype == torch.float32 else BF16, _s())
+    return PairPrep(wf, wd, bias, Ca, n1, table)
+
+
+class _Conv3dPair(torch.autograd.Function):
+    """two 3x3x3 stride-1 convs of the same input in one pass: (conv_a(x) [..,Ca], conv_b(x) padded to [..,n1])"""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, prep):
+        _chk(x, 'x')
+        B, H, W, D, C = x.shape
+        n0, n1 = prep.n0, prep.n1
+        y0 = torch.empty((B, H, W, D, n0), device=x.device, dtype=x.dtype)
+        y1 = torch.empty((B, H, W, D, n1), device=x.device, dtype=x.dtype)
+        ws = _conv_ws(B, H, W, D, C, n0 + n1, x)
+        _lib.call('ltu_conv3d_pair_fwd', _p(x), _p(prep.wf), _p(prep.bias), _p(y0), _p(y1), B, H, W, D, C, n0, n1, _p(ws), _dt(x), _s())
+        ctx.save_for_backward(x)
+        ctx.params = (wa, ba, wb, bb)
+        ctx.prep = prep
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        (x,) = ctx.saved_tensors
+        wa, ba, wb, bb = ctx.params
+        prep = ctx.prep
+        B, H, W, D, C = x.shape
+        n0, n1 = prep.n0, prep.n1
+        dt = _dt(x)
+        g0 = torch.zeros((B, H, W, D, n0), device=x.device, dtype=x.dtype) if g0 is None else g0.contiguous()
+        g1 = torch.zeros((B, H, W, D, n1), device=x.device, dtype=x.dtype) if g1 is None else g1.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ws = _conv_ws(B, H, W, D, n0 + n1, C, x)
+            _lib.call('ltu_conv3d_pair_dgrad', _p(g0), _p(g1), _p(prep.wd), _p(dx), B, H, W, D, C, n0, n1, _p(ws), dt, _s())
+        outs = []
+        for g, w, b, cop in ((g0, wa, ba, n0), (g1, wb, bb, n1)):
+            dw, fw = _grad_buf(w)
+            db, fb = _grad_buf(b)
+            ws = _wgrad_ws(g.numel() // cop, cop, 27 * C, x)
+            _lib.call('ltu_conv3d_wgrad', _p(g), _p(x), 0, _p(dw), _p(db), B, H, W, D, C, 0, cop, 1, 1, 1, 0, w.shape[0], w.shape[1],
+                      _p(ws), dt, _s())
+            outs += [_grad_done(w, dw, fw), _grad_done(b, db, fb)]
+        return (dx, *outs, None)
+
+
+def conv3d_pair(x, wa, ba, wb, bb, prep):
+    """(conv_a(x), conv_b(x) zero-padded to prep.n1 channels): both 3x3x3, stride 1, padding 1, computed in one pass"""
+    return _Conv3dPair.apply(x, wa, ba, wb, bb, prep)
+
+
 class UpConvPrep:
     """sub-pixel operands of a nearest-x2 + 3x3x3 conv: wf [8][Co][8][Ci], wd [Ci][64][Co] (activation dtype)"""
     __slots__ = ('wf', 'wd', 'table')

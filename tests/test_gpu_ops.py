@@ -151,6 +151,40 @@ def test_conv3d_bf16(ops, case):
     assert rel_err(bd.grad, br.grad) < 2e-3
 
 
+@pytest.mark.parametrize('dtype,tol,wtol', [(torch.float32, 1e-4, 1e-4), (torch.bfloat16, 1e-2, 2e-3)])
+@pytest.mark.parametrize('case', [
+    # B, Ci, Ca, Cb, n1, H, W, D
+    (2, 32, 16, 2, 16, 9, 7, 12),      # level-0 shape class: weight-stationary kernel, data gradient from a 16+16 concat
+    (1, 64, 32, 2, 32, 8, 8, 16),      # generic halo kernel, 64-column tile
+    (1, 256, 128, 3, 32, 4, 4, 8),     # deep level: channel-split forward, 160-channel gradient concat
+])
+def test_conv3d_pair(ops, case, dtype, tol, wtol):
+    """conv1 + mask head of a decoder level fused into one conv against the two separate F.conv3d calls"""
+    B, Ci, Ca, Cb, n1, H, W, D = case
+    g = G(13)
+    rd = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = rd(torch.randn(B, Ci, H, W, D, generator=g))
+    wa, wb = rd(torch.randn(Ca, Ci, 3, 3, 3, generator=g) * 0.1), rd(torch.randn(Cb, Ci, 3, 3, 3, generator=g) * 0.1)
+    ba, bb = torch.randn(Ca, generator=g), torch.randn(Cb, generator=g)
+    xr, war, wbr, bar, bbr = (t.clone().requires_grad_(True) for t in (x, wa, wb, ba, bb))
+    ya, yb = F.conv3d(xr, war, bar, padding=1), F.conv3d(xr, wbr, bbr, padding=1)
+    ga, gb = rd(torch.randn(ya.shape, generator=g)), rd(torch.randn(yb.shape, generator=g))
+    torch.autograd.backward([ya, yb], [ga, gb])
+    xd = to_cl(x, dtype).requires_grad_(True)
+    pd = [t.to(DEV).requires_grad_(True) for t in (wa, ba, wb, bb)]
+    prep = ops.conv_pair_prep(pd[0].detach(), pd[1].detach(), pd[2].detach(), pd[3].detach(), n1, dtype)
+    y0, y1 = ops.conv3d_pair(xd, pd[0], pd[1], pd[2], pd[3], prep)
+    assert y0.shape[-1] == Ca and y1.shape[-1] == n1
+    assert (y1[..., Cb:].float().abs().max().item() == 0.0)            # padded head columns: zero weights, zero bias
+    g1 = torch.zeros(y1.shape, device=DEV, dtype=dtype)
+    g1[..., :Cb] = to_cl(gb, dtype)
+    torch.autograd.backward([y0, y1], [to_cl(ga, dtype), g1])
+    assert rel_err(from_cl(y0), ya) < tol and rel_err(from_cl(y1)[:, :Cb], yb) < tol
+    assert rel_err(from_cl(xd.grad), xr.grad) < tol
+    for got, ref in zip(pd, (war, bar, wbr, bbr)):
+        assert rel_err(got.grad, ref.grad) < wtol
+
+
 # ---------------------------------------------------------------------------------------------- conv3d
 CONV_CASES = [
     # B, Ci, Co, H, W, D, stride, C1, ups, cop
