@@ -113,6 +113,11 @@ int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* bias, void* 
                         int N0, int N1, float* ws, int dtype, ltu_stream_t s);
 int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void* wd, void* dx, int B, int H, int W, int D, int C, int N0,
                           int N1, float* ws, int dtype, ltu_stream_t s);
+/* weight gradients of the pair (+=) straight into the two PyTorch-layout gradients dwa [co_a][ci][3][3][3], dwb [co_b][ci][3][3][3]
+ * and dba / dbb; ws: ltu_wgrad_ws_floats(B*H*W*D, N0+N1, 27*C) floats (one pass over x for both) or NULL. */
+int ltu_conv3d_pair_wgrad(const void* g0, const void* g1, const void* x, float* dwa, float* dba, float* dwb, float* dbb, int B,
+                          int H, int W, int D, int C, int N0, int N1, int co_a, int co_b, int ci, float* ws, int dtype,
+                          ltu_stream_t s);
 /* data gradient: g [B,Ho,Wo,Do,Co], wd [C0+C1][27][Co] -> dx0 [B,Hl,Wl,Dl,C0] (+ dx1 [..,C1]); (Hl,Wl,Dl)
  * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
 int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,

@@ -36,6 +36,7 @@ SIGNATURES = {
     'ltu_conv3d_ws_floats': [I, I, I, I, I, I],
     'ltu_conv3d_pair_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, P, I, P],
     'ltu_conv3d_pair_dgrad': [P, P, P, P, I, I, I, I, I, I, I, P, I, P],
+    'ltu_conv3d_pair_wgrad': [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_affine_sample': [P, P, P, I, I, I, I, P],

@@ -548,7 +548,9 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (h < a.H && w < a.W && d < a.D && n < a.N) {
         const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
-        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.grad) + vox * a.ldg + n);
+        const uint16_t* gp = (a.grad1 != nullptr && n >= a.gn0) ? reinterpret_cast<const uint16_t*>(a.grad1) + vox * a.ldg1 + (n - a.gn0)
+                                                                 : reinterpret_cast<const uint16_t*>(a.grad) + vox * a.ldg + n;
+        v = *reinterpret_cast<const uint4*>(gp);
       }
       greg[p] = v;
     }
@@ -638,6 +640,7 @@ long long conv_wgrad_halo_ws_floats(int N, int K) {
 // fills part/bpart/npad/kpad/splits; returns LTU_OK after launching, or 1 when the shape is not handled
 int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
   if (!whalo_shape_ok(a.C, a.N) || a.c0 % 8 || a.lda0 % 8 || a.lda1 % 8 || a.ldg % 8) return 1;
+  if (a.grad1 != nullptr && (a.gn0 % 8 || a.ldg1 % 8)) return 1;
   if (a.H < 2 || a.W < 2 || a.D < 4) return 1;
   a.CC = a.C % 32 == 0 ? 32 : 16;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);

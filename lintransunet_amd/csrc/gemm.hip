@@ -701,6 +701,41 @@ extern "C" int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void*
   return LTU_E_DTYPE;
 }
 
+// weight gradients of a conv pair from ONE pass over x (bf16 halo path): the gradient tile is the virtual concat of g0 / g1;
+// rows [0, co_a) land in dwa [co_a][ci][27], rows [N0, N0 + co_b) in dwb.  Other dtypes / shapes: two ordinary calls.
+extern "C" int ltu_conv3d_pair_wgrad(const void* g0, const void* g1, const void* x, float* dwa, float* dba, float* dwb,
+                                     float* dbb, int B, int H, int W, int D, int C, int N0, int N1, int co_a, int co_b, int ci,
+                                     float* ws, int dtype, ltu_stream_t s) {
+  if (dtype == LTU_BF16 && ws != nullptr && use_halo()) {
+    WGradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    int Ho, Wo, Do;
+    int rc = conv_fwd_desc(wa.g, B, H, W, D, C, 0, N0 + N1, 1, 1, 1, 0, &Ho, &Wo, &Do);
+    if (rc) return rc;
+    wa.g.a0 = x; wa.g.a1 = x;
+    wa.dw = dwa; wa.db = dba; wa.t_co = co_a; wa.t_ci = ci;
+    wa.dw2 = dwb; wa.db2 = dbb; wa.n0_2 = N0; wa.t_co2 = co_b;
+    wa.part = ws; wa.nseg_w = 1;
+    WHaloArgs h;
+    memset(&h, 0, sizeof(h));
+    h.x0 = x; h.x1 = x; h.grad = g0; h.grad1 = g1; h.gn0 = N0; h.ldg1 = N1;
+    h.B = B; h.H = H; h.W = W; h.D = D;
+    h.C = C; h.c0 = C; h.lda0 = C; h.lda1 = C;
+    h.N = N0 + N1; h.ldg = N0; h.part = ws;
+    int nsplit = 0;
+    const int hr = launch_conv_wgrad_halo_bf16(h, &nsplit, (hipStream_t)s);
+    if (hr == LTU_OK) {
+      wa.npad = N0 + N1; wa.kpad = 27 * C;
+      wa.bpart = ws + (long long)nsplit * wa.npad * wa.kpad;
+      return launch_wgrad_reduce(wa, nsplit, (hipStream_t)s);
+    }
+    if (hr != 1) return hr;
+  }
+  int rc = ltu_conv3d_wgrad(g0, x, nullptr, dwa, dba, B, H, W, D, C, 0, N0, 1, 1, 1, 0, co_a, ci, ws, dtype, s);
+  if (rc) return rc;
+  return ltu_conv3d_wgrad(g1, x, nullptr, dwb, dbb, B, H, W, D, C, 0, N1, 1, 1, 1, 0, co_b, ci, ws, dtype, s);
+}
+
 // fp32 launchers for the other translation units (upconv.hip)
 int launch_nt_f32(const IGemmArgs& g, hipStream_t st) { return launch_nt<float, float>(g, st); }
 int launch_tn_f32(WGradArgs& wa, hipStream_t st) { return launch_tn<float>(wa, st); }

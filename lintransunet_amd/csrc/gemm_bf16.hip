@@ -558,6 +558,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
     if (wa.t_co) {
       const int slot = k / g.C, c = k - slot * g.C;
       if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
+      else if (wa.dw2 != nullptr && n >= wa.n0_2 && n - wa.n0_2 < wa.t_co2 && c < wa.t_ci)
+        wa.dw2[((long long)(n - wa.n0_2) * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
     } else if (wa.nseg_w > 1) {
       const int nper = g.N / wa.nseg_w, seg = n / nper;
       wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
@@ -570,6 +572,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
     if (wa.dbseg[seg]) wa.dbseg[seg][n - seg * nper] += v;
   } else if (wa.db && n < (wa.t_co ? wa.t_co : g.N)) {
     wa.db[n] += v;
+  } else if (wa.db2 != nullptr && n >= wa.n0_2 && n - wa.n0_2 < wa.t_co2) {
+    wa.db2[n - wa.n0_2] += v;
   }
 }
 

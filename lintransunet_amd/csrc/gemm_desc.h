@@ -60,6 +60,10 @@ struct WGradArgs {
   float* part;
   float* bpart;
   int npad, kpad;
+  // second PyTorch-layout conv gradient (conv pairs): rows [n0_2, n0_2 + t_co2) of the tile go to dw2 [t_co2][t_ci][27] / db2
+  float* dw2;
+  float* db2;
+  int n0_2, t_co2;
   float* dwseg[3];    // gradient blocks of N/nseg_w rows each (fused q,k,v projections)
   float* dbseg[3];
   int nseg_w;
@@ -119,6 +123,8 @@ struct WHaloArgs {
   const void* x0;
   const void* x1;
   const void* grad;     // [voxels][ldg]
+  const void* grad1;    // optional second gradient source: columns [gn0, N) come from grad1 [voxels][ldg1] (conv pairs)
+  int gn0, ldg1;
   int B, H, W, D;
   int C, c0, lda0, lda1;
   int N, ldg;

@@ -421,14 +421,14 @@ class _Conv3dPair(torch.autograd.Function):
             dx = torch.empty_like(x)
             ws = _conv_ws(B, H, W, D, n0 + n1, C, x)
             _lib.call('ltu_conv3d_pair_dgrad', _p(g0), _p(g1), _p(prep.wd), _p(dx), B, H, W, D, C, n0, n1, _p(ws), dt, _s())
-        outs = []
-        for g, w, b, cop in ((g0, wa, ba, n0), (g1, wb, bb, n1)):
-            dw, fw = _grad_buf(w)
-            db, fb = _grad_buf(b)
-            ws = _wgrad_ws(g.numel() // cop, cop, 27 * C, x)
-            _lib.call('ltu_conv3d_wgrad', _p(g), _p(x), 0, _p(dw), _p(db), B, H, W, D, C, 0, cop, 1, 1, 1, 0, w.shape[0], w.shape[1],
-                      _p(ws), dt, _s())
-            outs += [_grad_done(w, dw, fw), _grad_done(b, db, fb)]
+        dwa, fwa = _grad_buf(wa)
+        dba, fba = _grad_buf(ba)
+        dwb, fwb = _grad_buf(wb)
+        dbb, fbb = _grad_buf(bb)
+        ws = _wgrad_ws(g0.numel() // n0, n0 + n1, 27 * C, x)
+        _lib.call('ltu_conv3d_pair_wgrad', _p(g0), _p(g1), _p(x), _p(dwa), _p(dba), _p(dwb), _p(dbb), B, H, W, D, C, n0, n1,
+                  wa.shape[0], wb.shape[0], wa.shape[1], _p(ws), dt, _s())
+        outs = [_grad_done(wa, dwa, fwa), _grad_done(ba, dba, fba), _grad_done(wb, dwb, fwb), _grad_done(bb, dbb, fbb)]
         return (dx, *outs, None)
 
 
