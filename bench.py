@@ -202,7 +202,7 @@ def main():
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
         out = {
-            'metric': '128^3 CT patches/sec (fwd+bwd)', 'value': patches / dt, 'unit': 'patches/s', 'n_gpus': world,
+            'metric': f'{args.size}^3 CT patches/sec (fwd+bwd)', 'value': patches / dt, 'unit': 'patches/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
