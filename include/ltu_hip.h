@@ -105,6 +105,9 @@ int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* 
  * small grid (the deep U-Net levels) split its input channels over several workgroups per tile; 0 when the shape does not
  * split.  (B,H,W,D) = the conv's output grid, C = input channels of the call (Co for the data gradient), Co = its outputs. */
 long long ltu_conv3d_ws_floats(int B, int H, int W, int D, int C, int Co);
+/* the same for the gather implicit GEMMs (strided convs: M output voxels, N = Co, K = 27*C; ltu_upconv_dgrad: M = B*H*W*D,
+ * N = Ci, K = 64*Co): floats of workspace that let a small grid split its K loop, 0 when it does not split */
+long long ltu_igemm_ws_floats(long long M, int N, int K);
 /* Two stride-1 convs over the same input in one pass (a decoder level's conv1 and its mask head read the same upsampled tensor:
  * model/Unet_3Dblock.py:1353 + 1380): wf [N0+N1][27][C], bias [N0+N1]; columns [0,N0) -> y0 [..,N0], the rest -> y1 [..,N1].
  * Data gradient of the pair: g0 [..,N0] and g1 [..,N1] read as one virtual concat against wd [C][27][N0+N1] -> dx [..,C]
@@ -134,7 +137,7 @@ int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, 
  * convs on the low-res grid with pre-summed weights (ltu_weight_prep kinds 5 / 6).  x [B,H,W,D,Ci] -> y [B,2H,2W,2D,Co]. */
 int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bias, void* y, int B, int H, int W, int D, int Ci, int Co,
                    int dtype, ltu_stream_t s);
-int ltu_upconv_dgrad(const void* g, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co, int dtype,
+int ltu_upconv_dgrad(const void* g, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co, float* ws, int dtype,
                      ltu_stream_t s);
 /* dweff: zero-filled scratch [8][Co][8][Ci] fp32; dw_torch [co_real][ci_real][3][3][3] += and db[Co] += ;
  * ws: optional ltu_wgrad_ws_floats(B*H*W*D, Co, 8*Ci) floats (bf16 two-stage reduction) */

@@ -46,7 +46,8 @@ SIGNATURES = {
     'ltu_weight_prep_chunks': [P, P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],
     'ltu_upconv_fwd': [P, P, P, P, I, I, I, I, I, I, I, P],
-    'ltu_upconv_dgrad': [P, P, P, I, I, I, I, I, I, I, P],
+    'ltu_upconv_dgrad': [P, P, P, I, I, I, I, I, I, P, I, P],
+    'ltu_igemm_ws_floats': [L, I, I],
     'ltu_upconv_wgrad': [P, P, P, P, P, I, I, P, I, I, I, I, I, I, I, P],
     'ltu_linattn_splits': [I, I],
     'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],

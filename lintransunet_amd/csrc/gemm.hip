@@ -474,6 +474,7 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
       const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
       if (hr != 1) return hr;
     }
+    g.part = ws;                           // strided / upsampling convs on small grids split their K loop
     return launch_nt_bf16(g, (hipStream_t)s);
   }
   if (dtype != LTU_F32) return LTU_E_DTYPE;
@@ -481,8 +482,10 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
 }
 
 extern "C" long long ltu_conv3d_ws_floats(int B, int H, int W, int D, int C, int Co) {
-  return conv_halo_ws_floats(B, H, W, D, C, Co);
+  const long long halo = conv_halo_ws_floats(B, H, W, D, C, Co), ig = igemm_nt_ws_floats((long long)B * H * W * D, Co, 27 * C);
+  return halo > ig ? halo : ig;
 }
+extern "C" long long ltu_igemm_ws_floats(long long M, int N, int K) { return igemm_nt_ws_floats(M, N, K); }
 
 extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi,
                                 int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co,

@@ -147,9 +147,15 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = (g.K + BK - 1) / BK;
+  int nkt = (g.K + BK - 1) / BK;
+  int kt0 = 0;
+  if (g.part != nullptr) {                 // split over K: this workgroup's tile range
+    kt0 = (int)blockIdx.z * g.kt_per_split;
+    const int kt1 = kt0 + g.kt_per_split < nkt ? kt0 + g.kt_per_split : nkt;
+    nkt = kt1 > kt0 ? kt1 - kt0 : 0;
+  }
   // every load of this thread sits at the same k offset inside a tile (NT % CPRK == 0): one cursor
-  KCur cur = kcur_init(g, (tid % CPRK) * 8);
+  KCur cur = kcur_init(g, kt0 * BK + (tid % CPRK) * 8);
   const uint16_t* wrow[LB];
 #pragma unroll
   for (int p = 0; p < LB; ++p) {
@@ -244,6 +250,21 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
     }
   }
 
+  if (g.part != nullptr) {                 // fp32 partial tile (folded by igemm_fold_kernel)
+    float* pz = g.part + (long long)blockIdx.z * g.M * g.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n_blk + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long m = m_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M && n < g.N) pz[m * g.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   // epilogue: bias, convert, stage the BM x BN tile in LDS, then whole-vector stores
   uint16_t* Cs = smem;   // [BM][LDC]
   const int nper = g.N / g.nseg;
@@ -305,6 +326,52 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
   }
 }
 
+// out[m][n] = bf16(sum_z part[z][m][n] + bias[n]) for the K-split launches (out_identity, N % 4 == 0)
+__global__ void __launch_bounds__(256) igemm_fold_kernel(const IGemmArgs g) {
+  const int nq = g.N / 4;
+  const long long total = g.M * nq;
+  const int nper = g.N / g.nseg;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long m = t / nq;
+    const int n = (int)(t - m * nq) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int seg = (n + e) / nper;
+      v[e] = g.bias[seg] ? g.bias[seg][n + e - seg * nper] : 0.f;
+    }
+    for (int z = 0; z < g.ksplit; ++z) {
+      const float4 q = *reinterpret_cast<const float4*>(g.part + ((long long)z * g.M + m) * g.N + n);
+      v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+    }
+    uint2 pk;
+    pk.x = pack_bf16x2(v[0], v[1]);
+    pk.y = pack_bf16x2(v[2], v[3]);
+    uint16_t* dst = n < g.n0 ? reinterpret_cast<uint16_t*>(g.o0) + out_voxel_b(g, m) * g.ldo0 + n
+                             : reinterpret_cast<uint16_t*>(g.o1) + out_voxel_b(g, m) * g.ldo1 + (n - g.n0);
+    *reinterpret_cast<uint2*>(dst) = pk;
+  }
+}
+
+// split geometry of the N > 64 configuration (64 x 128 tiles, BK 64): only grids that leave the chip mostly idle
+static int nt_split(long long M, int N, int K, int* kps) {
+  if (N <= 64) return 1;
+  const long long blocks = ((M + 63) / 64) * ((N + 127) / 128);
+  const int nkt = (K + 63) / 64;
+  if (blocks > 300 || nkt < 16) return 1;
+  int want = (int)((640 + blocks - 1) / blocks);
+  if (want > 8) want = 8;
+  if (want > nkt / 8) want = nkt / 8;
+  if (want < 2) return 1;
+  *kps = (nkt + want - 1) / want;
+  return (nkt + *kps - 1) / *kps;
+}
+long long igemm_nt_ws_floats(long long M, int N, int K) {
+  int kps = 0;
+  const int ks = nt_split(M, N, K, &kps);
+  return ks > 1 ? (long long)ks * M * N : 0;
+}
+
 // tuning override for experiments: LTU_NT_VARIANT = 0 (auto) | 1 (BK 32, 2 buffers) | 2 (BK 64, 2 buffers) | 3 (BK 128, 1 buffer)
 static int nt_variant() {
   static int v = -1;
@@ -345,6 +412,21 @@ int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
   }
   static int small_tile = -1;
   if (small_tile < 0) { const char* e = getenv("LTU_NT_SMALLTILE"); small_tile = e ? atoi(e) : 0; }
+  if (g.part != nullptr) {                   // K split (workspace given by the caller): 64 x 128 tiles, BK 64
+    int kps = 0;
+    const bool ok = g.out_identity && !g.accum && g.N % 4 == 0 && g.n0 % 4 == 0 && !getenv("LTU_NO_NT_SPLIT");
+    const int ks = ok ? nt_split(g.M, g.N, g.K, &kps) : 1;
+    if (ks > 1) {
+      g.ksplit = ks; g.kt_per_split = kps;
+      dim3 grid(cdiv(g.M, 64), cdiv(g.N, 128), ks);
+      hipLaunchKernelGGL((igemm_nt_bf16_kernel<2, 2, 1, 2, 64, 2>), grid, dim3(256), 0, st, g);
+      long long fb = (g.M * (g.N / 4) + 255) / 256;
+      if (fb > 2048) fb = 2048;
+      hipLaunchKernelGGL(igemm_fold_kernel, dim3((unsigned)fb), dim3(256), 0, st, g);
+      return ltu_check_launch();
+    }
+    g.part = nullptr;
+  }
   if (g.N > 64) {
     if (small_tile == 2) launch_nt_cfg<2, 2, 1, 1>(g, st);
     else if (small_tile == 3) launch_nt_cfg<2, 2, 2, 2>(g, st);

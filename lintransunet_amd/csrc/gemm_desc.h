@@ -30,7 +30,12 @@ struct IGemmArgs {
   int ldo0, ldo1;
   int accum;         // != 0: add to the existing output instead of overwriting
   int dbg;           // experiments only: 1 = skip output stores, 2 = skip matrix work, 4 = skip A loads
+  // split over K for small grids with long K loops (bf16 NT kernel): workgroup z handles K tiles [z*kt_per_split, ...) and
+  // stores its fp32 tile to part[z][M][N]; igemm_fold_kernel adds the splits and the bias.  part == nullptr: no split.
+  float* part;
+  int ksplit, kt_per_split;
 };
+long long igemm_nt_ws_floats(long long M, int N, int K);
 
 struct RowCoord {
   int b, h, w, d;

@@ -74,7 +74,7 @@ extern "C" int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bi
 
 // dx[v] = sum over (class, slot) of g[2v + (p - 2 off)] . Weff[class][slot]^T      (wsub_d [Ci][64][Co])
 extern "C" int ltu_upconv_dgrad(const void* grad, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co,
-                                int dtype, ltu_stream_t s) {
+                                float* ws, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
   IGemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -97,6 +97,7 @@ extern "C" int ltu_upconv_dgrad(const void* grad, const void* wsub_d, void* dx, 
   g.w[0] = wsub_d;
   g.out_identity = 1;
   g.n0 = Ci; g.o0 = dx; g.o1 = dx; g.ldo0 = Ci; g.ldo1 = Ci;
+  g.part = dtype == LTU_BF16 ? ws : nullptr;     // small grids split the 64*Co-long K loop (ltu_igemm_ws_floats(B*H*W*D, Ci, 64*Co))
   return run_nt(g, dtype, (hipStream_t)s);
 }
 

@@ -297,7 +297,7 @@ class _Conv3d(torch.autograd.Function):
         Hl, Wl, Dl = (2 * Hi, 2 * Wi, 2 * Di) if ups else (Hi, Wi, Di)
         Ho, Wo, Do = (Hl - 1) // sh + 1, (Wl - 1) // sw + 1, (Dl - 1) // sd + 1
         y = torch.empty((B, Ho, Wo, Do, cop), device=dev, dtype=x0.dtype)
-        ws = _conv_ws(B, Ho, Wo, Do, CiP, cop, x0) if (sh, sw, sd) == (1, 1, 1) and not ups else None
+        ws = _conv_ws(B, Ho, Wo, Do, CiP, cop, x0)
         _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias_p), _p(y), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
                   int(ups), _p(ws), _dt(x0), _s())
         ctx.save_for_backward(x0, x1)
@@ -490,7 +490,9 @@ class _UpConv3d(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, dt, _s())
+            nws = _lib.load().ltu_igemm_ws_floats(B * H * W * D, Ci, 64 * Co) if x.dtype == torch.bfloat16 else 0
+            wsd = torch.empty(nws, device=x.device, dtype=torch.float32) if nws > 0 else None
+            _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, _p(wsd), dt, _s())
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
         dweff = scratch_zeros((8, Co, 8, Ci), x.device)
