@@ -252,6 +252,23 @@ __global__ void head_softmax_bwd_kernel(const float* __restrict__ dp, const floa
     for (int c = 0; c < CP; ++c) st1<T>(dz + m * CP + c, c < C ? p[m * C + c] * (dp[m * C + c] - dot) : 0.f);
   }
 }
+// bf16 rows of CP = 8k padded logits: one 16-byte store per 8 channels (the fused conv pairs pad the heads to 16 / 32 columns)
+__global__ void head_softmax_bwd_bf16x8_kernel(const float* __restrict__ dp, const float* __restrict__ p, uint4* __restrict__ dz,
+                                               long long M, int C, int CP) {
+  const int v8 = CP / 8;
+  GRID_STRIDE(i, M * v8) {
+    const long long m = i / v8;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (i - m * v8 == 0) {
+      float dot = 0.f, g[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < C; ++c) dot += dp[m * C + c] * p[m * C + c];
+      for (int c = 0; c < C; ++c) g[c] = p[m * C + c] * (dp[m * C + c] - dot);
+      o.x = pack_bf16x2(g[0], g[1]);
+      o.y = pack_bf16x2(g[2], g[3]);
+    }
+    dz[i] = o;
+  }
+}
 extern "C" int ltu_head_softmax_fwd(const void* z, float* p, long long M, int C, int CP, int dtype, ltu_stream_t s) {
   if (C > 4 || CP < C) return LTU_E_SHAPE;
   LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((head_softmax_fwd_kernel<T>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, M, C, CP); });
@@ -260,6 +277,10 @@ extern "C" int ltu_head_softmax_fwd(const void* z, float* p, long long M, int C,
 extern "C" int ltu_head_softmax_bwd(const float* dp, const float* p, void* dz, long long M, int C, int CP, int dtype,
                                     ltu_stream_t s) {
   if (C > 4 || CP < C) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && CP % 8 == 0 && ((uintptr_t)dz & 15) == 0) {
+    hipLaunchKernelGGL(head_softmax_bwd_bf16x8_kernel, dim3(sgrid(M * (CP / 8))), dim3(256), 0, (hipStream_t)s, dp, p, (uint4*)dz, M, C, CP);
+    return ltu_check_launch();
+  }
   LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((head_softmax_bwd_kernel<T>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, M, C, CP); });
   return ltu_check_launch();
 }
