@@ -179,14 +179,17 @@ __global__ void roi_plan_kernel(const RoiArgs a, const int* __restrict__ hist) {
     quantiles(hy, a.W, &lo, &hi, &c);
     fit_extent(lo, hi, c, a.W, a.min_w, &bx[1], &bx[3]);
     float* o = a.box + b * 6;
+    if (blockIdx.y == 0) {
     o[0] = bx[0]; o[1] = bx[1]; o[2] = 0.f; o[3] = bx[2]; o[4] = bx[3]; o[5] = (float)(a.D - 1);
+    }
   }
   __syncthreads();
   const float x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
-  build_axis(a.fh, b, true, x0, x1, a.H - 1, a.h_roi, a.eval_h);
-  build_axis(a.fw, b, true, y0, y1, a.W - 1, a.w_roi, a.eval_w);
-  build_axis(a.bh, b, false, x0, x1, a.H - 1, a.h_roi, a.eval_h);
-  build_axis(a.bw, b, false, y0, y1, a.W - 1, a.w_roi, a.eval_w);
+  // grid (B, 4): every workgroup derives the box (cheap) and builds one of the four axis plans
+  if (blockIdx.y == 0) build_axis(a.fh, b, true, x0, x1, a.H - 1, a.h_roi, a.eval_h);
+  else if (blockIdx.y == 1) build_axis(a.fw, b, true, y0, y1, a.W - 1, a.w_roi, a.eval_w);
+  else if (blockIdx.y == 2) build_axis(a.bh, b, false, x0, x1, a.H - 1, a.h_roi, a.eval_h);
+  else build_axis(a.bw, b, false, y0, y1, a.W - 1, a.w_roi, a.eval_w);
 }
 
 // plan buffers: ints  = [src0 B*ND | cnt B*NS | lidx B*NS*L],  floats = [wt B*ND*2 | lw B*NS*L],  L = 2*ND
@@ -236,71 +239,74 @@ extern "C" int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C
   const long long n = (long long)H * W * D;
   const int nblk = (int)(n / 4096 < 1 ? 1 : (n / 4096 > 256 ? 256 : n / 4096));
   hipLaunchKernelGGL(roi_hist_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)s, prob, H, W, D, C, thr, hist);
-  hipLaunchKernelGGL(roi_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a, (const int*)hist);
+  hipLaunchKernelGGL(roi_plan_kernel, dim3(B, 4), dim3(256), 0, (hipStream_t)s, a, (const int*)hist);
   return ltu_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ resamplers
 // dst[b,i,j,d,:] = sum_{a,e} wh[i][a] ww[j][e] src[b, h0(i)+a, w0(j)+e, d, :]
+// grid (blocks, B * ND_h): the (b, i) row of the destination comes from blockIdx.y (its h taps are hoisted), threads walk
+// (j, d, channel quad) with 32-bit arithmetic.
 template <typename T>
-__global__ void plan_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const AxisPlan ph, const AxisPlan pw, int B,
-                                   int D, int C) {
-  const int cv = C / 4;
-  const long long n = (long long)B * ph.ND * pw.ND * D * cv;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(t % cv);
-    long long r = t / cv;
-    const int d = (int)(r % D); r /= D;
-    const int j = (int)(r % pw.ND); r /= pw.ND;
-    const int i = (int)(r % ph.ND);
-    const int b = (int)(r / ph.ND);
-    const int h0 = ph.src0[(long long)b * ph.ND + i], w0 = pw.src0[(long long)b * pw.ND + j];
-    const float* wh = ph.wt + ((long long)b * ph.ND + i) * 2;
-    const float* ww = pw.wt + ((long long)b * pw.ND + j) * 2;
+__global__ void __launch_bounds__(256) plan_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const AxisPlan ph,
+                                                          const AxisPlan pw, int B, int D, int C) {
+  const unsigned cv = C / 4;
+  const unsigned b = blockIdx.y / (unsigned)ph.ND, i = blockIdx.y - b * (unsigned)ph.ND;
+  const int h0 = ph.src0[b * ph.ND + i];
+  const float wh0 = ph.wt[(b * ph.ND + i) * 2], wh1 = ph.wt[(b * ph.ND + i) * 2 + 1];
+  const int hs0 = min(max(h0, 0), ph.NS - 1), hs1 = min(max(h0 + 1, 0), ph.NS - 1);
+  const unsigned n = (unsigned)pw.ND * D * cv;
+  const T* sb = src + (long long)b * ph.NS * pw.NS * D * C;
+  T* db = dst + (long long)blockIdx.y * n * 4;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const unsigned r = t / cv, v = t - r * cv;
+    const unsigned j = r / (unsigned)D, d = r - j * (unsigned)D;
+    const int w0 = pw.src0[b * pw.ND + j];
+    const float ww0 = pw.wt[(b * pw.ND + j) * 2], ww1 = pw.wt[(b * pw.ND + j) * 2 + 1];
+    const int ws0 = min(max(w0, 0), pw.NS - 1), ws1 = min(max(w0 + 1, 0), pw.NS - 1);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float wgt[4] = {wh0 * ww0, wh0 * ww1, wh1 * ww0, wh1 * ww1};
+    const int hh[4] = {hs0, hs0, hs1, hs1}, wv[4] = {ws0, ws1, ws0, ws1};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float w = wh[a] * ww[e];
-        if (w == 0.f) continue;
-        const int hs = min(max(h0 + a, 0), ph.NS - 1), ws = min(max(w0 + e, 0), pw.NS - 1);
-        const float4 q = Vec4<T>::load(src + ((((long long)b * ph.NS + hs) * pw.NS + ws) * D + d) * C + v * 4);
-        acc.x += q.x * w; acc.y += q.y * w; acc.z += q.z * w; acc.w += q.w * w;
-      }
-    Vec4<T>::store(dst + t * 4, acc);
+    for (int q = 0; q < 4; ++q) {
+      if (wgt[q] == 0.f) continue;
+      const float4 x = Vec4<T>::load(sb + (((long long)hh[q] * pw.NS + wv[q]) * D + d) * C + v * 4);
+      acc.x += x.x * wgt[q]; acc.y += x.y * wgt[q]; acc.z += x.z * wgt[q]; acc.w += x.w * wgt[q];
+    }
+    Vec4<T>::store(db + (long long)t * 4, acc);
   }
 }
 
 // adjoint: dsrc[b,x,y,d,:] = sum_{(i,wi) in list_h(x)} sum_{(j,wj) in list_w(y)} wi wj ddst[b,i,j,d,:]
+// grid (blocks, B * NS_h): row (b, x) from blockIdx.y, its h list hoisted.
 template <typename T>
-__global__ void plan_scatter_kernel(const T* __restrict__ ddst, T* __restrict__ dsrc, const AxisPlan ph, const AxisPlan pw, int B,
-                                    int D, int C) {
-  const int cv = C / 4;
-  const long long n = (long long)B * ph.NS * pw.NS * D * cv;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(t % cv);
-    long long r = t / cv;
-    const int d = (int)(r % D); r /= D;
-    const int y = (int)(r % pw.NS); r /= pw.NS;
-    const int x = (int)(r % ph.NS);
-    const int b = (int)(r / ph.NS);
-    const int nh = ph.cnt[(long long)b * ph.NS + x], nw = pw.cnt[(long long)b * pw.NS + y];
-    const int* lih = ph.lidx + ((long long)b * ph.NS + x) * ph.L;
-    const float* lwh = ph.lw + ((long long)b * ph.NS + x) * ph.L;
-    const int* liw = pw.lidx + ((long long)b * pw.NS + y) * pw.L;
-    const float* lww = pw.lw + ((long long)b * pw.NS + y) * pw.L;
+__global__ void __launch_bounds__(256) plan_scatter_kernel(const T* __restrict__ ddst, T* __restrict__ dsrc, const AxisPlan ph,
+                                                           const AxisPlan pw, int B, int D, int C) {
+  const unsigned cv = C / 4;
+  const unsigned b = blockIdx.y / (unsigned)ph.NS, x = blockIdx.y - b * (unsigned)ph.NS;
+  const int nh = ph.cnt[b * ph.NS + x];
+  const int* lih = ph.lidx + (long long)(b * ph.NS + x) * ph.L;
+  const float* lwh = ph.lw + (long long)(b * ph.NS + x) * ph.L;
+  const unsigned n = (unsigned)pw.NS * D * cv;
+  const T* gb = ddst + (long long)b * ph.ND * pw.ND * D * C;
+  T* ob = dsrc + (long long)blockIdx.y * n * 4;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const unsigned r = t / cv, v = t - r * cv;
+    const unsigned y = r / (unsigned)D, d = r - y * (unsigned)D;
+    const int nw = pw.cnt[b * pw.NS + y];
+    const int* liw = pw.lidx + (long long)(b * pw.NS + y) * pw.L;
+    const float* lww = pw.lw + (long long)(b * pw.NS + y) * pw.L;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = 0; a < nh; ++a) {
       const int i = lih[a];
       const float wi = lwh[a];
       for (int e = 0; e < nw; ++e) {
         const float w = wi * lww[e];
-        const float4 q = Vec4<T>::load(ddst + ((((long long)b * ph.ND + i) * pw.ND + liw[e]) * D + d) * C + v * 4);
+        const float4 q = Vec4<T>::load(gb + (((long long)i * pw.ND + liw[e]) * D + d) * C + v * 4);
         acc.x += q.x * w; acc.y += q.y * w; acc.z += q.z * w; acc.w += q.w * w;
       }
     }
-    Vec4<T>::store(dsrc + t * 4, acc);
+    Vec4<T>::store(ob + (long long)t * 4, acc);
   }
 }
 
@@ -323,11 +329,15 @@ extern "C" int ltu_roi_resample(const void* in, void* out, int* plan_i, float* p
   const AxisPlan& pw = which == 0 ? a.fw : a.bw;
   LTU_DISPATCH_T(dtype, {
     if (!adjoint) {
-      const long long n = (long long)B * ph.ND * pw.ND * D * (C / 4);
-      hipLaunchKernelGGL((plan_gather_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, ph, pw, B, D, C);
+      const long long n = (long long)pw.ND * D * (C / 4);
+      if (n >= (1LL << 31) || (long long)B * ph.ND > 65535) return LTU_E_SHAPE;
+      hipLaunchKernelGGL((plan_gather_kernel<T>), dim3((unsigned)((n + 511) / 512), B * ph.ND), dim3(256), 0, (hipStream_t)s,
+                         (const T*)in, (T*)out, ph, pw, B, D, C);
     } else {
-      const long long n = (long long)B * ph.NS * pw.NS * D * (C / 4);
-      hipLaunchKernelGGL((plan_scatter_kernel<T>), dim3(rgrid(n)), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, ph, pw, B, D, C);
+      const long long n = (long long)pw.NS * D * (C / 4);
+      if (n >= (1LL << 31) || (long long)B * ph.NS > 65535) return LTU_E_SHAPE;
+      hipLaunchKernelGGL((plan_scatter_kernel<T>), dim3((unsigned)((n + 511) / 512), B * ph.NS), dim3(256), 0, (hipStream_t)s,
+                         (const T*)in, (T*)out, ph, pw, B, D, C);
     }
   });
   return ltu_check_launch();
@@ -428,6 +438,51 @@ __global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict_
   }
 }
 
+// The same with the (w, d) candidate lists of the plane built once per workgroup in LDS (W, D <= 256): the kernel above spends
+// ~150 instructions per output vector re-deriving them.
+#define TRI_TAB 256
+template <typename T>
+__global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
+                                                                int D, int C, int Ho, int Wo, int Do, TriScale sc) {
+  __shared__ int t_n[2][TRI_TAB];
+  __shared__ int t_o[2][TRI_TAB][8];
+  __shared__ float t_w[2][TRI_TAB][8];
+  for (int idx = threadIdx.x; idx < W + D; idx += 256) {
+    const int ax = idx < W ? 0 : 1, i = ax ? idx - W : idx;
+    int os[8]; float ws[8];
+    const int n = ax ? tri_cands(i, D, Do, sc.d, sc.id, os, ws) : tri_cands(i, W, Wo, sc.w, sc.iw, os, ws);
+    t_n[ax][i] = n;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { t_o[ax][i][q] = q < n ? os[q] : 0; t_w[ax][i][q] = q < n ? ws[q] : 0.f; }
+  }
+  const unsigned cv = C / 4;
+  const unsigned b = blockIdx.y / (unsigned)H, h = blockIdx.y - b * (unsigned)H;
+  int oh[8];
+  float wh[8];
+  const int nh = tri_cands((int)h, H, Ho, sc.h, sc.ih, oh, wh);
+  __syncthreads();
+  const unsigned n = (unsigned)W * D * cv;
+  const T* gb = dy + (long long)b * Ho * Wo * Do * C;
+  T* xb = dx + ((long long)b * H + h) * n * 4;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const unsigned r = t / cv, v = t - r * cv;
+    const unsigned w = r / (unsigned)D, d = r - w * (unsigned)D;
+    const int nw = t_n[0][w], nd = t_n[1][d];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < nh; ++a)
+      for (int e = 0; e < nw; ++e) {
+        const float whw = wh[a] * t_w[0][w][e];
+        const T* row = gb + ((long long)oh[a] * Wo + t_o[0][w][e]) * Do * C + v * 4;
+        for (int f = 0; f < nd; ++f) {
+          const float wgt = whw * t_w[1][d][f];
+          const float4 q = Vec4<T>::load(row + (long long)t_o[1][d][f] * C);
+          acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
+        }
+      }
+    Vec4<T>::store(xb + (long long)t * 4, acc);
+  }
+}
+
 static float tri_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 static float tri_inv(int in, int out) { return (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1); }
 
@@ -448,8 +503,12 @@ extern "C" int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, i
     } else {
       const long long n = (long long)W * D * (C / 4);
       const unsigned gx = (unsigned)((n + 511) / 512 < 1 ? 1 : (n + 511) / 512);
-      hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W,
-                         D, C, Ho, Wo, Do, sc);
+      if (W <= TRI_TAB && D <= TRI_TAB)
+        hipLaunchKernelGGL((trilinear_bwd_tab_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H,
+                           W, D, C, Ho, Wo, Do, sc);
+      else
+        hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W,
+                           D, C, Ho, Wo, Do, sc);
     }
   });
   return ltu_check_launch();
