@@ -131,6 +131,16 @@ class GradReducer:
             self.flat.append(flat)
         self.pending = [0] * len(self.buckets)
         self.active = False
+        # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) sums and the buckets are divided afterwards
+        self.avg = self.world > 1 and dist.get_backend(group) == 'nccl'
+
+    def _all_reduce(self, flat):
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _finish_bucket(self, flat, handle):
+        handle.wait()
+        if not self.avg:
+            flat.div_(self.world)
 
     def zero_grad(self):
         for f in self.flat:
@@ -148,15 +158,14 @@ class GradReducer:
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.world > 1:
             ops.flush_deferred()            # pending second-stage reductions may still owe this bucket their sums
-            self.handles.append((bi, dist.all_reduce(self.flat[bi], group=self.group, async_op=True)))
+            self.handles.append((bi, self._all_reduce(self.flat[bi])))
 
     def reduce_all(self):
         """all-reduce every bucket now (used after a graph replay, where no hooks run)"""
         if self.world > 1:
-            hs = [dist.all_reduce(f, group=self.group, async_op=True) for f in self.flat]
+            hs = [self._all_reduce(f) for f in self.flat]
             for f, h in zip(self.flat, hs):
-                h.wait()
-                f.div_(self.world)
+                self._finish_bucket(f, h)
 
     def finish(self):
         ops.flush_deferred()                # safety net for callers that ran backward without train_step
@@ -165,10 +174,9 @@ class GradReducer:
             launched = {bi for bi, _ in self.handles}
             for bi in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
                 if bi not in launched:
-                    self.handles.append((bi, dist.all_reduce(self.flat[bi], group=self.group, async_op=True)))
+                    self.handles.append((bi, self._all_reduce(self.flat[bi])))
             for bi, h in self.handles:
-                h.wait()
-                self.flat[bi].div_(self.world)
+                self._finish_bucket(self.flat[bi], h)
         self.handles = []
 
 

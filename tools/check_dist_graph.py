@@ -15,7 +15,8 @@ model = get_model_dict('MaskTransUnet')([8, 8, 8, 16, 32], [20, 12, 9, 10, 6], [
                                         dropout=0.3, act_dtype=torch.bfloat16).to(dev).train()
 train.broadcast_parameters(model)
 reducer = train.GradReducer(model, unused=train.UNUSED_PARAMETERS)
-reducer.world = 2           # force the collective path (sums are then halved: irrelevant here)
+reducer.world = 2           # force the collective path
+reducer.avg = True          # ... with RCCL's in-collective average, as at N > 1
 x = seedgen.seeded_volume((2, 1, 32, 32, 32), 1).to(dev)
 lab = seedgen.seeded_label((2, 1, 32, 32, 32), 2).to(dev)
 step = train.GraphedStep(model, x, lab, O_step.dynamic_weights(0), reducer)
