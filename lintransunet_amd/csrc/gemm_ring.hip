@@ -25,6 +25,14 @@ __device__ __forceinline__ void glds16(const uint16_t* src, uint16_t* lds_wave_b
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
+// 4-byte variant: lane l lands at M0 + 4 l (used for the bias row of the projection kernel)
+__device__ __forceinline__ void glds4(const float* src, float* lds_wave_base) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void*)lds_wave_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+__device__ __attribute__((aligned(16))) float ring_zero_f32[4];          // source of absent / out-of-range bias entries
 // retire all but the youngest N LDS-DMA of this wave, then meet the other waves: after it every wave's pieces of the
 // oldest unit have landed and every wave has finished reading the unit before it
 template <int N>
@@ -171,17 +179,18 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
   const int n_blk = blockIdx.y * BN;
   const int nper = g.N / g.nseg;
 
-  if (tid < BN) {
-    const int n = n_blk + tid;
-    float v = 0.f;
+  // The bias row travels by LDS-DMA like everything else: a plain load + ds_write + barrier here would put one full memory
+  // round trip in front of the first asynchronous issue of every launch (~1 us of a 6 us fixed cost).
+  for (int p = wave; p < BN / 64; p += NW) {
+    const int n = n_blk + p * 64 + lane;
+    const float* src = ring_zero_f32;
     if (n < g.N) {
       const int seg = n / nper;
       const float* bp = seg == 0 ? g.bias[0] : (seg == 1 ? g.bias[1] : g.bias[2]);
-      if (bp != nullptr) v = bp[n - seg * nper];
+      if (bp != nullptr) src = bp + (n - seg * nper);
     }
-    bias_l[tid] = v;
+    glds4(src, bias_l + p * 64);
   }
-  __syncthreads();                                          // nothing asynchronous in flight yet
 
   // LDS-DMA piece = 8 rows x 128 B.  Slot = chunk ^ ((row >> 1) & 7): the 16 rows a quarter-wave reads with ds_read_b128 then
   // occupy 16 distinct 16-byte slots of the 256-byte bank row.  Every piece this wave fills has the parity of `wave`.
@@ -221,16 +230,18 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 bias4[TNW][4];                                    // this lane's 4 x 4 consecutive columns of each 32-column tile
-#pragma unroll
-  for (int j = 0; j < TNW; ++j)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) bias4[j][rr] = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
   const int sw = (li >> 1) & 7;
   const int a_off = (wm * 32 * TM + li) * 64, w_off = (wn * 32 * TNW + li) * 64;
   int kc = 0, tile = blockIdx.x;
   bool after_store = false;
   for (int u = 0; u < R - 1 && u < nunits; ++u) issue(u);
+  // bias and weights are older than the R - 1 units just issued: wait for them only (all of it when fewer units exist)
+  if (nunits >= R - 1) ring_sync<PW * (R - 1)>(); else ring_sync<0>();
+  float4 bias4[TNW][4];                                    // this lane's 4 x 4 consecutive columns of each 32-column tile
+#pragma unroll
+  for (int j = 0; j < TNW; ++j)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bias4[j][rr] = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
   for (int q = 0; q < nunits; ++q) {
     if (q + R - 2 < nunits) {
       if (after_store) ring_sync<PW * (R - 2) + S>(); else ring_sync<PW * (R - 2)>();
