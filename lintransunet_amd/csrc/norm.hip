@@ -287,37 +287,60 @@ __global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __r
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One row (d <= 256 channels) per group of d/4 lanes; groups never straddle a wavefront.
 // z = x + drop(r) is written over r; y = (z-mean)*rstd*gamma + beta; stat[row] = {mean, rstd}
-template <typename T, int G>
-__global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ stat,
-                                     long long M, float eps, float p, uint64_t seed, const uint64_t* step) {
-  const int d = G * 4;
+// V = 4-element vectors per lane (d = 4 V G): V = 2 from d = 128 up means 16-byte accesses for bf16 and half the shuffle
+// steps; a workgroup walks `iters` row groups so that a launch is a few thousand workgroups at most.
+template <typename T, int G, int V>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ y, float* __restrict__ stat, long long M, float eps,
+                                                            float p, uint64_t seed, const uint64_t* step, int iters) {
+  constexpr int d = G * 4 * V, E = 4 * V;
   const int gl = threadIdx.x % G;
-  const long long rows_per_block = blockDim.x / G;
-  const long long row = (long long)blockIdx.x * rows_per_block + threadIdx.x / G;
+  const int rows_per_block = 256 / G;
   const DropCfg dc = make_drop(p, seed, step);
-  const bool ok = row < M;
-  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (ok) {
-    const long long e = row * d + gl * 4;
-    z = Vec4<T>::load(x + e);
-    float4 rv = Vec4<T>::load(r + e);
-    rv = drop4(dc, (uint64_t)(e >> 2), rv);
-    z.x += rv.x; z.y += rv.y; z.z += rv.z; z.w += rv.w;
-    Vec4<T>::store(r + e, z);
+  float gm[E], bt[E];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const float4 a = *reinterpret_cast<const float4*>(gamma + gl * E + 4 * v), c = *reinterpret_cast<const float4*>(beta + gl * E + 4 * v);
+    gm[4 * v] = a.x; gm[4 * v + 1] = a.y; gm[4 * v + 2] = a.z; gm[4 * v + 3] = a.w;
+    bt[4 * v] = c.x; bt[4 * v + 1] = c.y; bt[4 * v + 2] = c.z; bt[4 * v + 3] = c.w;
   }
-  const float mean = group_sum<G>(z.x + z.y + z.z + z.w) / (float)d;
-  const float dx0 = z.x - mean, dx1 = z.y - mean, dx2 = z.z - mean, dx3 = z.w - mean;
-  const float var = group_sum<G>(dx0 * dx0 + dx1 * dx1 + dx2 * dx2 + dx3 * dx3) / (float)d;
-  const float rstd = rsqrtf(var + eps);
-  if (ok) {
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
-    const float4 bt = *reinterpret_cast<const float4*>(beta + gl * 4);
-    float4 o = make_float4(dx0 * rstd * gm.x + bt.x, dx1 * rstd * gm.y + bt.y, dx2 * rstd * gm.z + bt.z, dx3 * rstd * gm.w + bt.w);
-    Vec4<T>::store(y + row * d + gl * 4, o);
-    if (gl == 0) {
-      stat[row * 2] = mean;
-      stat[row * 2 + 1] = rstd;
+  for (int it = 0; it < iters; ++it) {
+    const long long row = ((long long)blockIdx.x * iters + it) * rows_per_block + threadIdx.x / G;
+    const bool ok = row < M;
+    float z[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) z[k] = 0.f;
+    const long long e = row * d + gl * E;
+    if (ok) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float4 xv = Vec4<T>::load(x + e + 4 * v);
+        float4 rv = Vec4<T>::load(r + e + 4 * v);
+        rv = drop4(dc, (uint64_t)((e >> 2) + v), rv);
+        z[4 * v] = xv.x + rv.x; z[4 * v + 1] = xv.y + rv.y; z[4 * v + 2] = xv.z + rv.z; z[4 * v + 3] = xv.w + rv.w;
+        Vec4<T>::store(r + e + 4 * v, make_float4(z[4 * v], z[4 * v + 1], z[4 * v + 2], z[4 * v + 3]));
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) sum += z[k];
+    const float mean = group_sum<G>(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) { z[k] -= mean; sq += z[k] * z[k]; }
+    const float var = group_sum<G>(sq) / (float)d;
+    const float rstd = rsqrtf(var + eps);
+    if (ok) {
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+        Vec4<T>::store(y + e + 4 * v, make_float4(z[4 * v] * rstd * gm[4 * v] + bt[4 * v], z[4 * v + 1] * rstd * gm[4 * v + 1] + bt[4 * v + 1],
+                                                   z[4 * v + 2] * rstd * gm[4 * v + 2] + bt[4 * v + 2],
+                                                   z[4 * v + 3] * rstd * gm[4 * v + 3] + bt[4 * v + 3]));
+      if (gl == 0) {
+        stat[row * 2] = mean;
+        stat[row * 2 + 1] = rstd;
+      }
     }
   }
 }
@@ -513,10 +536,12 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
 extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y, float* stat,
                                  long long M, int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   LTU_DISPATCH_T(dtype, {
-    LN_DISPATCH_G(d, {
+    LN_DISPATCH_GV(d, {
       const int rows = 256 / G;
-      hipLaunchKernelGGL((layernorm_fwd_kernel<T, G>), dim3(cdiv(M, rows)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)r,
-                         gamma, beta, (T*)y, stat, M, eps, p, seed, step);
+      const long long groups = (M + rows - 1) / rows;
+      const int iters = (int)((groups + 4095) / 4096 < 1 ? 1 : (groups + 4095) / 4096);
+      hipLaunchKernelGGL((layernorm_fwd_kernel<T, G, V>), dim3((unsigned)((groups + iters - 1) / iters)), dim3(256), 0, (hipStream_t)s,
+                         (const T*)x, (T*)r, gamma, beta, (T*)y, stat, M, eps, p, seed, step, iters);
     });
   });
   return ltu_check_launch();
