@@ -69,6 +69,11 @@ int ltu_weight_prep_chunks(const void* table, const int* chunks, int nchunks, in
  * be NULL.  accumulate != 0 adds to y. */
 int ltu_linear_fwd(const void* a, int lda, const void* const* w, int nw, const float* const* bias, void* y, int ldy,
                    int M, int N, int K, int accumulate, int dtype, ltu_stream_t s);
+/* FFN front half: u [M,N] = a . w^T + bias and h = dropout(gelu(u)) (model/trans_block.py:203-208).  bf16 shapes of the
+ * weight-stationary projection kernel get both from one launch (GELU + dropout in its epilogue); otherwise the projection and
+ * ltu_gelu_dropout_fwd run back to back with identical results.  ltu_gelu_dropout_bwd(dh, u, ...) is the matching backward. */
+int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias, void* u, void* h, int M, int N, int K, float p,
+                        uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* ---- deferred second stage of the two-stage reductions ------------------------------------------
  * ltu_linear_wgrad / ltu_layernorm_bwd can leave the folding of their per-split partial sums to the caller: pass a job
  * record, collect a few, and fold them with ONE launch (ltu_reduce_batch) before the gradients are read.  A record whose

@@ -42,6 +42,7 @@ SIGNATURES = {
     'ltu_affine_sample': [P, P, P, I, I, I, I, P],
     'ltu_zoom_sample': [P, P, P, I, I, I, I, P],
     'ltu_adjust_contrast': [P, P, P, P, I, L, P],
+    'ltu_linear_gelu_fwd': [P, I, P, P, P, P, I, I, I, F, U, P, I, P],
     'ltu_weight_prep': [P, I, I, P],
     'ltu_weight_prep_chunks': [P, P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],

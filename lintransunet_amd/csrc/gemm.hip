@@ -375,6 +375,32 @@ extern "C" int ltu_linear_fwd(const void* a, int lda, const void* const* w, int 
   return launch_nt<float, float>(g, (hipStream_t)s);
 }
 
+// u = a . w^T + bias and h = dropout(gelu(u)) (transformer FFN, model/trans_block.py:203-208).  bf16 shapes the weight-stationary
+// projection kernel handles get both from ONE launch (GELU in its epilogue); everything else runs the projection and
+// ltu_gelu_dropout_fwd back to back, with identical results (the fused epilogue also applies GELU to the bf16-rounded u).
+extern "C" int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+extern "C" int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias, void* u, void* h, int M, int N, int K,
+                                   float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+  if (K % 4 != 0 || lda % 4 != 0) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && !getenv("LTU_NO_GELU_FUSE")) {
+    IGemmArgs g;
+    dense_desc(g, M, N, K);
+    g.a0 = a; g.a1 = a; g.lda0 = lda; g.lda1 = lda;
+    g.nseg = 1; g.w[0] = w; g.bias[0] = bias;
+    g.o0 = u; g.o1 = u; g.ldo0 = N; g.ldo1 = N;
+    g.gelu_out = h; g.drop_p = p; g.drop_seed = seed; g.drop_step = reinterpret_cast<const unsigned long long*>(step);
+    if (g.C % 8 == 0 && g.lda0 % 8 == 0 && g.N % 4 == 0) {
+      const int rr = launch_nt_ring_bf16(g, (hipStream_t)s);
+      if (rr != 1) return rr;
+    }
+  }
+  const void* wl[1] = {w};
+  const float* bl[1] = {bias};
+  const int rc = ltu_linear_fwd(a, lda, wl, 1, bl, u, N, M, N, K, 0, dtype, s);
+  if (rc) return rc;
+  return ltu_gelu_dropout_fwd(u, h, (long long)M * N, p, seed, step, dtype, s);
+}
+
 extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) {
   const long long tn = tn_geometry(M, N, K, 32).ws_floats, halo = conv_wgrad_halo_ws_floats(N, K);
   const long long ring = tn_ring_ws_floats(M, N, K);

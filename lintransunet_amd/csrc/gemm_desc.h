@@ -34,6 +34,12 @@ struct IGemmArgs {
   // stores its fp32 tile to part[z][M][N]; igemm_fold_kernel adds the splits and the bias.  part == nullptr: no split.
   float* part;
   int ksplit, kt_per_split;
+  // fused GELU + dropout epilogue of the weight-stationary projection kernel (transformer FFN: trans_block.py:208): the
+  // pre-activation goes to o0 as usual and h = dropout(gelu(bf16(u))) to gelu_out [M][N]; nullptr: plain projection
+  void* gelu_out;
+  float drop_p;
+  unsigned long long drop_seed;
+  const unsigned long long* drop_step;
 };
 long long igemm_nt_ws_floats(long long M, int N, int K);
 
@@ -147,7 +153,7 @@ int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st);
 bool tn_ring_shape_ok(long long M, int N, int K);
 long long tn_ring_ws_floats(long long M, int N, int K);
 int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out = nullptr);   // LTU_OK / hipError, or 1 = shape not handled
-int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled
+int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled (also: gelu_out set and no ring)
 
 // class convolutions on an LDS halo brick (conv_halo.hip): fine voxel o = m q + p gets sum_e [cls_e == class(p)] x[q + d_e] . W_e^T
 struct ClsEntry {

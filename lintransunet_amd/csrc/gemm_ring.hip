@@ -163,12 +163,12 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
 //     ring slot just consumed (wave-private quarter), 16-byte row-major reads, 16-byte global stores.
 // vmcnt book-keeping: loads and stores retire in order, so the wait after an epilogue allows for its S stores as well
 // (exact only when every store was issued, i.e. for full tiles; otherwise the stricter count is used).
-template <int WM, int TNW, int R>
+template <int WM, int TNW, int R, bool GELU>
 __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmArgs g, int tiles_m) {
   extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
   constexpr int NW = 2 * WM, TM = 4 / WM, BN = 64 * TNW, AUNIT = 128 * 64;
   constexpr int PW = 16 / NW;                               // LDS-DMA pieces of an A unit per wave
-  constexpr int S = 2 * TM * TNW;                           // global stores per wave and tile
+  constexpr int S = 2 * TM * TNW * (GELU ? 2 : 1);          // global stores per wave and tile
   const int KC = g.K >> 6;
   uint16_t* Wl = smem;                                      // [KC][BN][64]
   uint16_t* ring = smem + KC * BN * 64;                     // [R][128][64]
@@ -178,6 +178,8 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
   const int li = lane & 31, lh = lane >> 5;
   const int n_blk = blockIdx.y * BN;
   const int nper = g.N / g.nseg;
+  DropCfg dc;                              // scalar loads only (lgkmcnt): no interference with the vmcnt book-keeping below
+  if constexpr (GELU) dc = make_drop(g.drop_p, (uint64_t)g.drop_seed, reinterpret_cast<const uint64_t*>(g.drop_step));
 
   // The bias row travels by LDS-DMA like everything else: a plain load + ds_write + barrier here would put one full memory
   // round trip in front of the first asynchronous issue of every launch (~1 us of a 6 us fixed cost).
@@ -300,6 +302,22 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
           uint16_t* dst = reinterpret_cast<uint16_t*>(g.o0) + grow * g.ldo0 + gcol;
           if (full) *reinterpret_cast<uint4*>(dst) = v;
           else if (grow < g.M && gcol < g.N) *reinterpret_cast<uint4*>(dst) = v;
+          if constexpr (GELU) {            // h = dropout(gelu(u)) on the bf16-rounded u, as the stand-alone kernel computes it
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f[2 * e] = gelu_erf(__uint_as_float(w4[e] << 16));
+              f[2 * e + 1] = gelu_erf(__uint_as_float(w4[e] & 0xffff0000u));
+            }
+            const unsigned long long g4 = (unsigned long long)(grow * g.N + gcol) >> 2;
+            const float4 ha = drop4(dc, g4, make_float4(f[0], f[1], f[2], f[3]));
+            const float4 hb = drop4(dc, g4 + 1, make_float4(f[4], f[5], f[6], f[7]));
+            const uint4 hv = make_uint4(pack_bf16x2(ha.x, ha.y), pack_bf16x2(ha.z, ha.w), pack_bf16x2(hb.x, hb.y), pack_bf16x2(hb.z, hb.w));
+            uint16_t* hd = reinterpret_cast<uint16_t*>(g.gelu_out) + grow * g.N + gcol;
+            if (full) *reinterpret_cast<uint4*>(hd) = hv;
+            else if (grow < g.M && gcol < g.N) *reinterpret_cast<uint4*>(hd) = hv;
+          }
         }
       }
     kc = 0;
@@ -308,8 +326,8 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
   }
 }
 
-template <int WM, int TNW, int R>
-static int launch_lin_ring(const IGemmArgs& g, hipStream_t st) {
+template <int WM, int TNW, int R, bool GELU>
+static int launch_lin_ring_e(const IGemmArgs& g, hipStream_t st) {
   const int BN = 64 * TNW;
   const int tiles_m = (int)((g.M + 127) / 128), nt = cdiv(g.N, BN);
   int P = 256 / nt;
@@ -319,12 +337,17 @@ static int launch_lin_ring(const IGemmArgs& g, hipStream_t st) {
   const int smem_bytes = BN * g.K * 2 + R * 16384 + BN * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_ring_bf16_kernel<WM, TNW, R>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_ring_bf16_kernel<WM, TNW, R, GELU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((linear_ring_bf16_kernel<WM, TNW, R>), dim3(P, nt), dim3(128 * WM), smem_bytes, st, g, tiles_m);
+  hipLaunchKernelGGL((linear_ring_bf16_kernel<WM, TNW, R, GELU>), dim3(P, nt), dim3(128 * WM), smem_bytes, st, g, tiles_m);
   return ltu_check_launch();
+}
+template <int WM, int TNW, int R>
+static int launch_lin_ring(const IGemmArgs& g, hipStream_t st) {
+  if (g.gelu_out != nullptr) return launch_lin_ring_e<WM, TNW, R, true>(g, st);
+  return launch_lin_ring_e<WM, TNW, R, false>(g, st);
 }
 
 static bool ring_enabled();
@@ -335,6 +358,7 @@ int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st) {
   if (w8 < 0) { const char* e = getenv("LTU_NT_RING_WAVES"); w8 = (e && atoi(e) == 4) ? 0 : 1; }
   if (!on || !ring_enabled()) return 1;
   if (g.ntaps != 1 || g.K != g.C || g.c0 != g.C || !g.out_identity || g.accum || g.n0 != g.N || g.dbg) return 1;
+  if (g.gelu_out != nullptr && (g.nseg != 1 || g.ldo0 != g.N || ((uintptr_t)g.gelu_out & 15))) return 1;
   if (g.K % 64 || g.K > 768 || g.N % 8 || g.N < 96 || g.M < 512 || g.lda0 % 8 || g.ldo0 % 8 || g.N % g.nseg) return 1;
   uintptr_t al = (uintptr_t)g.a0 | (uintptr_t)g.o0;
   for (int i = 0; i < g.nseg; ++i) al |= (uintptr_t)g.w[i];
@@ -343,6 +367,13 @@ int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st) {
   if (tnw1_below < 0) { const char* e = getenv("LTU_NT_RING_TNW1_BELOW"); tnw1_below = e ? atoi(e) : 2048; }     // few row tiles: narrower column tiles spread them over more workgroups
   if (w8) {
     if (g.K <= 256 && g.M < tnw1_below) return launch_lin_ring<4, 1, 4>(g, st);
+    if (g.gelu_out != nullptr && g.K <= 256) {
+      // the GELU epilogue is a long VALU phase during which nothing is issued: a deeper ring keeps loads in flight across it
+      static int deep = -1;
+      if (deep < 0) { const char* e = getenv("LTU_GELU_RING_DEEP"); deep = e ? atoi(e) : 1; }
+      if (deep && g.K <= 128) return launch_lin_ring_e<4, 2, 6, true>(g, st);
+      if (deep) return launch_lin_ring_e<4, 2, 5, true>(g, st);
+    }
     if (g.K <= 256) return launch_lin_ring<4, 2, 4>(g, st);
     if (g.K <= 384) return launch_lin_ring<4, 2, 3>(g, st);
     if (g.K <= 512) return launch_lin_ring<4, 1, 4>(g, st);

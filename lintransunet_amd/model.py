@@ -280,8 +280,7 @@ class MaskTransUnet(nn.Module):
         a = ops.linear(a, [lin[3].weight], [lin[3].bias], prep=wl[(id(lay), 'o')])
         t, tres = ops.res_layernorm(tres, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0,
                                     fork=True)
-        f = ops.linear(t, [lay.linear1.weight], [lay.linear1.bias], prep=wl[(id(lay), 'f1')])
-        f = ops.gelu_dropout(f, p, seeds.next() if p > 0 else 0)
+        f = ops.linear_gelu(t, lay.linear1.weight, lay.linear1.bias, p, seeds.next() if p > 0 else 0, prep=wl[(id(lay), 'f1')])
         f = ops.linear(f, [lay.linear2.weight], [lay.linear2.bias], prep=wl[(id(lay), 'f2')])
         out = ops.res_layernorm(tres, f, lay.layer_norm2.weight, lay.layer_norm2.bias, 1e-6, p, seeds.next() if p > 0 else 0,
                                 fork=not last)

@@ -567,6 +567,53 @@ def linear(x, weights, biases, prep=None):
     return _Linear.apply(x, prep, *weights, *biases)
 
 
+class _LinearGelu(torch.autograd.Function):
+    """h = dropout(gelu(x . W^T + b)): the FFN front half of a transformer layer (model/trans_block.py:203-208) in one launch
+    where the projection kernel can carry GELU in its epilogue; backward = GELU backward, then the projection's backward."""
+
+    @staticmethod
+    def forward(ctx, x, prep, w, b, p, seed):
+        _chk(x, 'x')
+        M, K = x.shape
+        N = w.shape[0]
+        u = torch.empty((M, N), device=x.device, dtype=x.dtype)
+        h = torch.empty((M, N), device=x.device, dtype=x.dtype)
+        wop = prep.w[0] if prep is not None else _w_operand(w, x.dtype)
+        _lib.call('ltu_linear_gelu_fwd', _p(x), K, _p(wop), _p(b), _p(u), _p(h), M, N, K, float(p), seed, _step_ptr(), _dt(x), _s())
+        ctx.save_for_backward(x, u)
+        ctx.params = (w, b)
+        ctx.prep = prep
+        ctx.cfg = (p, seed)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        x, u = ctx.saved_tensors
+        w, b = ctx.params
+        p, seed = ctx.cfg
+        gh = gh.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dev, dt = x.device, _dt(x)
+        g = torch.empty_like(u)
+        _lib.call('ltu_gelu_dropout_bwd', _p(gh), _p(u), _p(g), u.numel(), float(p), seed, _step_ptr(), dt, _s())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ctx.prep.wt if ctx.prep is not None else _w_transposed([w], N, K, x.dtype)
+            dx = torch.empty((M, K), device=dev, dtype=x.dtype)
+            _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
+        dw, fw = _grad_buf(w)
+        db, fb = _grad_buf(b)
+        wsb = _wgrad_ws(M, N, K, x)
+        _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
+        return dx, None, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
+
+
+def linear_gelu(x, weight, bias, p=0.0, seed=0, prep=None):
+    """dropout(gelu(x . weight^T + bias)) for x [M,K]"""
+    return _LinearGelu.apply(x, prep, weight, bias, p, seed)
+
+
 # ---------------------------------------------------------------------------------------------- norms
 
 class _InstNormAct(torch.autograd.Function):
