@@ -266,19 +266,22 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
       for (int j = 0; j < TNW; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(Ws + j * 32 * 64 + co);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (!(g.dbg & 2)) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (++kc < KC) continue;
 
     // ---- tile finished: stage 32 x 32 sub-tiles through this unit's slot (every wave is done with it after the barrier)
     asm volatile("s_barrier" ::: "memory");
     uint16_t* stg = ring + (q % R) * AUNIT + wave * 1024;    // wave-private [32][32] bf16, 4 chunks per row
-    const bool full = (long long)(tile + 1) * 128 <= g.M && n_blk + BN <= g.N;
+    const bool full = (long long)(tile + 1) * 128 <= g.M && n_blk + BN <= g.N && !(g.dbg & 1);
+    const long long Meff = (g.dbg & 1) ? 0 : g.M;          // ablation: no global stores
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
           const int gcol = n_blk + wn * 32 * TNW + j * 32 + ch * 8;
           uint16_t* dst = reinterpret_cast<uint16_t*>(g.o0) + grow * g.ldo0 + gcol;
           if (full) *reinterpret_cast<uint4*>(dst) = v;
-          else if (grow < g.M && gcol < g.N) *reinterpret_cast<uint4*>(dst) = v;
+          else if (grow < Meff && gcol < g.N) *reinterpret_cast<uint4*>(dst) = v;
           if constexpr (GELU) {            // h = dropout(gelu(u)) on the bf16-rounded u, as the stand-alone kernel computes it
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
             float f[8];
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
             const uint4 hv = make_uint4(pack_bf16x2(ha.x, ha.y), pack_bf16x2(ha.z, ha.w), pack_bf16x2(hb.x, hb.y), pack_bf16x2(hb.z, hb.w));
             uint16_t* hd = reinterpret_cast<uint16_t*>(g.gelu_out) + grow * g.N + gcol;
             if (full) *reinterpret_cast<uint4*>(hd) = hv;
-            else if (grow < g.M && gcol < g.N) *reinterpret_cast<uint4*>(hd) = hv;
+            else if (grow < Meff && gcol < g.N) *reinterpret_cast<uint4*>(hd) = hv;
           }
         }
       }
@@ -352,12 +355,18 @@ static int launch_lin_ring(const IGemmArgs& g, hipStream_t st) {
 
 static bool ring_enabled();
 // dense projection through the weight-stationary ring kernel; returns 1 when the shape is not handled
-int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st) {
+int launch_nt_ring_bf16(const IGemmArgs& g_in, hipStream_t st) {
+  const IGemmArgs& g = g_in;
   static int on = -1, w8 = -1;
   if (on < 0) { const char* e = getenv("LTU_NO_NT_RING"); on = (e && atoi(e)) ? 0 : 1; }
   if (w8 < 0) { const char* e = getenv("LTU_NT_RING_WAVES"); w8 = (e && atoi(e) == 4) ? 0 : 1; }
   if (!on || !ring_enabled()) return 1;
   if (g.ntaps != 1 || g.K != g.C || g.c0 != g.C || !g.out_identity || g.accum || g.n0 != g.N || g.dbg) return 1;
+  static int rdbg = -1;                      // ablations (tools/bench_nt.py): 1 = no global stores, 2 = no MFMA
+  if (rdbg < 0) { const char* e = getenv("LTU_RING_DBG"); rdbg = e ? atoi(e) : 0; }
+  IGemmArgs gd = g_in;
+  gd.dbg = rdbg;
+  const IGemmArgs& g2 = gd;
   if (g.gelu_out != nullptr && (g.nseg != 1 || g.ldo0 != g.N || ((uintptr_t)g.gelu_out & 15))) return 1;
   if (g.K % 64 || g.K > 768 || g.N % 8 || g.N < 96 || g.M < 512 || g.lda0 % 8 || g.ldo0 % 8 || g.N % g.nseg) return 1;
   uintptr_t al = (uintptr_t)g.a0 | (uintptr_t)g.o0;
@@ -366,23 +375,23 @@ int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st) {
   static int tnw1_below = -1;
   if (tnw1_below < 0) { const char* e = getenv("LTU_NT_RING_TNW1_BELOW"); tnw1_below = e ? atoi(e) : 2048; }     // few row tiles: narrower column tiles spread them over more workgroups
   if (w8) {
-    if (g.K <= 256 && g.M < tnw1_below) return launch_lin_ring<4, 1, 4>(g, st);
+    if (g.K <= 256 && g.M < tnw1_below) return launch_lin_ring<4, 1, 4>(g2, st);
     if (g.gelu_out != nullptr && g.K <= 256) {
       // the GELU epilogue is a long VALU phase during which nothing is issued: a deeper ring keeps loads in flight across it
       static int deep = -1;
       if (deep < 0) { const char* e = getenv("LTU_GELU_RING_DEEP"); deep = e ? atoi(e) : 1; }
-      if (deep && g.K <= 128) return launch_lin_ring_e<4, 2, 6, true>(g, st);
-      if (deep) return launch_lin_ring_e<4, 2, 5, true>(g, st);
+      if (deep && g.K <= 128) return launch_lin_ring_e<4, 2, 6, true>(g2, st);
+      if (deep) return launch_lin_ring_e<4, 2, 5, true>(g2, st);
     }
-    if (g.K <= 256) return launch_lin_ring<4, 2, 4>(g, st);
-    if (g.K <= 384) return launch_lin_ring<4, 2, 3>(g, st);
-    if (g.K <= 512) return launch_lin_ring<4, 1, 4>(g, st);
-    return launch_lin_ring<4, 1, 3>(g, st);
+    if (g.K <= 256) return launch_lin_ring<4, 2, 4>(g2, st);
+    if (g.K <= 384) return launch_lin_ring<4, 2, 3>(g2, st);
+    if (g.K <= 512) return launch_lin_ring<4, 1, 4>(g2, st);
+    return launch_lin_ring<4, 1, 3>(g2, st);
   }
-  if (g.K <= 256) return launch_lin_ring<2, 2, 4>(g, st);
-  if (g.K <= 384) return launch_lin_ring<2, 2, 3>(g, st);
-  if (g.K <= 512) return launch_lin_ring<2, 1, 4>(g, st);
-  return launch_lin_ring<2, 1, 3>(g, st);
+  if (g.K <= 256) return launch_lin_ring<2, 2, 4>(g2, st);
+  if (g.K <= 384) return launch_lin_ring<2, 2, 3>(g2, st);
+  if (g.K <= 512) return launch_lin_ring<2, 1, 4>(g2, st);
+  return launch_lin_ring<2, 1, 3>(g2, st);
 }
 
 #define TN_RING 6
