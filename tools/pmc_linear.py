@@ -15,7 +15,7 @@ def launches():
     out = []
     for M, d in STACKS:
         for _ in range(LAYERS):
-            out += [(M, d, 3 * d, 3), (M, d, d, 1), (M, d, 2 * d, 1), (M, 2 * d, d, 1)]
+            out += [(M, d, 3 * d, 3), (M, d, d, 1), (M, d, 2 * d, -1), (M, 2 * d, d, 1)]      # nw = -1: FFN front half (GELU epilogue)
     return out
 
 
@@ -28,14 +28,18 @@ def run():
     with torch.no_grad():
         for M, K, N, nw in launches():
             key = (M, K, N, nw)
+            n_w = abs(nw)
             if key not in cache:
                 x = torch.randn(M, K, device='cuda').bfloat16()
-                ws = [torch.randn(N // nw, K, device='cuda') * 0.05 for _ in range(nw)]
-                bs = [torch.zeros(N // nw, device='cuda') for _ in range(nw)]
+                ws = [torch.randn(N // n_w, K, device='cuda') * 0.05 for _ in range(n_w)]
+                bs = [torch.zeros(N // n_w, device='cuda') for _ in range(n_w)]
                 prep = ops.LinPrep([w.bfloat16() for w in ws], None)
                 cache[key] = (x, ws, bs, prep)
             x, ws, bs, prep = cache[key]
-            ops.linear(x, ws, bs, prep=prep)
+            if nw < 0:
+                ops.linear_gelu(x, ws[0], bs[0], 0.3, 7, prep=prep)
+            else:
+                ops.linear(x, ws, bs, prep=prep)
     torch.cuda.synchronize()
 
 
@@ -51,7 +55,7 @@ def parse(fetch_dir, write_dir):
     fetch, nf = total(fetch_dir, 'FETCH_SIZE')
     write, nw = total(write_dir, 'WRITE_SIZE')
     L = launches()
-    algo = sum((M * K + M * N + N * K) * 2 for M, K, N, _ in L)
+    algo = sum((M * K + (2 if nw < 0 else 1) * M * N + N * K) * 2 for M, K, N, nw in L)      # the FFN front half writes u and h
     # MI355X_MICROARCH.md (HBM): counters are in KiB; FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950
     hbm = (2.0 * fetch + write) * 1024.0
     print(json.dumps({'kernel': 'linear_ring_bf16_kernel (forward transformer projections of one bench step)',
