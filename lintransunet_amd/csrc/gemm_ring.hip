@@ -335,8 +335,11 @@ static int launch_lin_ring_e(const IGemmArgs& g, hipStream_t st) {
   const int tiles_m = (int)((g.M + 127) / 128), nt = cdiv(g.N, BN);
   int P = 256 / nt;
   if (P < 1) P = 1;
-  if (P > tiles_m) P = tiles_m;
   if (P >= 8) P &= ~7;                       // column tiles of one row tile then share an XCD (ids differ by P)
+  if (P > tiles_m) {                         // fewer row tiles than workgroups: one tile each (rounding DOWN to a multiple of 8
+    const int up = (tiles_m + 7) & ~7;       // would leave a few tiles for a second round), a few idle workgroups instead
+    P = up <= P ? up : tiles_m;
+  }
   const int smem_bytes = BN * g.K * 2 + R * 16384 + BN * 4;
   static bool attr_done = false;
   if (!attr_done) {
