@@ -28,12 +28,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_batch(batch, size, seed, device):
-    """N(0,1) volume clipped to the dataset's normalised HU range + ellipsoid labels."""
+def synthetic_batch(batch, size, seed, device, n_classes=2):
+    """N(0,1) volume clipped to the dataset's normalised HU range + ellipsoid labels (3 label
+    values for the multi-class configuration 4)."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn((batch, 1) + size, generator=g).clamp_(-4.51, 4.14)
     from oracle import seedgen       # label generator only (test infrastructure helper, not on the timed path)
-    lab = seedgen.seeded_label((batch, 1) + size, seed + 1, n_blobs=2)
+    lab = seedgen.seeded_label((batch, 1) + size, seed + 1, n_blobs=2, n_classes=n_classes)
     return x.to(device), lab.to(device)
 
 
@@ -113,6 +114,8 @@ def main():
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--batch', type=int, default=2, help='patches per GPU')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--classes', type=int, default=2, choices=[2, 3],
+                    help='model outputs: 2 = single-class pancreas (BASELINE configs 2/3), 3 = multi-class path (config 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured HIP graph')
     args = ap.parse_args()
@@ -132,13 +135,15 @@ def main():
     torch.manual_seed(1234)          # same initial weights on every rank (then broadcast for good measure)
     act = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = get_model_dict('MaskTransUnet')([16, 32, 64, 128, 256], [100, 65, 40, 25, 10], [False, True, True, True, True],
-                                            1, 2, dropout=0.3, act_dtype=act).to(dev).train()
+                                            1, args.classes, dropout=0.3, act_dtype=act).to(dev).train()
     train.broadcast_parameters(model)
     torch.manual_seed(1234 + rank)   # dropout streams differ per rank
     reducer = train.GradReducer(model, bucket_mb=16.0, unused=train.UNUSED_PARAMETERS)
     size = (args.size,) * 3
     weights = train.get_dynamic_weight(1)[0]
-    batches = [synthetic_batch(args.batch, size, 100 + 10 * rank + i, dev) for i in range(2)]
+    batches = [synthetic_batch(args.batch, size, 100 + 10 * rank + i, dev, args.classes) for i in range(2)]
+    # multi-class script (train3D_multi_class.py / utils_3D_multi_class.py:85-102): CE + Dice(class 1) + Dice(class 2), weights 10/1/2
+    specs = train.level_specs(5, ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'), criterion_weight=[10, 1, 2]) if args.classes == 3 else None
 
     # live timing of the dominant kernel family (the dense projections of the transformers)
     timer = KernelTimer()
@@ -163,7 +168,7 @@ def main():
     def eager_step(i):
         reducer.zero_grad()
         x, lab = batches[i % 2]
-        return train.train_step(model, x, lab, weights, reducer=reducer)
+        return train.train_step(model, x, lab, weights, specs=specs, reducer=reducer)
 
     # The dominant kernel family (forward projections) is recorded over one eager step and re-timed below from a graph of
     # exactly those launches; the timed region of the headline number replays the whole step from a captured HIP graph.
@@ -180,7 +185,7 @@ def main():
     step = eager_step
     if not args.no_graph:
         try:
-            graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer)
+            graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer, specs=specs)
             step = lambda i: graphed(*batches[i % 2])
             launch = 'hip-graph replay'
         except Exception as e:                     # a failed capture must not cost the measurement: same kernels, launched eagerly
@@ -218,7 +223,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
-                                   f'{args.batch} per GPU, dropout 0.3, random-init weights', 'global_batch': args.batch * world,
+                                   f'{args.batch} per GPU, dropout 0.3, random-init weights' + (', 3 labels (multi-class losses)' if args.classes == 3 else ''), 'global_batch': args.batch * world,
                        'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch},
             'roofline': {'bound': 'hbm', 'kernel': 'linear_ring_bf16_kernel (transformer projections, forward launches; the FFN front half carries GELU + dropout)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -198,8 +198,8 @@ int ltu_gelu_dropout_bwd(const void* dh, const void* u, void* du, long long n, f
 int ltu_head_softmax_fwd(const void* z, float* p, long long M, int C, int CP, int dtype, ltu_stream_t s);
 int ltu_head_softmax_bwd(const float* dp, const float* p, void* dz, long long M, int C, int CP, int dtype, ltu_stream_t s);
 /* final head (model/Unet_3Dblock.py:1392-1394): z [B,h,w,D,4C] -> window un-embedding + softmax -> p f32 [B,2h,2w,D,C] */
-int ltu_final_softmax_fwd(const void* z, float* p, int B, int h, int w, int D, int C, int dtype, ltu_stream_t s);
-int ltu_final_softmax_bwd(const float* dp, const float* p, void* dz, int B, int h, int w, int D, int C, int dtype,
+int ltu_final_softmax_fwd(const void* z, float* p, int B, int h, int w, int D, int C, int CP, int dtype, ltu_stream_t s);   /* z rows of CP >= 4C channels (padded conv output) */
+int ltu_final_softmax_bwd(const float* dp, const float* p, void* dz, int B, int h, int w, int D, int C, int CP, int dtype,
                           ltu_stream_t s);
 /* eval branch (model/trans_3DUnet.py:199-202): one-hot of the arg-max class, p/o f32 [M][C] */
 int ltu_onehot_argmax(const float* p, float* o, long long M, int C, ltu_stream_t s);

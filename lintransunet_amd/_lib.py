@@ -71,8 +71,8 @@ SIGNATURES = {
     'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, P, I, P],
     'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],
     'ltu_head_softmax_bwd': [P, P, P, L, I, I, I, P],
-    'ltu_final_softmax_fwd': [P, P, I, I, I, I, I, I, P],
-    'ltu_final_softmax_bwd': [P, P, P, I, I, I, I, I, I, P],
+    'ltu_final_softmax_fwd': [P, P, I, I, I, I, I, I, I, P],
+    'ltu_final_softmax_bwd': [P, P, P, I, I, I, I, I, I, I, P],
     'ltu_onehot_argmax': [P, P, L, I, P],
     'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],

@@ -288,7 +288,7 @@ extern "C" int ltu_head_softmax_bwd(const float* dp, const float* p, void* dz, l
 // final head (model/Unet_3Dblock.py:1392-1394): z T [B,h,w,D,4C] -> window un-embedding + softmax over classes
 // -> probs f32 [B,2h,2w,D,C];  channel c*4 + kh*2 + kw of voxel (h,w) is class c of voxel (2h+kh, 2w+kw).
 template <typename T>
-__global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restrict__ p, int B, int h, int w, int D, int C) {
+__global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restrict__ p, int B, int h, int w, int D, int C, int CP) {
   const long long n = (long long)B * h * w * D;
   GRID_STRIDE(i, n) {
     const int d = (int)(i % D);
@@ -298,7 +298,7 @@ __global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restr
     const int b = (int)(t / h);
     float v[16];
     for (int k = 0; k < 4 * C; k += 4) {
-      const float4 q = Vec4<T>::load(z + i * 4 * C + k);
+      const float4 q = Vec4<T>::load(z + i * CP + k);
       v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
     }
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restr
 }
 template <typename T>
 __global__ void final_softmax_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p, T* __restrict__ dz, int B,
-                                         int h, int w, int D, int C) {
+                                         int h, int w, int D, int C, int CP) {
   const long long n = (long long)B * h * w * D;
   GRID_STRIDE(i, n) {
     const int d = (int)(i % D);
@@ -329,18 +329,19 @@ __global__ void final_softmax_bwd_kernel(const float* __restrict__ dp, const flo
       for (int c = 0; c < C; ++c) dot += dp[o + c] * p[o + c];
       for (int c = 0; c < C; ++c) v[c * 4 + q] = p[o + c] * (dp[o + c] - dot);
     }
-    for (int k = 0; k < 4 * C; k += 4) Vec4<T>::store(dz + i * 4 * C + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+    for (int k = 0; k < 4 * C; k += 4) Vec4<T>::store(dz + i * CP + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+    for (int k = 4 * C; k < CP; k += 4) Vec4<T>::store(dz + i * CP + k, make_float4(0.f, 0.f, 0.f, 0.f));      // padded conv columns
   }
 }
-extern "C" int ltu_final_softmax_fwd(const void* z, float* p, int B, int h, int w, int D, int C, int dtype, ltu_stream_t s) {
-  if (C < 1 || C > 4) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((final_softmax_fwd_kernel<T>), dim3(sgrid((long long)B * h * w * D)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, B, h, w, D, C); });
+extern "C" int ltu_final_softmax_fwd(const void* z, float* p, int B, int h, int w, int D, int C, int CP, int dtype, ltu_stream_t s) {
+  if (C < 1 || C > 4 || CP < 4 * C || CP % 4) return LTU_E_SHAPE;
+  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((final_softmax_fwd_kernel<T>), dim3(sgrid((long long)B * h * w * D)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, B, h, w, D, C, CP); });
   return ltu_check_launch();
 }
-extern "C" int ltu_final_softmax_bwd(const float* dp, const float* p, void* dz, int B, int h, int w, int D, int C, int dtype,
-                                     ltu_stream_t s) {
-  if (C < 1 || C > 4) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((final_softmax_bwd_kernel<T>), dim3(sgrid((long long)B * h * w * D)), dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, B, h, w, D, C); });
+extern "C" int ltu_final_softmax_bwd(const float* dp, const float* p, void* dz, int B, int h, int w, int D, int C, int CP,
+                                     int dtype, ltu_stream_t s) {
+  if (C < 1 || C > 4 || CP < 4 * C || CP % 4) return LTU_E_SHAPE;
+  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((final_softmax_bwd_kernel<T>), dim3(sgrid((long long)B * h * w * D)), dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, B, h, w, D, C, CP); });
   return ltu_check_launch();
 }
 

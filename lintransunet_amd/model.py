@@ -225,6 +225,10 @@ class MaskTransUnet(nn.Module):
         self.last_boxes = []
         self._store = None
 
+    def _final_cop(self):
+        n = 4 * self.dim_output
+        return n if self.act_dtype == torch.float32 else (n + 7) // 8 * 8
+
     # ------------------------------------------------------------------ prepared weight operands
     def _weights(self, device):
         st = self._store
@@ -243,7 +247,8 @@ class MaskTransUnet(nn.Module):
             lvl = nl - 2 - i
             st.add_conv_pair(lvl, blk.conv1, dec.mask_conv_list[lvl], 16 if lvl == 0 else 32)
             st.add_conv(blk.conv2)
-        st.add_conv(dec.final_block)
+        # bf16 GEMM operands need channel counts in multiples of 8: 4C = 12 output channels (3 labels) are padded to 16
+        st.add_conv(dec.final_block, cop=self._final_cop())
         for ag in dec.att_conv_list:
             st.add_linear(id(ag.W_x[0]), [ag.W_x[0].weight])
             st.add_linear(id(ag.W_g[0]), [ag.W_g[0].weight])
@@ -359,7 +364,7 @@ class MaskTransUnet(nn.Module):
                 skip = self._roi_bridge(dec.bridge_list[lvl], skip, m.detach(), self.roi_size_list[lvl], p, seeds)
             t = ops.instnorm_act(t1, act=ops.ACT_LRELU)
             t = self._conv_in_act(t, blk.conv2, x1=skip, p=p, seeds=seeds)
-        z = ops.conv3d(t, dec.final_block.weight, dec.final_block.bias, prep=store.conv[id(dec.final_block)])
+        z = ops.conv3d(t, dec.final_block.weight, dec.final_block.bias, cop=self._final_cop(), prep=store.conv[id(dec.final_block)])
         out = ops.final_softmax(z, C)
         if self.training:
             return _cl(out), [_cl(m) for m in masks]

@@ -893,25 +893,25 @@ class _FinalSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, C):
         _chk(z, 'z')
-        B, h, w, D, _ = z.shape
+        B, h, w, D, CP = z.shape
         p = torch.empty((B, 2 * h, 2 * w, D, C), device=z.device, dtype=torch.float32)
-        _lib.call('ltu_final_softmax_fwd', _p(z), _p(p), B, h, w, D, C, _dt(z), _s())
+        _lib.call('ltu_final_softmax_fwd', _p(z), _p(p), B, h, w, D, C, CP, _dt(z), _s())
         ctx.save_for_backward(p)
-        ctx.cfg = (B, h, w, D, C, z.dtype)
+        ctx.cfg = (B, h, w, D, C, CP, z.dtype)
         return p
 
     @staticmethod
     def backward(ctx, g):
         (p,) = ctx.saved_tensors
-        B, h, w, D, C, zdt = ctx.cfg
+        B, h, w, D, C, CP, zdt = ctx.cfg
         g = g.contiguous()
-        dz = torch.empty((B, h, w, D, 4 * C), device=p.device, dtype=zdt)
-        _lib.call('ltu_final_softmax_bwd', _p(g), _p(p), _p(dz), B, h, w, D, C, _dt(dz), _s())
+        dz = torch.empty((B, h, w, D, CP), device=p.device, dtype=zdt)
+        _lib.call('ltu_final_softmax_bwd', _p(g), _p(p), _p(dz), B, h, w, D, C, CP, _dt(dz), _s())
         return dz, None
 
 
 def final_softmax(z, C):
-    """window un-embedding + class softmax: z [B,h,w,D,4C] -> fp32 probabilities [B,2h,2w,D,C]."""
+    """window un-embedding + class softmax: z [B,h,w,D,CP >= 4C] (conv output, possibly padded) -> fp32 probabilities [B,2h,2w,D,C]."""
     return _FinalSoftmax.apply(z, C)
 
 

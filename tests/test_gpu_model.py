@@ -248,6 +248,33 @@ def test_model_multiclass_fp32(golden_dir):
     assert worst <= 1e-2, worst
 
 
+def test_model_multiclass_bf16(golden_dir):
+    """the 3-label configuration in bf16 storage (BASELINE config 4 runs it): 4C = 12 final-conv channels are padded to 16 for the
+    bf16 GEMMs; outputs, losses and Dice stay within bf16 distance of the fp32 vectors generated by the reference"""
+    from lintransunet_amd import train
+    from lintransunet_amd import losses as L
+    G = np.load(os.path.join(golden_dir, 'model_multi_small.npz'))
+    cfg = O_net.NetConfig(dim_output=3, **SMALL)
+    model = build(cfg, 400, dtype=torch.bfloat16)
+    x = seedgen.seeded_volume((2, 1, 32, 32, 32), 401).to(DEV)
+    label = seedgen.seeded_label((2, 1, 32, 32, 32), 402, n_classes=3).to(DEV)
+    predict, masks = model(x)
+    assert predict.shape == (2, 3, 32, 32, 32) and (predict.sum(1) - 1).abs().max().item() <= 1e-5
+    specs = train.level_specs(5, ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'), criterion_weight=[10, 1, 2])
+    totals, named = train.deep_supervision_loss(predict, masks, label, O_step.dynamic_weights(0), specs=specs)
+    torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(G['out']).double()
+    assert ((predict.detach().double().cpu() - ref).norm() / ref.norm()).item() <= 3e-2        # rel-L2 (single voxels move by up to 0.1)
+    total = sum(t.item() for t in totals)
+    assert abs(total - float(G['total'])) <= 2e-2 * abs(float(G['total']))
+    assert abs(L.DiceClassLoss()(predict.detach(), label).item() - float(G['dice1'])) <= 1e-2
+    assert abs(L.DiceClassLoss2()(predict.detach(), label).item() - float(G['dice2'])) <= 1e-2
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+
+
 def test_full_size_properties():
     """BASELINE size (128^3, 2 patches, the reference's channel / ROI configuration, bf16 storage) is out of the oracle's reach, so
     check what must hold at any size: class probabilities sum to 1 everywhere, every op is per-sample (swapping the two patches
