@@ -279,6 +279,8 @@ class MaskTransUnet(nn.Module):
         projections, `tres` (same values) the residual: two autograd edges whose gradients the LayerNorm backward sums."""
         lin = lay.self_attn.linears
         wl = self._store.lin
+        if ops.WGRAD_FLUSH_PER_LAYER:
+            t = ops.wgrad_flush_point(t)     # the qkv data gradient is the last backward op of a layer
         qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
                          prep=wl[(id(lay), 'qkv')])
         a = ops.linear_attention(qkv, B, N, d)
@@ -296,6 +298,7 @@ class MaskTransUnet(nn.Module):
         matter to the layers (per-token ops + a set reduction over tokens), so voxels stay in place."""
         B, H, W, D, d = x.shape
         N = H * W * D
+        x = ops.wgrad_flush_point(x)         # backward: the transformer's weight gradients go out as one branch from here
         t = tres = x.reshape(B * N, d)
         for n, lay in enumerate(layers):
             # the positional conv after layer 0 consumes a single tensor; so does whatever follows the last layer

@@ -184,6 +184,64 @@ def flush_deferred():
     _DEFERRED.clear()
 
 
+# ---- weight-gradient branch ------------------------------------------------------------------------
+# Weight gradients of the transformer projections are consumed only at the end of the step, so they need not sit on the
+# data-gradient chain.  With a branch installed (train.GraphedStep) their launches are collected and issued on a second
+# stream once per transformer (ONE cross-stream edge per bridge: a HIP-graph edge between branches costs ~4 us, so per-kernel
+# edges lose more than the overlap gains; two long branches gain 13-23 %, tools/bench_overlap.py).
+_WG_BRANCH = None        # {'side': torch.cuda.Stream, 'jobs': [(fn, tensors)]}
+import os as _os
+WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
+
+
+def wgrad_branch_install(side_stream):
+    """collect the projection weight-gradient launches instead of issuing them inline (None uninstalls)"""
+    global _WG_BRANCH
+    _WG_BRANCH = None if side_stream is None else {'side': side_stream, 'jobs': []}
+
+
+def wgrad_branch_flush():
+    """issue the collected launches on the side stream, ordered after everything issued so far on the current stream"""
+    br = _WG_BRANCH
+    if br is None or not br['jobs']:
+        return
+    side = br['side']
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for fn, tensors in br['jobs']:
+            for t in tensors:
+                t.record_stream(side)          # allocated on the main stream, read by the side stream
+            fn()
+    br['jobs'].clear()
+
+
+def wgrad_branch_join():
+    """flush what is left and make the current stream wait for the branch (end of backward)"""
+    br = _WG_BRANCH
+    if br is None:
+        return
+    wgrad_branch_flush()
+    torch.cuda.current_stream().wait_stream(br['side'])
+
+
+class _WgradFlushPoint(torch.autograd.Function):
+    """identity in forward; its backward runs when the gradient reaches this point, i.e. after everything downstream has
+    run its backward: the model puts one at the input of every token transformer"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        wgrad_branch_flush()
+        return g
+
+
+def wgrad_flush_point(x):
+    return _WgradFlushPoint.apply(x) if (_WG_BRANCH is not None and x.requires_grad) else x
+
+
 _NORM_WS = {}
 
 
@@ -549,6 +607,15 @@ class _Linear(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         gw = [_grad_buf(w) for w in ws]
         gb = [_grad_buf(b) for b in bs]
+        if _WG_BRANCH is not None and all(f for _, f in gw) and all(f for _, f in gb):
+            def launch(g=g, x=x, gw=gw, gb=gb):
+                wsb = _wgrad_ws(M, N, K, x)
+                _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
+                          M, N, K, _p(wsb), 0, dt, _s())
+            _WG_BRANCH['jobs'].append((launch, (g, x)))
+            dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
+            dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
+            return (dx, None, *dws, *dbs)
         wsb = _wgrad_ws(M, N, K, x)
         # Not deferred by default: 16 MB of partial tiles per projection are folded straight away while they still sit in
         # L2 / MALL (measured: a batched fold of 8 cold workspaces costs twice the 8 separate hot ones).
@@ -604,8 +671,14 @@ class _LinearGelu(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        wsb = _wgrad_ws(M, N, K, x)
-        _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
+
+        def launch(g=g, x=x):
+            wsb = _wgrad_ws(M, N, K, x)
+            _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
+        if _WG_BRANCH is not None and fw and fb:
+            _WG_BRANCH['jobs'].append((launch, (g, x)))
+        else:
+            launch()
         return dx, None, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
 
 

@@ -7,6 +7,7 @@ one bucketed all-reduce of the gradients over RCCL/xGMI (gloo on CPU tests), lau
 from autograd hooks so that it overlaps the rest of backward.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -84,6 +85,7 @@ def train_step(model, images, labels, weights, step_times=1, specs=None, reducer
     if reducer is not None:
         reducer.prepare()
     torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    ops.wgrad_branch_join()                 # weight-gradient branch (if one is installed) back into this stream
     ops.flush_deferred()                    # second stages of the two-stage reductions still queued by backward
     if reducer is not None:
         reducer.finish()
@@ -196,10 +198,17 @@ class GraphedStep:
         self.counter = torch.zeros(1, device=dev, dtype=torch.int64)
         ops.set_step_counter(self.counter)
 
+        # opt-in (LTU_WGRAD_BRANCH=1): measured +0.5 % only (21.09 vs 21.20 ms), see DESIGN.md section 7
+        self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get('LTU_WGRAD_BRANCH', '0') == '1' else None
+
         def body():
             self.counter.add_(1)
             reducer.zero_grad()
-            return train_step(model, self.x, self.lab, weights, step_times=step_times, specs=specs, reducer=None)
+            ops.wgrad_branch_install(self.wg_stream)       # projection weight gradients on a second graph branch
+            try:
+                return train_step(model, self.x, self.lab, weights, step_times=step_times, specs=specs, reducer=None)
+            finally:
+                ops.wgrad_branch_install(None)
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
