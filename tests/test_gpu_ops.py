@@ -115,6 +115,8 @@ def test_linear_bf16(ops, M, K, N, nw):
     (3, 16, 16, 4, 12, 8, (1, 1, 1), 0, False, None),
     (2, 16, 64, 9, 7, 10, (2, 2, 2), 0, False, None),    # class-halo data gradient: 8 parity classes, odd input dims
     (1, 40, 32, 8, 5, 17, (2, 2, 1), 0, False, None),    # 4 classes
+    (2, 128, 128, 8, 8, 8, (2, 2, 2), 0, False, None),   # strided forward on a tiny grid with K = 3456: K-split implicit GEMM + fold
+    (1, 256, 128, 4, 4, 8, (1, 1, 1), 0, False, None),   # stride-1 halo conv on one brick row: channel-split + fold
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
@@ -237,7 +239,8 @@ def test_conv3d(ops, case):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
-@pytest.mark.parametrize('B,Ci,Co,H,W,D', [(2, 16, 8, 3, 4, 2), (1, 32, 16, 5, 3, 4), (1, 128, 32, 4, 3, 5), (2, 64, 72, 5, 6, 9)])
+@pytest.mark.parametrize('B,Ci,Co,H,W,D', [(2, 16, 8, 3, 4, 2), (1, 32, 16, 5, 3, 4), (1, 128, 32, 4, 3, 5), (2, 64, 72, 5, 6, 9),
+                                          (1, 128, 64, 4, 4, 4)])     # last: K = 64*Co = 4096 on a tiny grid -> K-split data gradient
 def test_upconv_subpixel(ops, dtype, tol, B, Ci, Co, H, W, D):
     """nearest x2 + conv3x3x3 computed as 8 parity-class 2x2x2 convs with pre-summed weights == the plain formulation"""
     g = G(13)
