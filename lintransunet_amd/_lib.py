@@ -101,6 +101,10 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise LtuError(f'{LIB_PATH} is missing: the HIP extension has not been built; there is no fallback path')
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); libltu_hip.so must bind to THAT copy, because device
+    # pointers and streams come from torch.  Importing torch first puts its runtime into the process before ours is resolved
+    # (loaded the other way round, the system runtime under /opt/rocm answers our launches with hipErrorNoDevice).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
