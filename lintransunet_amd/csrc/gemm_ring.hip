@@ -416,7 +416,12 @@ static RingGeom tn_ring_geometry(long long M, int N, int K) {
   long long want = ring_blocks() / ((long long)t.nk * t.nn);
   if (want < 1) want = 1;
   long long rows = (M + want - 1) / want;
-  if (rows < 512) rows = 512;
+  static int minrows = -1;
+  if (minrows < 0) { const char* e = getenv("LTU_RING_MINROWS"); minrows = (e && atoi(e) >= 32) ? atoi(e) : 0; }
+  // few rows: shorter splits put more workgroups on the serial unit loop (measured: 1 024 rows 14.8 -> 9.0 us at 128 rows per
+  // split, 8 640 rows 17.7 -> 16.5 us at 256; below that the second stage grows faster than the first shrinks)
+  const int mr = minrows > 0 ? minrows : (M <= 2048 ? 128 : 256);
+  if (rows < mr) rows = mr;
   rows = (rows + 31) / 32 * 32;
   t.rows = (int)rows;
   t.nsplit = (int)((M + rows - 1) / rows);
