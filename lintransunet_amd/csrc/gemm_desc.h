@@ -1,5 +1,6 @@
 // Descriptors shared by the fp32-MFMA (gemm.hip) and bf16-MFMA (gemm_bf16.hip) implicit-GEMM kernels.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 struct Tap {
@@ -91,10 +92,13 @@ static inline TnGeom tn_geometry(long long M, int N, int K, int brows) {
   t.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
   t.nk = (K + t.bk - 1) / t.bk;
   t.nn = (N + t.bn - 1) / t.bn;
-  long long want = 512 / ((long long)t.nk * t.nn);
+  static int tn_want = -1, tn_min = -1;
+  if (tn_want < 0) { const char* e = getenv("LTU_TN_WANT"); tn_want = (e && atoi(e) > 0) ? atoi(e) : 1024; }     // swept: 1024 / 128 (tools/sweep_tn.sh)
+  if (tn_min < 0) { const char* e = getenv("LTU_TN_MINROWS"); tn_min = (e && atoi(e) > 0) ? atoi(e) : 128; }
+  long long want = tn_want / ((long long)t.nk * t.nn);
   if (want < 1) want = 1;
   long long rows = (M + want - 1) / want;
-  if (rows < 256) rows = 256;
+  if (rows < tn_min) rows = tn_min;
   rows = (rows + brows - 1) / brows * brows;
   t.rows = (int)rows;
   t.nsplit = (int)((M + rows - 1) / rows);
