@@ -433,7 +433,9 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
 
 // ------------------------------------------------------------------------------------------------ host side
 static int stats_rows(long long S, int B, int* nchunks) {
-  long long want = 2048 / (B > 0 ? B : 1);
+  static int chunks = -1;
+  if (chunks < 0) { const char* e = getenv("LTU_IN_CHUNKS"); chunks = (e && atoi(e) > 0) ? atoi(e) : 2048; }
+  long long want = chunks / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   long long rows = (S + want - 1) / want;
   if (rows < 64) rows = 64;
