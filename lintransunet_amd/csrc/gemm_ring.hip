@@ -239,11 +239,8 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
   for (int u = 0; u < R - 1 && u < nunits; ++u) issue(u);
   // bias and weights are older than the R - 1 units just issued: wait for them only (all of it when fewer units exist)
   if (nunits >= R - 1) ring_sync<PW * (R - 1)>(); else ring_sync<0>();
-  float4 bias4[TNW][4];                                    // this lane's 4 x 4 consecutive columns of each 32-column tile
-#pragma unroll
-  for (int j = 0; j < TNW; ++j)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) bias4[j][rr] = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
+  // the bias row stays in LDS and is read in the epilogue (4 x 16 bytes per column tile): as registers it cost 16 TNW VGPRs,
+  // which kept the 128-column configuration above 128 registers, i.e. at one 8-wave workgroup per CU
   for (int q = 0; q < nunits; ++q) {
     if (q + R - 2 < nunits) {
       if (after_store) ring_sync<PW * (R - 2) + S>(); else ring_sync<PW * (R - 2)>();
@@ -288,7 +285,7 @@ __global__ void __launch_bounds__(128 * WM) linear_ring_bf16_kernel(const IGemmA
       for (int j = 0; j < TNW; ++j) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const float4 bv = bias4[j][rr];
+          const float4 bv = *reinterpret_cast<const float4*>(&bias_l[wn * 32 * TNW + j * 32 + 8 * rr + 4 * lh]);
           uint2 pk;
           pk.x = pack_bf16x2(acc[i][j][4 * rr + 0] + bv.x, acc[i][j][4 * rr + 1] + bv.y);
           pk.y = pack_bf16x2(acc[i][j][4 * rr + 2] + bv.z, acc[i][j][4 * rr + 3] + bv.w);
