@@ -600,7 +600,9 @@ static int pick_splits(int B, int N, int* tokens_per_split) {
 }
 // tokens per workgroup of the per-token kernels: ~512 workgroups, whole tiles
 static int pick_tokb(int B, int N) {
-  long long per = ((long long)B * N + 511) / 512;
+  static int blocks = -1;
+  if (blocks < 0) { const char* e = getenv("LTU_LA_TOKB_BLOCKS"); blocks = (e && atoi(e) > 0) ? atoi(e) : 256; }     // swept 256 .. 2048
+  long long per = ((long long)B * N + blocks - 1) / blocks;
   int tokb = (int)((per + 31) / 32 * 32);
   if (tokb < 32) tokb = 32;
   if (tokb > 512) tokb = 512;

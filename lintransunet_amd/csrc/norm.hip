@@ -556,7 +556,7 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z,
   LTU_DISPATCH_T(dtype, {
     LN_DISPATCH_GV(d, {
       const int nrg = 256 / G;
-      long long rows = (M + 1023) / 1024;
+      long long rows = (M + 1023) / 1024;        // 1024 workgroups (swept 512 / 1024 / 2048; the callers size the workspace for <= 2048)
       if (rows < nrg) rows = nrg;
       rows = (rows + nrg - 1) / nrg * nrg;
       const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
