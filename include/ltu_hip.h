@@ -11,8 +11,13 @@
  *     probabilities and gradients of weights are fp32; all accumulation is fp32.
  *   - Ownership: the caller allocates every buffer (outputs, workspaces, saved statistics).  The
  *     library never allocates, frees, retains pointers or synchronises; all work is enqueued on
- *     `stream`.  Functions are stateless and re-entrant.
- *   - Dropout: (p, seed) select a counter-based Philox mask; the backward entry points regenerate
+ *     `stream`.  Entry points keep no state between calls and may be called from several threads
+ *     (one process per GPU is the intended use).  The only process-global data are (a) the tuning
+ *     knob table of ltu_config_set (mutex-protected; knobs are looked up per call: override, then
+ *     the environment variable of the same name, then the default) and (b) per-device "dynamic
+ *     LDS limit raised" latches for four kernels (atomic bit masks).
+ *   - Dropout: (p, seed) select a counter-based hash mask (two chained murmur3 finalizers per
+ *     4-element group, csrc/common.h); the backward entry points regenerate
  *     the mask from the same (p, seed) instead of reading a stored one.  p = 0 disables.  `step` (nullable) is a
  *     device-resident counter mixed into the seed at run time, so a captured HIP graph draws fresh masks per replay.
  *   - Return value: 0 = LTU_OK, negative = LTU_E_* argument error, positive = hipError_t.
@@ -33,6 +38,11 @@ enum { LTU_OK = 0, LTU_E_DTYPE = -1, LTU_E_SHAPE = -2, LTU_E_ALIGN = -3, LTU_E_A
 enum { LTU_ACT_NONE = 0, LTU_ACT_LRELU = 1 };
 
 int ltu_version(void);
+/* Tuning / ablation knobs (grid sizes, split counts, kernel-variant switches; names = the LTU_* environment variables
+ * listed in DESIGN.md).  Sets (clear = 0) or removes (clear != 0) a process-wide override that takes precedence over
+ * the environment.  Results never depend on a knob beyond fp32 summation order.  Used by the tests to force code
+ * paths (e.g. several tiles per split in the linear-attention reductions at small N). */
+int ltu_config_set(const char* name, int value, int clear);
 
 /* ---- window embedding: model/Unet_3Dblock.py:123-136 ------------------------------------------
  * x f32 [B,1,H,W,D] (reference layout) -> y T [B,H/2,W/2,D,8]; channel kh*2+kw, channels 4..7 = 0

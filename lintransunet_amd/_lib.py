@@ -22,6 +22,7 @@ class ReduceJob(ctypes.Structure):
 # name -> argument types (return type is always int).  Mirrors include/ltu_hip.h one to one.
 SIGNATURES = {
     'ltu_version': [],
+    'ltu_config_set': [ctypes.c_char_p, I, I],
     'ltu_window_embed': [P, P, I, I, I, I, I, P],
     'ltu_pack_conv_weight': [P, P, P, I, I, I, I, I, P],
     'ltu_unpack_conv_wgrad': [P, P, I, I, I, P],
@@ -121,3 +122,8 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise LtuError(f'{name} failed: {_ERR.get(rc, "hipError_t " + str(rc))}')
+
+
+def config_set(name, value=None):
+    """process-wide knob override (value=None removes it); see ltu_config_set in include/ltu_hip.h"""
+    call('ltu_config_set', name.encode(), 0 if value is None else int(value), 1 if value is None else 0)

@@ -164,6 +164,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * 0.39894228040143267794f * e;
 }
 
+// ---- host-side configuration ---------------------------------------------------------------------
+// Tuning / ablation knobs.  Resolution order: ltu_config_set() override, then the environment variable of the same name, then
+// the built-in default.  Nothing is cached per call site, so the library holds no hidden per-process state besides the
+// override table (mutex-protected, misc.hip); geometry therefore follows a changed knob from the next launch on.
+int ltu_knob(const char* name, int dflt);
+static inline int ltu_knob_pos(const char* name, int dflt) {
+  const int v = ltu_knob(name, dflt);
+  return v > 0 ? v : dflt;
+}
+// "first call on this device": kernel attributes (dynamic LDS limits) are per device, so latches are a device bit mask
+#ifdef __cplusplus
+#include <atomic>
+struct LtuDevOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    return !(mask.fetch_or(bit) & bit);
+  }
+};
+#endif
+
 static inline int ltu_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? LTU_OK : (int)e;

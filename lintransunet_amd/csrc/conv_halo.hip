@@ -440,16 +440,16 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   if (a.c0 % a.CC != 0 && a.c0 != a.C) return 1;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
-  if (a.N <= 32 && a.C <= 32 && !getenv("LTU_NO_HALO_WS")) {      // few channels: weights stationary, persistent over bricks
-    static int wsb = -1;
-    if (wsb < 0) { const char* e = getenv("LTU_HALO_WS_BLOCKS"); wsb = (e && atoi(e) > 0) ? atoi(e) : 512; }
+  if (a.N <= 32 && a.C <= 32 && !ltu_knob("LTU_NO_HALO_WS", 0)) {      // few channels: weights stationary, persistent over bricks
+    int wsb = -1;
+    wsb = ltu_knob_pos("LTU_HALO_WS_BLOCKS", 512);
     const unsigned nblk = (unsigned)(bricks < wsb ? bricks : wsb);
     if (a.C > 16) hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<32>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     return ltu_check_launch();
   }
   int cps = 0;
-  a.ksplit = a.part != nullptr && !getenv("LTU_NO_HALO_SPLIT") ? halo_split(bricks, a.N, a.C, a.CC, &cps) : 1;
+  a.ksplit = a.part != nullptr && !ltu_knob("LTU_NO_HALO_SPLIT", 0) ? halo_split(bricks, a.N, a.C, a.CC, &cps) : 1;
   a.cps = cps;
   if (a.ksplit < 2) a.part = nullptr;
   const unsigned gz = (unsigned)a.ksplit;
@@ -620,8 +620,8 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
 }
 
 static int whalo_blocks() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LTU_WHALO_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 512; }
+  int v = -1;
+  v = ltu_knob_pos("LTU_WHALO_BLOCKS", 512);
   return v;
 }
 
@@ -1088,7 +1088,7 @@ int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st) {
     if (a.ent[e].wbase % 8) return 1;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
-  if (!getenv("LTU_NO_CLASS_RING") && a.ncls >= 3 && a.W >= 4) {
+  if (!ltu_knob("LTU_NO_CLASS_RING", 0) && a.ncls >= 3 && a.W >= 4) {
     // entries grouped by class; the ring kernel holds at most 8 (8 classes) / 12 (4 classes) entries per class
     ClassHaloArgs r = a;
     int ne = 0;
@@ -1103,12 +1103,11 @@ int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st) {
     if (fits) {
       const long long rb = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 7) / 8) * ((a.D + 7) / 8);
       constexpr int smem_bytes = 2 * CR_HROWS * 64 + 4 * 16384;
-      static bool attr_done = false;
-      if (!attr_done) {
+      static LtuDevOnce attr_once;
+      if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<8, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<8, 1, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_class_ring_bf16_kernel<4, 2, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-        attr_done = true;
       }
       bool full = a.ncls == 8;
       for (int c = 0; c < a.ncls; ++c) full = full && (r.cls_begin[c + 1] - r.cls_begin[c] == 8);
@@ -1294,8 +1293,8 @@ __global__ void __launch_bounds__(256) upconv_wgrad_class_bf16_kernel(const UpWg
 }
 
 static int upw_blocks() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LTU_UPW_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 256; }
+  int v = -1;
+  v = ltu_knob_pos("LTU_UPW_BLOCKS", 256);
   return v;
 }
 static bool upw_shape_ok(int Ci, int Co, int H, int W, int D) { return Ci % 32 == 0 && Co % 8 == 0 && H >= 2 && W >= 2 && D >= 2; }

@@ -382,7 +382,7 @@ extern "C" int ltu_gelu_dropout_fwd(const void* u, void* h, long long n, float p
 extern "C" int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias, void* u, void* h, int M, int N, int K,
                                    float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (K % 4 != 0 || lda % 4 != 0) return LTU_E_SHAPE;
-  if (dtype == LTU_BF16 && !getenv("LTU_NO_GELU_FUSE")) {
+  if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_GELU_FUSE", 0)) {
     IGemmArgs g;
     dense_desc(g, M, N, K);
     g.a0 = a; g.a1 = a; g.lda0 = lda; g.lda1 = lda;
@@ -451,8 +451,8 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
 }
 
 static bool use_halo() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LTU_NO_HALO"); v = (e && atoi(e)) ? 0 : 1; }
+  int v = -1;
+  v = ltu_knob("LTU_NO_HALO", 0) ? 0 : 1;
   return v == 1;
 }
 
@@ -566,7 +566,7 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
     if (hr != 1) return hr;
   }
   const int Ho = (Hl - 1) / sh + 1, Wo = (Wl - 1) / sw + 1, Do = (Dl - 1) / sd + 1;
-  if (dtype == LTU_BF16 && (sh == 2 || sw == 2 || sd == 2) && use_halo() && !getenv("LTU_NO_CLASS_HALO")) {
+  if (dtype == LTU_BF16 && (sh == 2 || sw == 2 || sd == 2) && use_halo() && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {
     // every parity class of the input grid from one LDS halo brick of the output gradient
     ClassHaloArgs a;
     memset(&a, 0, sizeof(a));

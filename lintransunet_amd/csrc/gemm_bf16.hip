@@ -373,14 +373,7 @@ long long igemm_nt_ws_floats(long long M, int N, int K) {
 }
 
 // tuning override for experiments: LTU_NT_VARIANT = 0 (auto) | 1 (BK 32, 2 buffers) | 2 (BK 64, 2 buffers) | 3 (BK 128, 1 buffer)
-static int nt_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("LTU_NT_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+static int nt_variant() { return ltu_knob("LTU_NT_VARIANT", 0); }
 
 template <int WM, int WN, int TM, int TN>
 static void launch_nt_cfg(const IGemmArgs& g, hipStream_t st) {
@@ -401,7 +394,7 @@ static void launch_nt_cfg(const IGemmArgs& g, hipStream_t st) {
 
 int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
   IGemmArgs g = g_in;
-  { const char* e = getenv("LTU_NT_DBG"); g.dbg = e ? atoi(e) : 0; }
+  g.dbg = ltu_knob("LTU_NT_DBG", 0);
   if (g.M <= 0 || g.N <= 0) return LTU_OK;
   if (g.M >= (1LL << 31)) return LTU_E_SHAPE;
   if (g.C % 8 || g.c0 % 8 || g.lda0 % 8 || g.lda1 % 8 || g.wrow % 8 || g.N % 4 || g.n0 % 4 || g.ldo0 % 4 || g.ldo1 % 4)
@@ -410,11 +403,11 @@ int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
     const int rr = launch_nt_ring_bf16(g, st);
     if (rr != 1) return rr;
   }
-  static int small_tile = -1;
-  if (small_tile < 0) { const char* e = getenv("LTU_NT_SMALLTILE"); small_tile = e ? atoi(e) : 0; }
+  int small_tile = -1;
+  small_tile = ltu_knob("LTU_NT_SMALLTILE", 0);
   if (g.part != nullptr) {                   // K split (workspace given by the caller): 64 x 128 tiles, BK 64
     int kps = 0;
-    const bool ok = g.out_identity && !g.accum && g.N % 4 == 0 && g.n0 % 4 == 0 && !getenv("LTU_NO_NT_SPLIT");
+    const bool ok = g.out_identity && !g.accum && g.N % 4 == 0 && g.n0 % 4 == 0 && !ltu_knob("LTU_NO_NT_SPLIT", 0);
     const int ks = ok ? nt_split(g.M, g.N, g.K, &kps) : 1;
     if (ks > 1) {
       g.ksplit = ks; g.kt_per_split = kps;

@@ -92,9 +92,9 @@ static inline TnGeom tn_geometry(long long M, int N, int K, int brows) {
   t.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
   t.nk = (K + t.bk - 1) / t.bk;
   t.nn = (N + t.bn - 1) / t.bn;
-  static int tn_want = -1, tn_min = -1;
-  if (tn_want < 0) { const char* e = getenv("LTU_TN_WANT"); tn_want = (e && atoi(e) > 0) ? atoi(e) : 1024; }     // swept: 1024 / 128 (tools/sweep_tn.sh)
-  if (tn_min < 0) { const char* e = getenv("LTU_TN_MINROWS"); tn_min = (e && atoi(e) > 0) ? atoi(e) : 128; }
+  int tn_want = -1, tn_min = -1;
+  tn_want = ltu_knob_pos("LTU_TN_WANT", 1024);     // swept: 1024 / 128 (tools/sweep_tn.sh)
+  tn_min = ltu_knob_pos("LTU_TN_MINROWS", 128);
   long long want = tn_want / ((long long)t.nk * t.nn);
   if (want < 1) want = 1;
   long long rows = (M + want - 1) / want;

@@ -338,11 +338,10 @@ static int launch_lin_ring_e(const IGemmArgs& g, hipStream_t st) {
     P = up <= P ? up : tiles_m;
   }
   const int smem_bytes = BN * g.K * 2 + R * 16384 + BN * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static LtuDevOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_ring_bf16_kernel<WM, TNW, R, GELU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   hipLaunchKernelGGL((linear_ring_bf16_kernel<WM, TNW, R, GELU>), dim3(P, nt), dim3(128 * WM), smem_bytes, st, g, tiles_m);
   return ltu_check_launch();
@@ -357,13 +356,13 @@ static bool ring_enabled();
 // dense projection through the weight-stationary ring kernel; returns 1 when the shape is not handled
 int launch_nt_ring_bf16(const IGemmArgs& g_in, hipStream_t st) {
   const IGemmArgs& g = g_in;
-  static int on = -1, w8 = -1;
-  if (on < 0) { const char* e = getenv("LTU_NO_NT_RING"); on = (e && atoi(e)) ? 0 : 1; }
-  if (w8 < 0) { const char* e = getenv("LTU_NT_RING_WAVES"); w8 = (e && atoi(e) == 4) ? 0 : 1; }
+  int on = -1, w8 = -1;
+  on = ltu_knob("LTU_NO_NT_RING", 0) ? 0 : 1;
+  w8 = ltu_knob("LTU_NT_RING_WAVES", 8) == 4 ? 0 : 1;
   if (!on || !ring_enabled()) return 1;
   if (g.ntaps != 1 || g.K != g.C || g.c0 != g.C || !g.out_identity || g.accum || g.n0 != g.N || g.dbg) return 1;
-  static int rdbg = -1;                      // ablations (tools/bench_nt.py): 1 = no global stores, 2 = no MFMA
-  if (rdbg < 0) { const char* e = getenv("LTU_RING_DBG"); rdbg = e ? atoi(e) : 0; }
+  int rdbg = -1;                      // ablations (tools/bench_nt.py): 1 = no global stores, 2 = no MFMA
+  rdbg = ltu_knob("LTU_RING_DBG", 0);
   IGemmArgs gd = g_in;
   gd.dbg = rdbg;
   const IGemmArgs& g2 = gd;
@@ -372,14 +371,14 @@ int launch_nt_ring_bf16(const IGemmArgs& g_in, hipStream_t st) {
   uintptr_t al = (uintptr_t)g.a0 | (uintptr_t)g.o0;
   for (int i = 0; i < g.nseg; ++i) al |= (uintptr_t)g.w[i];
   if (al & 15) return 1;
-  static int tnw1_below = -1;
-  if (tnw1_below < 0) { const char* e = getenv("LTU_NT_RING_TNW1_BELOW"); tnw1_below = e ? atoi(e) : 2048; }     // few row tiles: narrower column tiles spread them over more workgroups
+  int tnw1_below = -1;
+  tnw1_below = ltu_knob("LTU_NT_RING_TNW1_BELOW", 2048);     // few row tiles: narrower column tiles spread them over more workgroups
   if (w8) {
     if (g.K <= 256 && g.M < tnw1_below) return launch_lin_ring<4, 1, 4>(g2, st);
     if (g.gelu_out != nullptr && g.K <= 256) {
       // the GELU epilogue is a long VALU phase during which nothing is issued: a deeper ring keeps loads in flight across it
-      static int deep = -1;
-      if (deep < 0) { const char* e = getenv("LTU_GELU_RING_DEEP"); deep = e ? atoi(e) : 1; }
+      int deep = -1;
+      deep = ltu_knob("LTU_GELU_RING_DEEP", 1);
       if (deep && g.K <= 128) return launch_lin_ring_e<4, 2, 6, true>(g2, st);
       if (deep) return launch_lin_ring_e<4, 2, 5, true>(g2, st);
     }
@@ -396,13 +395,13 @@ int launch_nt_ring_bf16(const IGemmArgs& g_in, hipStream_t st) {
 
 #define TN_RING 6
 static int ring_blocks() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LTU_RING_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 256; }
+  int v = -1;
+  v = ltu_knob_pos("LTU_RING_BLOCKS", 256);
   return v;
 }
 static bool ring_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LTU_NO_RING"); v = (e && atoi(e)) ? 0 : 1; }
+  int v = -1;
+  v = ltu_knob("LTU_NO_RING", 0) ? 0 : 1;
   return v == 1;
 }
 
@@ -413,8 +412,8 @@ static RingGeom tn_ring_geometry(long long M, int N, int K) {
   long long want = ring_blocks() / ((long long)t.nk * t.nn);
   if (want < 1) want = 1;
   long long rows = (M + want - 1) / want;
-  static int minrows = -1;
-  if (minrows < 0) { const char* e = getenv("LTU_RING_MINROWS"); minrows = (e && atoi(e) >= 32) ? atoi(e) : 0; }
+  int minrows = -1;
+  minrows = ltu_knob("LTU_RING_MINROWS", 0) >= 32 ? ltu_knob("LTU_RING_MINROWS", 0) : 0;
   // few rows: shorter splits put more workgroups on the serial unit loop (measured: 1 024 rows 14.8 -> 9.0 us at 128 rows per
   // split, 8 640 rows 17.7 -> 16.5 us at 256; below that the second stage grows faster than the first shrinks)
   const int mr = minrows > 0 ? minrows : (M <= 2048 ? 128 : 256);
@@ -440,11 +439,10 @@ int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out) {
   wa.npad = g.N; wa.kpad = g.K;
   wa.bpart = wa.part + (long long)t.nsplit * wa.npad * wa.kpad;
   constexpr int smem_bytes = TN_RING * 2 * 32 * 128 * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static LtuDevOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_bf16_kernel<TN_RING>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               smem_bytes);
-    attr_done = true;
   }
   hipLaunchKernelGGL((wgrad_ring_bf16_kernel<TN_RING>), dim3(t.nk, t.nn, t.nsplit), dim3(256), smem_bytes, st, wa);
   int rc = ltu_check_launch();

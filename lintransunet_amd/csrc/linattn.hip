@@ -588,8 +588,8 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
 // ------------------------------------------------------------------------------------------------ host side
 static int pick_splits(int B, int N, int* tokens_per_split) {
   // ~256..512 streaming workgroups in total, whole 32-token tiles each
-  static int total = -1;
-  if (total < 0) { const char* e = getenv("LTU_LA_SPLITS"); total = (e && atoi(e) > 0) ? atoi(e) : 512; }
+  int total = -1;
+  total = ltu_knob_pos("LTU_LA_SPLITS", 512);
   int want = total / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   int tps = (N + want - 1) / want;
@@ -600,8 +600,8 @@ static int pick_splits(int B, int N, int* tokens_per_split) {
 }
 // tokens per workgroup of the per-token kernels: ~512 workgroups, whole tiles
 static int pick_tokb(int B, int N) {
-  static int blocks = -1;
-  if (blocks < 0) { const char* e = getenv("LTU_LA_TOKB_BLOCKS"); blocks = (e && atoi(e) > 0) ? atoi(e) : 256; }     // swept 256 .. 2048
+  int blocks = -1;
+  blocks = ltu_knob_pos("LTU_LA_TOKB_BLOCKS", 256);     // swept 256 .. 2048
   long long per = ((long long)B * N + blocks - 1) / blocks;
   int tokb = (int)((per + 31) / 32 * 32);
   if (tokb < 32) tokb = 32;

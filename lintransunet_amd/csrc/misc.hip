@@ -3,7 +3,44 @@
 
 #include "common.h"
 
-extern "C" int ltu_version(void) { return 2; }
+#include <mutex>
+#include <stdlib.h>
+
+extern "C" int ltu_version(void) { return 3; }
+
+// ---- knob overrides (ltu_config_set): a small table under a mutex; see common.h ------------------------------------------
+namespace {
+struct KnobOverride { char name[40]; int value; };
+std::mutex g_knob_mu;
+KnobOverride g_knob[32];
+int g_nknob = 0;
+}  // namespace
+
+extern "C" int ltu_config_set(const char* name, int value, int clear) {
+  if (name == nullptr || strlen(name) >= sizeof(g_knob[0].name)) return LTU_E_ARG;
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  for (int i = 0; i < g_nknob; ++i)
+    if (strcmp(g_knob[i].name, name) == 0) {
+      if (clear) { g_knob[i] = g_knob[g_nknob - 1]; --g_nknob; }
+      else g_knob[i].value = value;
+      return LTU_OK;
+    }
+  if (clear) return LTU_OK;
+  if (g_nknob == 32) return LTU_E_ARG;
+  strcpy(g_knob[g_nknob].name, name);
+  g_knob[g_nknob++].value = value;
+  return LTU_OK;
+}
+
+int ltu_knob(const char* name, int dflt) {
+  {
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    for (int i = 0; i < g_nknob; ++i)
+      if (strcmp(g_knob[i].name, name) == 0) return g_knob[i].value;
+  }
+  const char* e = getenv(name);
+  return (e != nullptr && *e != 0) ? atoi(e) : dflt;
+}
 
 // One descriptor per prepared operand.  kinds:
 //   0  cast        dst[i] = src[i]                                  R*C elements

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(1024) reduce_parts_kernel(const float* __restr
   else out[i >> 1] += v;
 }
 static void launch_reduce_parts(const float* part, int nparts, int n, int groups, float* out, float* out2, int mode, hipStream_t st) {
-  if (getenv("LTU_DBG_NO_STAGE2")) return;
+  if (ltu_knob("LTU_DBG_NO_STAGE2", 0)) return;
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 32), groups), dim3(1024), 0, st, part, nparts, n, out, out2, mode);
 }
 extern "C" long long ltu_norm_ws_floats(void) { return LTU_NORM_WS_FLOATS; }
@@ -433,8 +433,8 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
 
 // ------------------------------------------------------------------------------------------------ host side
 static int stats_rows(long long S, int B, int* nchunks) {
-  static int chunks = -1;
-  if (chunks < 0) { const char* e = getenv("LTU_IN_CHUNKS"); chunks = (e && atoi(e) > 0) ? atoi(e) : 2048; }
+  int chunks = -1;
+  chunks = ltu_knob_pos("LTU_IN_CHUNKS", 2048);
   long long want = chunks / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   long long rows = (S + want - 1) / want;

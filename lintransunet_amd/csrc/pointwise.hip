@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(256) gelu_drop_bf16x8_kernel(const uint4* __re
   if (i < n8) out[i] = gelu8<BWD>(dc, i, u[i], BWD ? dh[i] : z);
 }
 static unsigned gelu8_grid(long long n8) {
-  static int per = -1;
-  if (per < 0) { const char* e = getenv("LTU_GELU_PER_BLOCK"); per = (e && atoi(e) >= 256) ? atoi(e) : 512; }
+  int per = -1;
+  per = ltu_knob("LTU_GELU_PER_BLOCK", 512) >= 256 ? ltu_knob("LTU_GELU_PER_BLOCK", 512) : 512;
   long long blocks = (n8 + per - 1) / per;      // 512: two 16-byte pieces per thread
   if (blocks > 16384) blocks = 16384;
   return (unsigned)(blocks < 1 ? 1 : blocks);

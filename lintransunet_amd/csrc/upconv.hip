@@ -26,7 +26,7 @@ extern "C" int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bi
                               int Co, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
   const size_t esz = dtype == LTU_BF16 ? 2 : 4;
-  if (dtype == LTU_BF16 && !getenv("LTU_NO_CLASS_HALO")) {      // all 8 classes from one LDS halo brick
+  if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {      // all 8 classes from one LDS halo brick
     ClassHaloArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = wsub_f; a.bias = bias; a.o0 = y; a.o1 = y;
@@ -127,7 +127,7 @@ __global__ void upconv_fold_kernel(const float* __restrict__ dweff, float* __res
 extern "C" int ltu_upconv_wgrad(const void* grad, const void* x, float* dweff, float* db, float* dw_torch, int co_real,
                                 int ci_real, float* ws, int B, int H, int W, int D, int Ci, int Co, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
-  if (dtype == LTU_BF16 && ws != nullptr && !getenv("LTU_NO_CLASS_HALO")) {
+  if (dtype == LTU_BF16 && ws != nullptr && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {
     // all classes and taps from LDS halo bricks, folded in registers; the reduce kernel writes the PyTorch layout
     UpWgradArgs u;
     memset(&u, 0, sizeof(u));

@@ -392,6 +392,29 @@ def fx_model_multi(tag, cfg, size, batch, wseed):
         out[f'mask{i}'] = np32(m)
     np.savez_compressed(os.path.join(HERE, f'model_{tag}.npz'), **out)
 
+def fx_infer512():
+    """BASELINE config 5 at its real window size: the reference's eval-mode model (one-hot arg-max windows,
+    model/trans_3DUnet.py:199-202) as the predictor of the sliding-window driver (inference_embed_attn.py:141) over a 512x512x40
+    scan = two 512x512x32 windows, overlap 0.6.  The window scheduling / blending is the oracle's (monai absent: parity unpinned
+    there, oracle/infer.py); the per-window network output is the reference's own."""
+    cfg = O_net.NetConfig()
+    P = seedgen.seeded_params(O_net.param_shapes(cfg), 700)
+    Model = get_model_dict('MaskTransUnet')
+    model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
+                  dim_input=cfg.dim_input, dim_output=cfg.dim_output, kernel_size=3)
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    x = seedgen.seeded_volume((1, 1, 512, 512, 40), 701)
+    with torch.no_grad():
+        out = O_infer.sliding_window_inference(x, (512, 512, 32), 4, model, overlap=0.6)
+        first = O_net.forward(P, cfg, x[..., :32], training=False)          # the oracle's network on the first window
+        close(first, model(x[..., :32]), 'infer512.window0', 0)
+    votes = (out[0, 1] * 2).round().to(torch.uint8)                         # class-1 votes in {0, 1, 2} halves
+    assert torch.equal(votes.float() / 2, out[0, 1]) and torch.allclose(out.sum(1), torch.ones_like(out[:, 0]))
+    np.savez_compressed(os.path.join(HERE, 'infer512.npz'), votes2=votes.numpy(), fg_mean=np.float64(out[:, 1].double().mean().item()))
+    print(f'infer512.npz written (mean class-1 vote {out[:, 1].mean().item():.6f})')
+
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
@@ -401,6 +424,16 @@ def main():
     small3 = O_net.NetConfig(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6], dim_output=3)
     if len(sys.argv) > 1 and sys.argv[1] == 'multi':        # only the multi-class fixture
         fx_model_multi('multi_small', small3, (32, 32, 32), 2, 400)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':     # only the BASELINE-size fixtures (reference: ~25 s and ~16 GB each)
+        fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)
+        fx_model('full96', O_net.NetConfig(), (96, 96, 96), 2, 600, full_arrays=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'infer512':     # only the config-5 window fixture (~1 min)
+        fx_infer512()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'linattn':      # only the linear-attention fixture
+        fx_linattn()
         return
     fx_model_multi('multi_small', small3, (32, 32, 32), 2, 400)
     fx_metrics()
@@ -412,6 +445,9 @@ def main():
     fx_model('small', small, (32, 32, 32), 2, 100, full_arrays=True)
     fx_model('small_wide', small, (64, 96, 16), 1, 200, full_arrays=False)
     fx_model('full32', O_net.NetConfig(), (32, 32, 32), 1, 300, full_arrays=False)
+    fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)      # BASELINE configs 3/4 patch size
+    fx_model('full96', O_net.NetConfig(), (96, 96, 96), 2, 600, full_arrays=False)          # BASELINE config 2 (96^3, batch 2)
+    fx_infer512()
     print('golden vectors written to', HERE)
 
 

@@ -103,11 +103,17 @@ def test_model_small_fp32(golden_dir):
     assert abs(int(onehot[:, 1].sum().item()) - int(G['onehot_fg_count'])) <= 2
 
 
-@pytest.mark.parametrize('tag,cfgkw,size,wseed', [('small_wide', SMALL, (64, 96, 16), 200), ('full32', {}, (32, 32, 32), 300)])
-def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, wseed):
+# full128 / full96: the BASELINE patch sizes with the reference's channel / ROI configuration (configs 3 and 2), vectors from the
+# reference itself (tests/golden/make_golden.py fullsize)
+SAMPLED = [('small_wide', SMALL, (64, 96, 16), 1, 200), ('full32', {}, (32, 32, 32), 1, 300),
+           ('full128', {}, (128, 128, 128), 1, 500), ('full96', {}, (96, 96, 96), 2, 600)]
+
+
+@pytest.mark.parametrize('tag,cfgkw,size,batch,wseed', SAMPLED)
+def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, batch, wseed):
     G = np.load(os.path.join(golden_dir, f'model_{tag}.npz'))
     cfg = O_net.NetConfig(**cfgkw)
-    model, x, label, predict, masks, totals, named = run(cfg, size, 1, wseed)
+    model, x, label, predict, masks, totals, named = run(cfg, size, batch, wseed)
     for i, b in enumerate(model.last_boxes):
         assert torch.equal(b.cpu(), torch.from_numpy(G[f'box{i}'])), f'box{i}'
     flat = predict.detach().cpu().flatten()
@@ -121,6 +127,41 @@ def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, wseed):
     worst = max(abs(sd[k].grad.double().norm().item() - n) / max(n, 1e-3) for k, n in norms.items()
                 if not exact_zero_grad(k))
     assert worst <= 1e-2, worst
+    lv = G['level_losses']
+    for lvl, vals in enumerate(named):
+        got = [v.item() for v in vals.values()]
+        assert np.allclose(got, lv[lvl], rtol=1e-4, atol=1e-5), (lvl, got, lv[lvl])
+    for i, m in enumerate(masks):
+        ref = G[f'mask{i}']
+        mm = m.detach().cpu()
+        got = mm.numpy() if mm.numel() <= 70000 else mm.flatten()[:: max(1, mm.numel() // 4096)].numpy()
+        assert rel_err(torch.from_numpy(np.ascontiguousarray(got)), ref) <= 1e-3, f'mask{i}'
+
+
+# bf16 storage at the BASELINE sizes.  Gate: Dice ("bf16: Dice gate only").  The reference's own bf16-autocast vs fp32
+# pair differs by 8e-5 in Dice at 32^3; BF16_DICE_TOL is what this path is held to against the fp32 reference.
+BF16_DICE_TOL = 5e-4
+
+
+@pytest.mark.parametrize('tag,cfgkw,size,batch,wseed', [c for c in SAMPLED if c[0] in ('full128', 'full96', 'full32')])
+def test_model_sampled_bf16(golden_dir, tag, cfgkw, size, batch, wseed):
+    G = np.load(os.path.join(golden_dir, f'model_{tag}.npz'))
+    cfg = O_net.NetConfig(**cfgkw)
+    model, x, label, predict, masks, totals, named = run(cfg, size, batch, wseed, torch.bfloat16)
+    from lintransunet_amd import losses as L
+    dice = L.DiceClassLoss()(predict.detach(), label).item()
+    total = sum(t.item() for t in totals)
+    flat = predict.detach().cpu().flatten()
+    ref = torch.from_numpy(G['out_sample']).double()
+    rel_l2 = ((flat[torch.from_numpy(G['out_idx'])].double() - ref).norm() / ref.norm()).item()
+    print(f'[bf16 {tag}] dice {dice:.6f} vs {float(G["dice"]):.6f} (d {dice - float(G["dice"]):+.2e}), total {total:.6f} vs '
+          f'{float(G["total"]):.6f}, sampled rel-L2 {rel_l2:.2e}')
+    for i, b in enumerate(model.last_boxes):        # boxes come from thresholded bf16 masks: a boundary voxel may move an edge by one
+        assert (b.cpu() - torch.from_numpy(G[f'box{i}'])).abs().max().item() <= 1.0, f'box{i}'
+    assert abs(dice - float(G['dice'])) <= BF16_DICE_TOL
+    assert abs(total - float(G['total'])) <= 1e-2 * abs(float(G['total']))
+    assert rel_l2 <= 3e-2
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
 def test_model_small_bf16_dice(golden_dir):
@@ -130,7 +171,8 @@ def test_model_small_bf16_dice(golden_dir):
     model, x, label, predict, masks, totals, named = run(cfg, (32, 32, 32), 2, 100, torch.bfloat16)
     from lintransunet_amd import losses as L
     dice = L.DiceClassLoss()(predict.detach(), label).item()
-    assert abs(dice - float(G['dice'])) <= 2e-3
+    print(f'[bf16 small] dice {dice:.6f} vs {float(G["dice"]):.6f}')
+    assert abs(dice - float(G['dice'])) <= BF16_DICE_TOL
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
@@ -276,9 +318,10 @@ def test_model_multiclass_bf16(golden_dir):
 
 
 def test_full_size_properties():
-    """BASELINE size (128^3, 2 patches, the reference's channel / ROI configuration, bf16 storage) is out of the oracle's reach, so
-    check what must hold at any size: class probabilities sum to 1 everywhere, every op is per-sample (swapping the two patches
-    swaps outputs, masks and ROI boxes), and the gradient is linear in the loss scale."""
+    """BASELINE size (128^3, 2 patches per GPU, the reference's channel / ROI configuration, bf16 storage): besides the golden
+    comparisons above (test_model_sampled_fp32 / _bf16 [full128]), size-independent properties: class probabilities sum to 1
+    everywhere, every op is per-sample (swapping the two patches swaps outputs, masks and ROI boxes), and the gradient is linear
+    in the loss scale."""
     from lintransunet_amd import train
     from lintransunet_amd.model import get_model_dict
     torch.manual_seed(7)

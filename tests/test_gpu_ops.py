@@ -449,6 +449,71 @@ def test_linattn_bf16(ops, B, h, N):
         assert rel_err(qkv.grad[:, s * d:(s + 1) * d].float(), dref[:, s * d:(s + 1) * d]) < 2e-2
 
 
+def _linattn_vs_oracle(ops, B, h, N, dtype, seed=10, late=None):
+    """forward + dq/dk/dv of the HIP core against oracle.net.linear_attention (model/trans_block.py:41-67) on the same inputs.
+    `late`: token index that receives a dominant key (placed in a later 32-token tile of a split so that the running maximum is
+    finite when it has to rescale the accumulators)"""
+    g = G(seed)
+    rnd = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q, k, v, go = (rnd(torch.randn(B, h, N, 32, generator=g)) for _ in range(4))
+    k[:, :, N // 3 if late is None else late] += 8.0
+    k[:, :, 0] += 4.0
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = O_net.linear_attention(qr, kr, vr)
+    ref.backward(go)
+    d = h * 32
+    qkv = _qkv_pack(q, k, v).to(DEV, dtype).requires_grad_(True)
+    out = ops.linear_attention(qkv, B, N, d)
+    out.backward(go.transpose(1, 2).reshape(B * N, d).to(DEV, dtype))
+    dref = _qkv_pack(qr.grad, kr.grad, vr.grad)
+    errs = [rel_err(out.float(), ref.transpose(1, 2).reshape(B * N, d))]
+    errs += [rel_err(qkv.grad[:, s * d:(s + 1) * d].float(), dref[:, s * d:(s + 1) * d]) for s in range(3)]
+    return errs
+
+
+# the token counts of the four transformers at 128^3 (SURVEY section 7 step 3 / App. A): ROI level 1 (B=2, h=4, 57 408 tokens: 256
+# tokens = 8 tiles per split, the shape bench.py times), ROI level 2, ROI level 3, bottleneck
+HEADLINE = [(2, 4, 57408), (2, 8, 10752), (2, 8, 4320), (2, 8, 512)]
+
+
+@pytest.mark.parametrize('B,h,N', HEADLINE)
+def test_linattn_headline_fp32(ops, B, h, N):
+    from lintransunet_amd import _lib
+    tps = -(-N // max(1, 512 // B))
+    tps = max(32, (tps + 31) // 32 * 32)
+    assert _lib.load().ltu_linattn_splits(B, N) == -(-N // tps)
+    # dominant key in the LAST tile of the first split (finite running max when it arrives)
+    errs = _linattn_vs_oracle(ops, B, h, N, torch.float32, late=min(N, tps) - 1)
+    assert errs[0] < 1e-4 and max(errs[1:]) < 3e-4, errs
+
+
+@pytest.mark.parametrize('B,h,N', HEADLINE)
+def test_linattn_headline_bf16(ops, B, h, N):
+    tps = max(32, (-(-N // max(1, 512 // B)) + 31) // 32 * 32)
+    errs = _linattn_vs_oracle(ops, B, h, N, torch.bfloat16, late=min(N, tps) - 1)
+    assert errs[0] < 1.5e-2 and max(errs[1:]) < 2e-2, errs
+
+
+@pytest.mark.parametrize('splits,B,h,N,late', [(4, 2, 2, 1000, 200), (2, 1, 4, 517, 258), (1, 1, 8, 333, 300), (6, 2, 4, 4097, 1300)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linattn_many_tiles_per_split(ops, splits, B, h, N, late, dtype):
+    """few splits at small N (knob LTU_LA_SPLITS): every workgroup of linattn_kv_partial / linattn_dctx_partial walks several
+    32-token tiles, so the in-kernel running-max rescale (finite m_run, alpha < 1) and the prefetch-next-tile pipeline run
+    several iterations; the dominant key sits in a later tile of its split"""
+    from lintransunet_amd import _lib
+    _lib.config_set('LTU_LA_SPLITS', splits)
+    try:
+        nsplit = _lib.load().ltu_linattn_splits(B, N)
+        assert N / nsplit > 64          # > 2 tiles per split
+        errs = _linattn_vs_oracle(ops, B, h, N, dtype, seed=12, late=late)
+    finally:
+        _lib.config_set('LTU_LA_SPLITS', None)
+    if dtype == torch.float32:
+        assert errs[0] < 1e-4 and max(errs[1:]) < 3e-4, errs
+    else:
+        assert errs[0] < 1.5e-2 and max(errs[1:]) < 2e-2, errs
+
+
 def test_attn_layer_golden(ops, golden_dir):
     """one whole post-norm layer (qkv GEMM, attention core, out-proj, LN, FFN, LN) vs the reference's vectors"""
     Gd = np.load(os.path.join(golden_dir, 'attn_layer.npz'))

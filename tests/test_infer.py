@@ -107,6 +107,46 @@ def test_infer_volume_with_model():
     assert torch.equal(out_g, out)                                                # graph replay of the same kernels
 
 
+@pytest.mark.gpu
+def test_config5_window_batch_vs_oracle():
+    """BASELINE config 5 at its real window size: a 512x512x40 scan = two 512x512x32 windows (overlap 0.6, sw batch 4) through
+    the window gather / vote accumulate / finalize kernels, against oracle/infer.py with the same stand-in predictor: exact"""
+    from lintransunet_amd import infer as P
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((1, 1, 512, 512, 40), generator=g)
+    ref = O.sliding_window_inference(x, (512, 512, 32), 4, _onehot_predictor, overlap=0.6)
+    got = P.sliding_window_inference(x.to(DEV), (512, 512, 32), 4, _onehot_predictor, overlap=0.6)
+    assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_config5_model_golden(golden_dir, dtype):
+    """the real eval-mode network (reference channel / ROI configuration) over the same 512x512x40 scan: class-1 votes against the
+    vectors produced by the REFERENCE model under the oracle's window driver (tests/golden/make_golden.py infer512).  The network
+    has random weights, so 48 % of the voxels are foreground and many sit near the arg-max tie: fp32 may flip a few, bf16 more."""
+    from lintransunet_amd import infer as P
+    from lintransunet_amd.model import get_model_dict
+    from oracle import net as O_net, seedgen
+    G = np.load(os.path.join(golden_dir, 'infer512.npz'))
+    cfg = O_net.NetConfig()
+    model = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, 2, act_dtype=dtype)
+    model.load_state_dict(seedgen.seeded_params(O_net.param_shapes(cfg), 700), strict=True)
+    model = model.to(DEV)
+    x = seedgen.seeded_volume((1, 1, 512, 512, 40), 701).to(DEV)
+    out = P.infer_volume(model, x, depth_size=32, roi_xy=512, sw_batch_size=4, overlap=0.6)
+    assert out.shape == (1, 2, 512, 512, 40)
+    votes = (out[0, 1] * 2).round().to(torch.uint8).cpu()
+    ref = torch.from_numpy(G['votes2'])
+    mism = (votes != ref).float().mean().item()
+    print(f'[config5 {dtype}] voxels whose vote differs from the reference: {mism:.3e}')
+    assert mism <= (2e-4 if dtype == torch.float32 else 3e-2)
+    # Dice between the thresholded volumes (what inference_embed_attn.py:146-150 scores)
+    a, b = (votes >= 1).double(), (ref >= 1).double()
+    dice = (2 * (a * b).sum() / (a.sum() + b.sum())).item()
+    assert dice >= (1 - 2e-4 if dtype == torch.float32 else 0.97)
+
+
 def _blobs(seed, shape=(2, 3, 20, 18, 14)):
     g = torch.Generator().manual_seed(seed)
     B, C, H, W, D = shape
