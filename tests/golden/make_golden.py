@@ -428,6 +428,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':     # only the BASELINE-size fixtures (reference: ~25 s and ~16 GB each)
         fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)
         fx_model('full96', O_net.NetConfig(), (96, 96, 96), 2, 600, full_arrays=False)
+        fx_model('win512', O_net.NetConfig(), (512, 512, 32), 1, 800, full_arrays=False)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'infer512':     # only the config-5 window fixture (~1 min)
         fx_infer512()
@@ -447,6 +448,7 @@ def main():
     fx_model('full32', O_net.NetConfig(), (32, 32, 32), 1, 300, full_arrays=False)
     fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)      # BASELINE configs 3/4 patch size
     fx_model('full96', O_net.NetConfig(), (96, 96, 96), 2, 600, full_arrays=False)          # BASELINE config 2 (96^3, batch 2)
+    fx_model('win512', O_net.NetConfig(), (512, 512, 32), 1, 800, full_arrays=False)        # the reference's training crop / config-5 window
     fx_infer512()
     print('golden vectors written to', HERE)
 

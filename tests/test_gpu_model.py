@@ -106,7 +106,8 @@ def test_model_small_fp32(golden_dir):
 # full128 / full96: the BASELINE patch sizes with the reference's channel / ROI configuration (configs 3 and 2), vectors from the
 # reference itself (tests/golden/make_golden.py fullsize)
 SAMPLED = [('small_wide', SMALL, (64, 96, 16), 1, 200), ('full32', {}, (32, 32, 32), 1, 300),
-           ('full128', {}, (128, 128, 128), 1, 500), ('full96', {}, (96, 96, 96), 2, 600)]
+           ('full128', {}, (128, 128, 128), 1, 500), ('full96', {}, (96, 96, 96), 2, 600),
+           ('win512', {}, (512, 512, 32), 1, 800)]       # the reference's own training crop / inference window
 
 
 @pytest.mark.parametrize('tag,cfgkw,size,batch,wseed', SAMPLED)
@@ -139,11 +140,18 @@ def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, batch, wseed):
 
 
 # bf16 storage at the BASELINE sizes.  Gate: Dice ("bf16: Dice gate only").  The reference's own bf16-autocast vs fp32
-# pair differs by 8e-5 in Dice at 32^3; BF16_DICE_TOL is what this path is held to against the fp32 reference.
-BF16_DICE_TOL = 5e-4
+# pair differs by 8e-5 in Dice at 32^3; BF16_DICE_TOL is what this path is held to against the fp32 reference
+# (observed 7e-5 .. 1.8e-4 on these random-weight cases, where the Dice loss is 0.84 .. 0.92, i.e. nearly degenerate; the gate on
+# a trained model and a held-out volume is tests/test_heldout.py).
+# The ROI boxes are step functions of the coarser mask (get_mask_boundary2 thresholds it at 0.5, Unet_3Dblock.py:738-739).  With
+# random weights the masks hover around 0.5, so a bf16-sized perturbation can move a box edge by one cell; every activation behind
+# that ROI bridge then differs by O(1) although each op is exact to bf16 (tools/diag_trace.py shows the op-by-op picture: 2e-2
+# drift up to the first moved box, 3e-1 right after it).  The element-wise gate therefore applies when the boxes agree.
+BF16_DICE_TOL = 3e-4
+BF16_DICE_TOL_MOVED_BOX = 1e-3
 
 
-@pytest.mark.parametrize('tag,cfgkw,size,batch,wseed', [c for c in SAMPLED if c[0] in ('full128', 'full96', 'full32')])
+@pytest.mark.parametrize('tag,cfgkw,size,batch,wseed', [c for c in SAMPLED if c[0] in ('full128', 'full96', 'full32', 'win512')])
 def test_model_sampled_bf16(golden_dir, tag, cfgkw, size, batch, wseed):
     G = np.load(os.path.join(golden_dir, f'model_{tag}.npz'))
     cfg = O_net.NetConfig(**cfgkw)
@@ -156,11 +164,14 @@ def test_model_sampled_bf16(golden_dir, tag, cfgkw, size, batch, wseed):
     rel_l2 = ((flat[torch.from_numpy(G['out_idx'])].double() - ref).norm() / ref.norm()).item()
     print(f'[bf16 {tag}] dice {dice:.6f} vs {float(G["dice"]):.6f} (d {dice - float(G["dice"]):+.2e}), total {total:.6f} vs '
           f'{float(G["total"]):.6f}, sampled rel-L2 {rel_l2:.2e}')
-    for i, b in enumerate(model.last_boxes):        # boxes come from thresholded bf16 masks: a boundary voxel may move an edge by one
-        assert (b.cpu() - torch.from_numpy(G[f'box{i}'])).abs().max().item() <= 1.0, f'box{i}'
-    assert abs(dice - float(G['dice'])) <= BF16_DICE_TOL
+    moved = 0.0
+    for i, b in enumerate(model.last_boxes):
+        moved = max(moved, (b.cpu() - torch.from_numpy(G[f'box{i}'])).abs().max().item())
+    assert moved <= 1.0
+    assert abs(dice - float(G['dice'])) <= (BF16_DICE_TOL if moved == 0 else BF16_DICE_TOL_MOVED_BOX)
     assert abs(total - float(G['total'])) <= 1e-2 * abs(float(G['total']))
-    assert rel_l2 <= 3e-2
+    if moved == 0:
+        assert rel_l2 <= 3e-2
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 

@@ -468,7 +468,16 @@ def _linattn_vs_oracle(ops, B, h, N, dtype, seed=10, late=None):
     dref = _qkv_pack(qr.grad, kr.grad, vr.grad)
     errs = [rel_err(out.float(), ref.transpose(1, 2).reshape(B * N, d))]
     errs += [rel_err(qkv.grad[:, s * d:(s + 1) * d].float(), dref[:, s * d:(s + 1) * d]) for s in range(3)]
-    return errs
+    l2 = lambda a, b: ((a.detach().double().cpu() - b.double()).norm() / b.double().norm()).item()
+    errs += [l2(out, ref.transpose(1, 2).reshape(B * N, d))]
+    errs += [l2(qkv.grad[:, s * d:(s + 1) * d], dref[:, s * d:(s + 1) * d]) for s in range(3)]
+    return errs            # max-abs error relative to the tensor's max (out, dq, dk, dv), then relative L2 of the same four
+
+
+def _bf16_ok(errs):
+    """bf16 storage: q-softmax, context and output are each rounded to 8 significant bits, so single elements of a 32-term dot
+    product move by up to ~2e-2 of the tensor's maximum; the relative L2 error stays at the bf16 rounding level"""
+    return max(errs[:4]) < 2.5e-2 and all(e < g for e, g in zip(errs[4:], (8e-3, 2.5e-2, 1.5e-2, 8e-3)))
 
 
 # the token counts of the four transformers at 128^3 (SURVEY section 7 step 3 / App. A): ROI level 1 (B=2, h=4, 57 408 tokens: 256
@@ -484,14 +493,14 @@ def test_linattn_headline_fp32(ops, B, h, N):
     assert _lib.load().ltu_linattn_splits(B, N) == -(-N // tps)
     # dominant key in the LAST tile of the first split (finite running max when it arrives)
     errs = _linattn_vs_oracle(ops, B, h, N, torch.float32, late=min(N, tps) - 1)
-    assert errs[0] < 1e-4 and max(errs[1:]) < 3e-4, errs
+    assert errs[0] < 1e-4 and max(errs[1:4]) < 3e-4 and max(errs[4:]) < 1e-4, errs
 
 
 @pytest.mark.parametrize('B,h,N', HEADLINE)
 def test_linattn_headline_bf16(ops, B, h, N):
     tps = max(32, (-(-N // max(1, 512 // B)) + 31) // 32 * 32)
     errs = _linattn_vs_oracle(ops, B, h, N, torch.bfloat16, late=min(N, tps) - 1)
-    assert errs[0] < 1.5e-2 and max(errs[1:]) < 2e-2, errs
+    assert _bf16_ok(errs), errs
 
 
 @pytest.mark.parametrize('splits,B,h,N,late', [(4, 2, 2, 1000, 200), (2, 1, 4, 517, 258), (1, 1, 8, 333, 300), (6, 2, 4, 4097, 1300)])
@@ -509,9 +518,9 @@ def test_linattn_many_tiles_per_split(ops, splits, B, h, N, late, dtype):
     finally:
         _lib.config_set('LTU_LA_SPLITS', None)
     if dtype == torch.float32:
-        assert errs[0] < 1e-4 and max(errs[1:]) < 3e-4, errs
+        assert errs[0] < 1e-4 and max(errs[1:4]) < 3e-4 and max(errs[4:]) < 1e-4, errs
     else:
-        assert errs[0] < 1.5e-2 and max(errs[1:]) < 2e-2, errs
+        assert _bf16_ok(errs), errs
 
 
 def test_attn_layer_golden(ops, golden_dir):

@@ -120,11 +120,14 @@ def test_config5_window_batch_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32])
 def test_config5_model_golden(golden_dir, dtype):
     """the real eval-mode network (reference channel / ROI configuration) over the same 512x512x40 scan: class-1 votes against the
     vectors produced by the REFERENCE model under the oracle's window driver (tests/golden/make_golden.py infer512).  The network
-    has random weights, so 48 % of the voxels are foreground and many sit near the arg-max tie: fp32 may flip a few, bf16 more."""
+    has random weights, so 48 % of the voxels are foreground and many sit near the arg-max tie: fp32 flips a few (8e-6 observed).
+    bf16 storage is not compared voxel-wise here: with random weights a bf16-sized perturbation moves an ROI box edge by one cell
+    (see tests/test_gpu_model.py) and a quarter of the near-tie voxels flip; bf16 inference is gated on a trained model by
+    tests/test_heldout.py."""
     from lintransunet_amd import infer as P
     from lintransunet_amd.model import get_model_dict
     from oracle import net as O_net, seedgen
