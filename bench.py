@@ -6,18 +6,21 @@
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU, weak scaling (2 patches per GPU, BASELINE.json config 3): every rank draws its own
-synthetic patches, gradients are all-reduced (mean) over RCCL in buckets overlapped with backward.  A "step" is
-one inner training step of utils/utils_3D_embed_full.py:55-86 (dropout 0.3 as in training, no optimizer step,
-inputs resident in HBM).  Rank 0 prints ONE JSON line.
+synthetic patches, gradients are all-reduced (mean) over RCCL in buckets overlapped with backward (captured as
+side branches of the step's HIP graph).  A "step" is one inner training step of
+utils/utils_3D_embed_full.py:55-86 (dropout 0.3 as in training, no optimizer step, inputs resident in HBM).
+Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches itself: the parent starts N
+child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE
+anything touches the GPU, relays their output and exits non-zero if any child fails.  `--dry-run` exercises exactly
+that launcher + rendezvous + JSON plumbing on the CPU (gloo), without the model.
 """
 import argparse
 import json
 import os
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,18 +31,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
+# Whole-step mixed roofline of SURVEY.md section 8d: T_roof(fwd+bwd) per 128^3 patch = 3 * (394.1 GFLOP of 3x3x3 convs / 2.5 PFLOP/s
+# + 5.11 GB of everything else / 8 TB/s) = 2.39 ms; other patch sizes scale with the measured per-size work of the same table.
+ROOF_MS_PER_PATCH = {128: 3 * (394.1e9 / 2.5e15 + (5.797e9 - 0.686e9) / 8e12) * 1e3,
+                     96: 3 * (254.4e9 / 2.5e15 + (4.023e9 - 0.396e9) / 8e12) * 1e3}
+
+
 def synthetic_batch(batch, size, seed, device, n_classes=2):
     """N(0,1) volume clipped to the dataset's normalised HU range + ellipsoid labels (3 label
     values for the multi-class configuration 4)."""
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn((batch, 1) + size, generator=g).clamp_(-4.51, 4.14)
-    from oracle import seedgen       # label generator only (test infrastructure helper, not on the timed path)
-    lab = seedgen.seeded_label((batch, 1) + size, seed + 1, n_blobs=2, n_classes=n_classes)
-    return x.to(device), lab.to(device)
+    from lintransunet_amd import data
+    return data.synthetic_patches(batch, size, seed, device, n_classes=n_classes)
 
 
-def cpu_baseline(size=(128, 128, 128), threads=None):
-    """The oracle (CPU restatement of the reference, fp32, dropout on) timed for ONE step at B=1: a bounded sample."""
+def cpu_baseline(size=(128, 128, 128), threads=None, timed=2):
+    """The oracle (CPU restatement of the reference, fp32, dropout on): 1 warm-up + `timed` timed steps at B=1, mean."""
+    import torch
     from oracle import net as O_net, seedgen, step as O_step
     if threads is None:        # the box exposes every host core but grants a 16-core share per GPU
         try:
@@ -48,16 +55,23 @@ def cpu_baseline(size=(128, 128, 128), threads=None):
             threads = os.cpu_count() or 1
         threads = max(1, min(threads, 16))
     torch.set_num_threads(threads)
-    print(f'[bench] cpu_baseline: oracle step on {threads} host threads ...', file=sys.stderr, flush=True)
+    print(f'[bench] cpu_baseline: oracle, 1 warm-up + {timed} timed steps on {threads} host threads ...', file=sys.stderr, flush=True)
     cfg = O_net.NetConfig(dropout=0.3)
     P = seedgen.seeded_params(O_net.param_shapes(cfg), 7, requires_grad=True)
     x = seedgen.seeded_volume((1, 1) + size, 8)
     lab = seedgen.seeded_label((1, 1) + size, 9)
-    t0 = time.perf_counter()
-    O_step.train_step(P, cfg, x, lab, O_step.dynamic_weights(0))
-    dt = time.perf_counter() - t0
+    times = []
+    for i in range(1 + timed):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        O_step.train_step(P, cfg, x, lab, O_step.dynamic_weights(0))
+        times.append(time.perf_counter() - t0)
+        print(f'[bench] cpu_baseline step {i}: {times[-1]:.1f} s', file=sys.stderr, flush=True)
+    dt = sum(times[1:]) / timed
     return {'value': 1.0 / dt, 'unit': 'patches/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 fwd+bwd step, {size[0]}^3 B=1, fp32, dropout 0.3, no warm-up ({dt:.1f} s)'}
+            'sample': f'{timed} fwd+bwd steps after 1 warm-up, {size[0]}^3 B=1, fp32, dropout 0.3 (warm-up {times[0]:.1f} s, timed '
+                      + ', '.join(f'{t:.1f}' for t in times[1:]) + ' s)'}
 
 
 class KernelTimer:
@@ -82,6 +96,7 @@ class KernelTimer:
 
     def measure(self, replay_fn, reps=5):
         """replay_fn(args) re-issues one recorded launch; returns (total ms per pass over all recorded launches, launches)"""
+        import torch
         if not self.calls:
             return 0.0, 0
         s = torch.cuda.Stream()
@@ -106,7 +121,7 @@ class KernelTimer:
         return e0.elapsed_time(e1) / reps, len(self.calls)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -118,12 +133,105 @@ def main():
                     help='model outputs: 2 = single-class pancreas (BASELINE configs 2/3), 3 = multi-class path (config 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured HIP graph')
-    args = ap.parse_args()
+    ap.add_argument('--allreduce', default=None, choices=['graph', 'after'],
+                    help="gradient all-reduce of the graph-replayed step: captured inside the graph (overlapped, default) or after the replay")
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU/gloo rehearsal of the launcher, rendezvous, barrier / max-over-ranks timing and the JSON line; no GPU, no model')
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children.  The parent never initialises the GPU (it
+    imports nothing that does) and never replaces itself; rank 0's JSON line reaches stdout through the inherited descriptor."""
+    import subprocess
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(len(procs)))
+        while pending:
+            for i in list(pending):
+                code = procs[i].poll()
+                if code is None:
+                    continue
+                pending.discard(i)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f'[bench] rank {i} exited with {code}; stopping the other ranks', file=sys.stderr)
+                    for k in pending:
+                        procs[k].terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """the multi-process plumbing of main() on the CPU: gloo rendezvous, barrier-bracketed timed region, MAX over ranks, one line"""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get('LTU_BENCH_FAIL_RANK') == str(rank):       # test hook: a rank that dies before the rendezvous
+        raise RuntimeError('simulated rank failure')
+    if world > 1:
+        dist.init_process_group('gloo')
+    buf = torch.zeros(1 << 16)
+    for _ in range(args.warmup):
+        if world > 1:
+            dist.all_reduce(buf)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        buf.add_(1.0)
+        if world > 1:
+            dist.all_reduce(buf)
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': f'{args.size}^3 CT patches/sec (fwd+bwd)', 'value': None, 'unit': 'patches/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': tmax.item() / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'none',
+                          'config': {'workload': 'dry run: launcher + gloo rendezvous only, no GPU work', 'parallelism': f'dp{world}'}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))         # before torch / HIP are touched in this process
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        print(f'[bench] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: using {world} ranks', file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
@@ -182,16 +290,25 @@ def main():
     timer.calls = []
 
     launch = 'eager'
+    allreduce = 'hooks (overlapped with backward)' if world > 1 else 'none (1 rank)'
     step = eager_step
     if not args.no_graph:
-        try:
-            graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer, specs=specs)
-            step = lambda i: graphed(*batches[i % 2])
-            launch = 'hip-graph replay'
-        except Exception as e:                     # a failed capture must not cost the measurement: same kernels, launched eagerly
-            print(f'[bench] HIP-graph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
-            ops.set_step_counter(None)
-            torch.cuda.synchronize()
+        # ladder: collectives captured inside the step graph (overlapped) -> collectives after the replay -> eager launches.
+        # A failed capture must not cost the measurement; every rung runs the same kernels.
+        modes = [args.allreduce] if args.allreduce else (['graph', 'after'] if world > 1 else ['graph'])
+        for mode in modes:
+            try:
+                graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer, specs=specs, overlap=mode)
+                step = lambda i: graphed(*batches[i % 2])
+                launch = 'hip-graph replay'
+                if world > 1:
+                    allreduce = ('captured in the step graph (side branches, overlapped with backward)' if mode == 'graph'
+                                 else 'after the replay (exposed)')
+                break
+            except Exception as e:
+                print(f'[bench] rank {rank}: HIP-graph capture with all-reduce mode {mode!r} failed ({type(e).__name__}: {e})',
+                      file=sys.stderr)
+                torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -214,22 +331,32 @@ def main():
     if rank == 0:
         patches = args.batch * world * args.steps
         achieved = timer.work / (ms_lin * 1e-3) / 1e9 if ms_lin > 0 else 0.0       # GB/s
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_linear.json')                # FETCH/WRITE_SIZE of the same launches
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        # HBM traffic of the same launches from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): counters need their own
+        # rocprofv3 --pmc passes, so this is the committed offline collection of tools/pmc_collect.sh, not a live number
+        traffic, traffic_src = None, None
+        for name in ('r02_pmc_linear.json', 'r01_pmc_linear.json'):
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(pmc):
+                traffic, traffic_src = json.load(open(pmc)).get('hbm_bytes_per_launch'), 'profiles/' + name
+                break
+        ms_step = dt / args.steps * 1e3
+        roof_ms = ROOF_MS_PER_PATCH.get(args.size)
         out = {
             'metric': f'{args.size}^3 CT patches/sec (fwd+bwd)', 'value': patches / dt, 'unit': 'patches/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights' + (', 3 labels (multi-class losses)' if args.classes == 3 else ''), 'global_batch': args.batch * world,
-                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch},
+                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch, 'allreduce': allreduce},
             'roofline': {'bound': 'hbm', 'kernel': 'linear_ring_bf16_kernel (transformer projections, forward launches; the FFN front half carries GELU + dropout)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),
                          'algorithmic_bytes_per_launch': timer.work / max(n_lin, 1), 'traffic': traffic,
-                         'timing': 'one HIP event pair around a graph replay of exactly these launches'},
+                         'traffic_source': traffic_src,
+                         'timing': 'one HIP event pair around a graph replay of exactly these launches',
+                         # the whole step against SURVEY 8d's mixed roofline (convs at the MFMA peak + everything else at the HBM peak)
+                         'step_roofline_ms': roof_ms * args.batch if roof_ms else None,
+                         'step_frac': (roof_ms * args.batch / ms_step) if roof_ms else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(size)

@@ -256,9 +256,11 @@ int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W
  *      loss/multi_criterions.py:58-110,594-615 ------------------------------------------------------
  * p f32 [B][S][C] probabilities, label u8 [B][S].  total = w_ce*CE + w_bal*BalancedDice + sum_c w_dice[c]*Dice_c.
  * values[0] = total, [1] = CE, [2] = balanced Dice, [3+c] = Dice_c;  sums [B][C][4] zero-filled scratch;
- * coef [B][C][3] feeds ltu_loss_bwd: dp = gscale[0] * dTotal/dp. */
+ * coef [B][C][3] feeds ltu_loss_bwd: dp = gscale[0] * dTotal/dp.  scale_dev (nullable): device-resident factor on all three
+ * weights, read at run time (the per-epoch level weight of train3D.py:122-137 divided by the accumulation count of
+ * utils/utils_3D_embed_full.py:85, so a captured graph follows both without re-capture). */
 int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
-                 float w_ce, float w_bal, const float* w_dice, ltu_stream_t s);
+                 float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s);
 int ltu_loss_bwd(const float* p, const uint8_t* label, const float* coef, const float* gscale, float* dp, int B,
                  long long S, int C, ltu_stream_t s);
 /* label pyramid (utils/utils_3D_embed_full.py:64,73-76): u8 [B,H,W,D] -> max over (2,2,kd) windows */

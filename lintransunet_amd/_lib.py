@@ -83,7 +83,7 @@ SIGNATURES = {
     'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P],
     'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     'ltu_trilinear_up': [P, P, I, I, I, I, I, I, I, I, P],
-    'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P],
+    'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P, P],
     'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
     'ltu_label_maxpool': [P, P, I, I, I, I, I, P],
 }

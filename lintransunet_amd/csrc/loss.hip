@@ -63,9 +63,16 @@ struct LossCfg {
   float w_ce, w_bal, w_dice[LOSS_MAXC];
 };
 
+// scale_dev (nullable): a device-resident factor applied to all loss weights of this level (the per-epoch deep-supervision weight
+// divided by the number of accumulated micro-steps): a captured HIP graph then follows weight changes without being re-captured.
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ values, float* __restrict__ coef, int B,
-                                     long long S, int C, LossCfg cfg) {
+                                     long long S, int C, LossCfg cfg, const float* __restrict__ scale_dev) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (scale_dev != nullptr) {
+    const float sc = scale_dev[0];
+    cfg.w_ce *= sc; cfg.w_bal *= sc;
+    for (int c = 0; c < LOSS_MAXC; ++c) cfg.w_dice[c] *= sc;
+  }
   float ce = 0.f, bal = 0.f, dice[LOSS_MAXC] = {0.f, 0.f, 0.f, 0.f};
   const float Z = (float)B * (float)S * (float)C;
   for (int b = 0; b < B; ++b) {
@@ -137,7 +144,7 @@ __global__ void loss_bwd_kernel(const float* __restrict__ p, const uint8_t* __re
 }
 
 extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
-                            float w_ce, float w_bal, const float* w_dice, ltu_stream_t s) {
+                            float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s) {
   if (C < 1 || C > LOSS_MAXC) return LTU_E_SHAPE;
   long long want = 1024 / (B > 0 ? B : 1);
   if (want < 1) want = 1;
@@ -147,7 +154,7 @@ extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, f
   cfg.w_ce = w_ce; cfg.w_bal = w_bal;
   for (int c = 0; c < LOSS_MAXC; ++c) cfg.w_dice[c] = (c < C && w_dice) ? w_dice[c] : 0.f;
   hipLaunchKernelGGL(loss_sums_kernel, dim3(cdiv(S, rows), B), dim3(256), 0, (hipStream_t)s, p, label, sums, S, C, (int)rows);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, sums, values, coef, B, S, C, cfg);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, sums, values, coef, B, S, C, cfg, scale_dev);
   return ltu_check_launch();
 }
 

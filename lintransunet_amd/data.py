@@ -177,3 +177,26 @@ def augment(img, lab, params):
             _lib.call('ltu_crop_flip', _p(lab8[k]), _p(ol[k]), _p(desc[k]), 1, h, w, d, h, w, d, 1, _s())
         img, lab8 = oi, ol
     return img, lab8
+
+
+def synthetic_patches(batch, size, seed, device, n_classes=2, n_blobs=2):
+    """Synthetic CT-like training patches for benchmarks and soak runs: N(0,1) intensities clipped to
+    the dataset's normalised HU range [(-91 - 86.9) / 39.4, (250 - 86.9) / 39.4] and a label volume that is a union of `n_blobs`
+    random ellipsoids per patch (nested twice for 3 label values).  Host generators (seeded), uploaded once: a benchmark keeps its
+    inputs resident in HBM.  Returns (x f32 [B,1,H,W,D], label u8 [B,1,H,W,D])."""
+    g = torch.Generator().manual_seed(seed)
+    H, W, D = size
+    x = torch.randn((batch, 1, H, W, D), generator=g).clamp_((LOW_CLIP - MEAN) / STD, (HIGH_CLIP - MEAN) / STD)
+    hh = torch.arange(H, dtype=torch.float32).view(H, 1, 1)
+    ww = torch.arange(W, dtype=torch.float32).view(1, W, 1)
+    dd = torch.arange(D, dtype=torch.float32).view(1, 1, D)
+    lab = torch.zeros((batch, 1, H, W, D), dtype=torch.uint8)
+    for b in range(batch):
+        for _ in range(n_blobs):
+            c = 0.25 + 0.5 * torch.rand(3, generator=g)
+            r = 0.12 + 0.15 * torch.rand(3, generator=g)
+            dist = ((hh - c[0] * H) / (r[0] * H)) ** 2 + ((ww - c[1] * W) / (r[1] * W)) ** 2 + ((dd - c[2] * D) / (r[2] * D)) ** 2
+            lab[b, 0][dist <= 1.0] = 1
+            if n_classes == 3:
+                lab[b, 0][dist <= 0.25] = 2
+    return x.to(device), lab.to(device)

@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .ops import _p, _s
 
 
@@ -140,18 +140,24 @@ class GraphedPredictor:
     def __init__(self, model, batch, roi, device):
         self.model, self.n = model, batch
         self.x = torch.zeros((batch, 1) + tuple(roi), device=device, dtype=torch.float32)
+        self.ctx = ops.Context()          # own scratch arena: the graph bakes its addresses in, nobody else may move it
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side), torch.no_grad():
+        with torch.cuda.stream(side), torch.no_grad(), ops.use(self.ctx):
             for _ in range(2):
                 model(self.x)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'), torch.no_grad():
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'), torch.no_grad(), ops.use(self.ctx):
             self.y = model(self.x)
+        self.ctx.freeze()
+        self.sig = tuple(p.data_ptr() for p in model.parameters())
 
     def __call__(self, win):
+        if tuple(p.data_ptr() for p in self.model.parameters()) != self.sig:
+            raise _lib.LtuError('GraphedPredictor: parameter storage moved since capture (build the predictor after .to() / '
+                                'optimizer construction, or build a new one)')
         n = win.shape[0]
         self.x[:n].copy_(win)
         if n < self.n:

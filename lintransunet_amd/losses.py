@@ -37,13 +37,14 @@ class LevelCriterion(nn.Module):
     """
     _DICE = {'DiceClassLoss': 1, 'DiceClassLoss2': 2, 'DiceClassLoss0c': 0}
 
-    def __init__(self, spec: dict, scale: float = 1.0):
+    def __init__(self, spec: dict, scale: float = 1.0, scale_dev=None):
         super().__init__()
         unknown = set(spec) - {'CrossEntroLoss', 'BalanceDiceLoss', *self._DICE}
         if unknown:
             raise KeyError(f'no HIP kernel for losses {sorted(unknown)}')
         self.spec = dict(spec)
         self.scale = scale
+        self.scale_dev = scale_dev          # 1-element fp32 device tensor: run-time factor on top of `scale` (captured graphs)
 
     def forward(self, predict, target):
         p = _channels_last(predict)
@@ -55,7 +56,7 @@ class LevelCriterion(nn.Module):
             if name in self.spec:
                 wd[cls] += self.spec[name] * sc
         total, values = ops.level_loss(p, lab, self.spec.get('CrossEntroLoss', 0.0) * sc,
-                                       self.spec.get('BalanceDiceLoss', 0.0) * sc, wd)
+                                       self.spec.get('BalanceDiceLoss', 0.0) * sc, wd, self.scale_dev)
         named = {}
         for name, w in self.spec.items():
             if name == 'CrossEntroLoss':

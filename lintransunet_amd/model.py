@@ -224,6 +224,7 @@ class MaskTransUnet(nn.Module):
         dec.final_block = nn.Conv3d(L[0], dim_output * 4, 3, padding=1)
         self.last_boxes = []
         self._store = None
+        self._infer_ctx = None       # ops.Context of this model's no-grad forwards (own scratch arena)
 
     def _final_cop(self):
         n = 4 * self.dim_output
@@ -326,6 +327,21 @@ class MaskTransUnet(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError('lintransunet_amd.MaskTransUnet runs on MI355X only (no CPU fallback); move the input to cuda')
+        if torch.is_grad_enabled():
+            return self._forward(x)              # training: the caller's context (train.train_step recycles its arena per step)
+        # inference: nothing of an earlier forward is needed any more -> recycle (and re-zero) a scratch arena.  Unless the caller
+        # brought a context of its own (infer.GraphedPredictor), that is this model's private inference context, so an evaluation
+        # between a training forward and its backward cannot clobber the statistics the backward still needs.
+        lc = ops.current()
+        if lc is ops._DEFAULT_CTX:
+            if self._infer_ctx is None:
+                self._infer_ctx = ops.Context()
+            lc = self._infer_ctx
+        with ops.use(lc):
+            lc.begin_step(x.device)
+            return self._forward(x)
+
+    def _forward(self, x):
         L, nl, C = self.num_layers, len(self.num_layers), self.dim_output
         p = float(self.dropout) if self.training else 0.0
         self._step += 1
@@ -335,9 +351,6 @@ class MaskTransUnet(nn.Module):
         if H % 2 or W % 2:
             raise ValueError('H and W must be even')
         enc, dec = self.encode, self.decode
-        if not torch.is_grad_enabled():
-            ops.begin_step(x.device)         # inference: nothing of an earlier forward is needed any more -> recycle (and re-zero) the
-                                             # scratch arena; with autograd on, train.train_step does this once per step
         store = self._weights(x.device)
         store.refresh()                      # one launch: every cast / transposed / repacked weight of this step
 

@@ -12,8 +12,16 @@ Three host-side mechanisms keep the launch count down:
     kernels (`+=`), the Function returns None for it and calls `_ltu_hook(param)`.
   * `scratch_zeros`: small zero-initialised statistics buffers come from one arena that is cleared with
     a single fill per step instead of one `torch.zeros` launch each.
+
+All of this host-side state lives in a `Context` (scratch arena, deferred second stages, weight-gradient branch, dropout step
+counter, norm workspaces), never in module globals: every captured object (train.GraphedStep, infer.GraphedPredictor) and every
+model's no-grad forward owns one, so two models, an evaluation between a training forward and its backward, or a graph
+captured earlier cannot touch each other's buffers.  The context that is current when an op's forward runs (`ops.use(ctx)`,
+thread-local) is remembered by the autograd node and used by its backward, which autograd runs on another thread.
 """
+import contextlib
 import ctypes
+import threading
 
 import torch
 
@@ -49,21 +57,6 @@ def _chk(t, name='tensor'):
     return t
 
 
-_STEP = None      # device-resident uint64 step counter mixed into every dropout seed (see common.h: make_drop)
-
-
-def set_step_counter(t):
-    """Install (or clear with None) the device counter; advance it with `t.add_(1)` once per step, inside a captured graph too."""
-    global _STEP
-    if t is not None and (t.dtype != torch.int64 or not t.is_cuda or t.numel() != 1):
-        raise ValueError('step counter must be a 1-element int64 CUDA tensor')
-    _STEP = t
-
-
-def _step_ptr():
-    return 0 if _STEP is None else _STEP.data_ptr()
-
-
 def _ptr_array(tensors):
     arr = (_c_void_p * 3)()
     for i, t in enumerate(tensors):
@@ -71,18 +64,21 @@ def _ptr_array(tensors):
     return arr
 
 
-# ---------------------------------------------------------------------------------------------- scratch arena
+# ---------------------------------------------------------------------------------------------- context
 
 class _Arena:
-    """Bump allocator over one fp32 buffer that is zero-filled once per step."""
+    """Bump allocator over one fp32 buffer that is zero-filled once per step.  Once `frozen` (a HIP graph has captured addresses
+    inside the buffer) the buffer is never replaced: requests that do not fit fall back to `torch.zeros`."""
 
     def __init__(self):
         self.buf = None
         self.off = 0
         self.need = 0
+        self.frozen = False
 
     def begin_step(self, device):
-        if self.need > 0 and (self.buf is None or self.buf.numel() < self.need or self.buf.device != device):
+        grow = self.need > 0 and (self.buf is None or self.buf.numel() < self.need or self.buf.device != device)
+        if grow and not self.frozen:
             self.buf = torch.empty(int(self.need * 1.25) + 1024, device=device, dtype=torch.float32)
         if self.buf is not None:
             self.buf.zero_()
@@ -102,17 +98,145 @@ class _Arena:
         return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
-_ARENA = _Arena()
+class Context:
+    """Host-side state of one stream of steps (see the module docstring)."""
+    _DEFER_MAX = 8
+
+    def __init__(self):
+        self.arena = _Arena()
+        self.step = None            # device-resident int64 step counter mixed into every dropout seed (common.h: make_drop)
+        self.deferred = []          # (ReduceJob, workspace kept alive)
+        self.wg_branch = None       # {'side': torch.cuda.Stream, 'jobs': [(fn, tensors)]}
+        self.norm_ws_by_dev = {}
+        self.ones = {}
+
+    def one(self, device):
+        """a cached fp32 scalar 1 (the seed gradient of each level loss: no fill launch per level and step)"""
+        t = self.ones.get(device)
+        if t is None:
+            t = self.ones[device] = torch.ones((), device=device, dtype=torch.float32)
+        return t
+
+    # -- dropout step counter
+    def set_step_counter(self, t):
+        if t is not None and (t.dtype != torch.int64 or not t.is_cuda or t.numel() != 1):
+            raise ValueError('step counter must be a 1-element int64 CUDA tensor')
+        self.step = t
+
+    def step_ptr(self):
+        return 0 if self.step is None else self.step.data_ptr()
+
+    # -- scratch arena
+    def begin_step(self, device):
+        """Recycles and clears the scratch arena: once per training step (train.train_step, inside a captured graph too) and at
+        the start of a no-grad forward; never between a forward and its backward (saved statistics live in the arena)."""
+        self.arena.begin_step(device)
+
+    def scratch_zeros(self, shape, device):
+        return self.arena.zeros(tuple(shape), device)
+
+    def freeze(self):
+        """a HIP graph now holds addresses inside the arena: it must never move again"""
+        self.arena.frozen = True
+
+    def norm_ws(self, device):
+        """per-device scratch of the two-stage norm reductions (written and consumed inside one C call, so one buffer serves all)"""
+        ws = self.norm_ws_by_dev.get(device)
+        if ws is None:
+            ws = self.norm_ws_by_dev[device] = torch.empty(_lib.load().ltu_norm_ws_floats(), device=device, dtype=torch.float32)
+        return ws
+
+    # -- deferred second stages: the two-stage reductions (projection weight gradients, LayerNorm gamma/beta gradients) may leave
+    # their fold to `flush_deferred`, which folds up to 8 of them per launch.  Only gradients that live in a reducer's flat buffer
+    # are deferred (nothing reads those before the end of backward / the bucket's all-reduce, both of which flush first).
+    def defer_push(self, job, ws):
+        if job.part:
+            self.deferred.append((job, ws))
+            if len(self.deferred) >= self._DEFER_MAX:
+                self.flush_deferred()
+
+    def flush_deferred(self):
+        """fold every pending partial-sum workspace into its gradient (stream-ordered; call before gradients are consumed)"""
+        if not self.deferred:
+            return
+        arr = (_lib.ReduceJob * len(self.deferred))(*[j for j, _ in self.deferred])
+        _lib.call('ltu_reduce_batch', ctypes.addressof(arr), len(self.deferred), _s())
+        self.deferred.clear()
+
+    # -- weight-gradient branch: weight gradients of the transformer projections are consumed only at the end of the step, so they
+    # need not sit on the data-gradient chain.  With a branch installed their launches are collected and issued on a second stream
+    # once per transformer (ONE cross-stream edge per bridge: a HIP-graph edge between branches costs ~4 us, so per-kernel edges
+    # lose more than the overlap gains; two long branches gain 13-23 %, tools/bench_overlap.py).
+    def wgrad_branch_install(self, side_stream):
+        """collect the projection weight-gradient launches instead of issuing them inline (None uninstalls)"""
+        self.wg_branch = None if side_stream is None else {'side': side_stream, 'jobs': []}
+
+    def wgrad_branch_flush(self):
+        """issue the collected launches on the side stream, ordered after everything issued so far on the current stream"""
+        br = self.wg_branch
+        if br is None or not br['jobs']:
+            return
+        side = br['side']
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for fn, tensors in br['jobs']:
+                for t in tensors:
+                    t.record_stream(side)          # allocated on the main stream, read by the side stream
+                fn()
+        br['jobs'].clear()
+
+    def wgrad_branch_join(self):
+        """flush what is left and make the current stream wait for the branch (end of backward)"""
+        br = self.wg_branch
+        if br is None:
+            return
+        self.wgrad_branch_flush()
+        torch.cuda.current_stream().wait_stream(br['side'])
+
+
+_DEFAULT_CTX = Context()
+_TLS = threading.local()
+
+
+def current():
+    """the context ops launched from this thread use (the process default unless inside `use`)"""
+    return getattr(_TLS, 'ctx', None) or _DEFAULT_CTX
+
+
+@contextlib.contextmanager
+def use(ctx):
+    prev = getattr(_TLS, 'ctx', None)
+    _TLS.ctx = ctx
+    try:
+        yield ctx
+    finally:
+        _TLS.ctx = prev
+
+
+# module-level conveniences over the current context
+def set_step_counter(t):
+    """Install (or clear with None) the device counter; advance it with `t.add_(1)` once per step, inside a captured graph too."""
+    current().set_step_counter(t)
 
 
 def begin_step(device):
-    """Recycles and clears the scratch arena.  Called once per training step (train.train_step, inside the captured graph too)
-    and at the start of every no-grad forward; never between a forward and its backward (saved statistics live in the arena)."""
-    _ARENA.begin_step(device)
+    current().begin_step(device)
 
 
 def scratch_zeros(shape, device):
-    return _ARENA.zeros(tuple(shape), device)
+    return current().scratch_zeros(shape, device)
+
+
+def flush_deferred():
+    current().flush_deferred()
+
+
+def wgrad_branch_install(side_stream):
+    current().wgrad_branch_install(side_stream)
+
+
+def wgrad_branch_join():
+    current().wgrad_branch_join()
 
 
 # ---------------------------------------------------------------------------------------------- gradients of parameters
@@ -155,73 +279,13 @@ def _w_transposed(ws, rows, cols, dtype):
     return wt
 
 
-# ---- deferred second stages ------------------------------------------------------------------------
-# The two-stage reductions (projection weight gradients, LayerNorm gamma/beta gradients) leave their fold to
-# `flush_deferred`, which folds up to 8 of them per launch.  Only gradients that live in a reducer's flat buffer are
-# deferred (nothing reads those before the end of backward / the bucket's all-reduce, both of which flush first).
-_DEFERRED = []          # (ReduceJob, workspace kept alive)
-_DEFER_MAX = 8
 DEFER_WGRAD = False
-
-
-def _defer_job():
-    return _lib.ReduceJob()
-
-
-def _defer_push(job, ws):
-    if job.part:
-        _DEFERRED.append((job, ws))
-        if len(_DEFERRED) >= _DEFER_MAX:
-            flush_deferred()
-
-
-def flush_deferred():
-    """fold every pending partial-sum workspace into its gradient (stream-ordered; call before gradients are consumed)"""
-    if not _DEFERRED:
-        return
-    arr = (_lib.ReduceJob * len(_DEFERRED))(*[j for j, _ in _DEFERRED])
-    _lib.call('ltu_reduce_batch', ctypes.addressof(arr), len(_DEFERRED), _s())
-    _DEFERRED.clear()
-
-
-# ---- weight-gradient branch ------------------------------------------------------------------------
-# Weight gradients of the transformer projections are consumed only at the end of the step, so they need not sit on the
-# data-gradient chain.  With a branch installed (train.GraphedStep) their launches are collected and issued on a second
-# stream once per transformer (ONE cross-stream edge per bridge: a HIP-graph edge between branches costs ~4 us, so per-kernel
-# edges lose more than the overlap gains; two long branches gain 13-23 %, tools/bench_overlap.py).
-_WG_BRANCH = None        # {'side': torch.cuda.Stream, 'jobs': [(fn, tensors)]}
 import os as _os
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
 
 
-def wgrad_branch_install(side_stream):
-    """collect the projection weight-gradient launches instead of issuing them inline (None uninstalls)"""
-    global _WG_BRANCH
-    _WG_BRANCH = None if side_stream is None else {'side': side_stream, 'jobs': []}
-
-
-def wgrad_branch_flush():
-    """issue the collected launches on the side stream, ordered after everything issued so far on the current stream"""
-    br = _WG_BRANCH
-    if br is None or not br['jobs']:
-        return
-    side = br['side']
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for fn, tensors in br['jobs']:
-            for t in tensors:
-                t.record_stream(side)          # allocated on the main stream, read by the side stream
-            fn()
-    br['jobs'].clear()
-
-
-def wgrad_branch_join():
-    """flush what is left and make the current stream wait for the branch (end of backward)"""
-    br = _WG_BRANCH
-    if br is None:
-        return
-    wgrad_branch_flush()
-    torch.cuda.current_stream().wait_stream(br['side'])
+def _defer_job():
+    return _lib.ReduceJob()
 
 
 class _WgradFlushPoint(torch.autograd.Function):
@@ -230,27 +294,17 @@ class _WgradFlushPoint(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.lc = current()
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        wgrad_branch_flush()
+        ctx.lc.wgrad_branch_flush()
         return g
 
 
 def wgrad_flush_point(x):
-    return _WgradFlushPoint.apply(x) if (_WG_BRANCH is not None and x.requires_grad) else x
-
-
-_NORM_WS = {}
-
-
-def _norm_ws(device):
-    """per-device scratch for the two-stage norm reductions (written and consumed inside one C call, so one buffer serves all)"""
-    ws = _NORM_WS.get(device)
-    if ws is None:
-        ws = _NORM_WS[device] = torch.empty(_lib.load().ltu_norm_ws_floats(), device=device, dtype=torch.float32)
-    return ws
+    return _WgradFlushPoint.apply(x) if (current().wg_branch is not None and x.requires_grad) else x
 
 
 def _wgrad_ws(M, N, K, like):
@@ -335,6 +389,7 @@ class RoiPlan:
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, stride, ups, cop, prep):
+        lc = ctx.lc = current()
         _chk(x0, 'x0')
         B, Hi, Wi, Di, C0 = x0.shape
         C1 = 0 if x1 is None else _chk(x1, 'x1').shape[-1]
@@ -365,6 +420,7 @@ class _Conv3d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         x0, x1 = ctx.saved_tensors
         weight, bias = ctx.params
         stride, ups, cop, C0, C1, prep = ctx.cfg
@@ -452,6 +508,7 @@ class _Conv3dPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wa, ba, wb, bb, prep):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         B, H, W, D, C = x.shape
         n0, n1 = prep.n0, prep.n1
@@ -466,6 +523,7 @@ class _Conv3dPair(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g0, g1):
+        lc = ctx.lc
         (x,) = ctx.saved_tensors
         wa, ba, wb, bb = ctx.params
         prep = ctx.prep
@@ -524,6 +582,7 @@ class _UpConv3d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, prep):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         B, H, W, D, Ci = x.shape
         Co = weight.shape[0]
@@ -538,6 +597,7 @@ class _UpConv3d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         (x,) = ctx.saved_tensors
         weight, bias = ctx.params
         prep = ctx.prep
@@ -553,7 +613,7 @@ class _UpConv3d(torch.autograd.Function):
             _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, _p(wsd), dt, _s())
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
-        dweff = scratch_zeros((8, Co, 8, Ci), x.device)
+        dweff = lc.scratch_zeros((8, Co, 8, Ci), x.device)
         ws = None
         if x.dtype == torch.bfloat16:
             ws = torch.empty(_lib.load().ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci), device=x.device, dtype=torch.float32)
@@ -576,6 +636,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, prep, *wb):
+        lc = ctx.lc = current()
         nw = len(wb) // 2
         ws, bs = wb[:nw], wb[nw:]
         _chk(x, 'x')
@@ -592,6 +653,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         (x,) = ctx.saved_tensors
         ws, bs = ctx.params
         nw = len(ws)
@@ -607,12 +669,12 @@ class _Linear(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         gw = [_grad_buf(w) for w in ws]
         gb = [_grad_buf(b) for b in bs]
-        if _WG_BRANCH is not None and all(f for _, f in gw) and all(f for _, f in gb):
+        if lc.wg_branch is not None and all(f for _, f in gw) and all(f for _, f in gb):
             def launch(g=g, x=x, gw=gw, gb=gb):
                 wsb = _wgrad_ws(M, N, K, x)
                 _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
                           M, N, K, _p(wsb), 0, dt, _s())
-            _WG_BRANCH['jobs'].append((launch, (g, x)))
+            lc.wg_branch['jobs'].append((launch, (g, x)))
             dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
             dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
             return (dx, None, *dws, *dbs)
@@ -623,7 +685,7 @@ class _Linear(torch.autograd.Function):
         _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
                   M, N, K, _p(wsb), ctypes.addressof(job) if job is not None else 0, dt, _s())
         if job is not None:
-            _defer_push(job, wsb)
+            lc.defer_push(job, wsb)
         dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
         dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
         return (dx, None, *dws, *dbs)
@@ -640,13 +702,14 @@ class _LinearGelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, prep, w, b, p, seed):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         M, K = x.shape
         N = w.shape[0]
         u = torch.empty((M, N), device=x.device, dtype=x.dtype)
         h = torch.empty((M, N), device=x.device, dtype=x.dtype)
         wop = prep.w[0] if prep is not None else _w_operand(w, x.dtype)
-        _lib.call('ltu_linear_gelu_fwd', _p(x), K, _p(wop), _p(b), _p(u), _p(h), M, N, K, float(p), seed, _step_ptr(), _dt(x), _s())
+        _lib.call('ltu_linear_gelu_fwd', _p(x), K, _p(wop), _p(b), _p(u), _p(h), M, N, K, float(p), seed, lc.step_ptr(), _dt(x), _s())
         ctx.save_for_backward(x, u)
         ctx.params = (w, b)
         ctx.prep = prep
@@ -655,6 +718,7 @@ class _LinearGelu(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh):
+        lc = ctx.lc
         x, u = ctx.saved_tensors
         w, b = ctx.params
         p, seed = ctx.cfg
@@ -663,7 +727,7 @@ class _LinearGelu(torch.autograd.Function):
         N = w.shape[0]
         dev, dt = x.device, _dt(x)
         g = torch.empty_like(u)
-        _lib.call('ltu_gelu_dropout_bwd', _p(gh), _p(u), _p(g), u.numel(), float(p), seed, _step_ptr(), dt, _s())
+        _lib.call('ltu_gelu_dropout_bwd', _p(gh), _p(u), _p(g), u.numel(), float(p), seed, lc.step_ptr(), dt, _s())
         dx = None
         if ctx.needs_input_grad[0]:
             wt = ctx.prep.wt if ctx.prep is not None else _w_transposed([w], N, K, x.dtype)
@@ -675,8 +739,8 @@ class _LinearGelu(torch.autograd.Function):
         def launch(g=g, x=x):
             wsb = _wgrad_ws(M, N, K, x)
             _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
-        if _WG_BRANCH is not None and fw and fb:
-            _WG_BRANCH['jobs'].append((launch, (g, x)))
+        if lc.wg_branch is not None and fw and fb:
+            lc.wg_branch['jobs'].append((launch, (g, x)))
         else:
             launch()
         return dx, None, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
@@ -692,29 +756,31 @@ def linear_gelu(x, weight, bias, p=0.0, seed=0, prep=None):
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, act, p, seed):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        sums = scratch_zeros((B, C, 3), x.device)
+        sums = lc.scratch_zeros((B, C, 3), x.device)
         dt = _dt(x)
-        _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(_norm_ws(x.device)), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(lc.norm_ws(x.device)), B, S, C, dt, _s())
         y = torch.empty_like(x)
-        _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, _step_ptr(), dt, _s())
+        _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, lc.step_ptr(), dt, _s())
         ctx.save_for_backward(x, sums)
         ctx.cfg = (act, p, seed, res is not None)
         return y
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         x, sums = ctx.saved_tensors
         act, p, seed, has_res = ctx.cfg
         g = g.contiguous()
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        bsums = scratch_zeros((B, C, 2), x.device)
+        bsums = lc.scratch_zeros((B, C, 2), x.device)
         dx = torch.empty_like(x)
-        _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(_norm_ws(x.device)), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
-                  _step_ptr(), _dt(x), _s())
+        _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(lc.norm_ws(x.device)), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
+                  lc.step_ptr(), _dt(x), _s())
         return dx, (g if has_res else None), None, None, None
 
 
@@ -726,13 +792,14 @@ def instnorm_act(x, res=None, act=ACT_LRELU, p=0.0, seed=0):
 class _ResLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, gamma, beta, eps, p, seed, fork=False):
+        lc = ctx.lc = current()
         _chk(x, 'x'); _chk(r, 'r')
         M, d = x.shape
         y = torch.empty_like(x)
         stat = torch.empty((M, 2), device=x.device, dtype=torch.float32)
         # r is overwritten with z = x + dropout(r): it is the producer's private output buffer
         _lib.call('ltu_layernorm_fwd', _p(x), _p(r), _p(gamma), _p(beta), _p(y), _p(stat), M, d, float(eps), float(p), seed,
-                  _step_ptr(), _dt(x), _s())
+                  lc.step_ptr(), _dt(x), _s())
         ctx.save_for_backward(r, stat)
         ctx.params = (gamma, beta)
         ctx.cfg = (p, seed)
@@ -745,6 +812,7 @@ class _ResLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, g2=None):
+        lc = ctx.lc
         z, stat = ctx.saved_tensors
         gamma, beta = ctx.params
         p, seed = ctx.cfg
@@ -758,14 +826,14 @@ class _ResLayerNorm(torch.autograd.Function):
         dr = torch.empty_like(z) if p > 0 else dz
         dgamma, fg = _grad_buf(gamma)
         dbeta, fb = _grad_buf(beta)
-        job, ws = None, _norm_ws(g.device)
+        job, ws = None, lc.norm_ws(g.device)
         if fg and fb:                      # gamma/beta gradients live in a reducer bucket: fold the partials later, batched
             job = _defer_job()
             ws = torch.empty(2048 * 2 * d, device=g.device, dtype=torch.float32)       # private: it outlives this call
         _lib.call('ltu_layernorm_bwd', _p(g), _p(g2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta),
-                  _p(ws), ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, _step_ptr(), _dt(z), _s())
+                  _p(ws), ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, lc.step_ptr(), _dt(z), _s())
         if job is not None:
-            _defer_push(job, ws)
+            lc.defer_push(job, ws)
         return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None, None
 
 
@@ -778,20 +846,22 @@ def res_layernorm(x, r, gamma, beta, eps=1e-6, p=0.0, seed=0, fork=False):
 class _GeluDropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, p, seed):
+        lc = ctx.lc = current()
         _chk(u, 'u')
         h = torch.empty_like(u)
-        _lib.call('ltu_gelu_dropout_fwd', _p(u), _p(h), u.numel(), float(p), seed, _step_ptr(), _dt(u), _s())
+        _lib.call('ltu_gelu_dropout_fwd', _p(u), _p(h), u.numel(), float(p), seed, lc.step_ptr(), _dt(u), _s())
         ctx.save_for_backward(u)
         ctx.cfg = (p, seed)
         return h
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         (u,) = ctx.saved_tensors
         p, seed = ctx.cfg
         g = g.contiguous()
         du = torch.empty_like(u)
-        _lib.call('ltu_gelu_dropout_bwd', _p(g), _p(u), _p(du), u.numel(), float(p), seed, _step_ptr(), _dt(u), _s())
+        _lib.call('ltu_gelu_dropout_bwd', _p(g), _p(u), _p(du), u.numel(), float(p), seed, lc.step_ptr(), _dt(u), _s())
         return du, None, None
 
 
@@ -804,6 +874,7 @@ def gelu_dropout(u, p=0.0, seed=0):
 class _LinAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, B, N, d):
+        lc = ctx.lc = current()
         _chk(qkv, 'qkv')
         H = d // 32
         dev = qkv.device
@@ -820,6 +891,7 @@ class _LinAttn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         qkv, cx, colstats, qstat = ctx.saved_tensors
         B, N, d, nsplit = ctx.cfg
         H = d // 32
@@ -844,10 +916,11 @@ def linear_attention(qkv, B, N, d):
 class _PosConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, p, seed):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         B, H, W, D, C = x.shape
         y = torch.empty_like(x)
-        _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, float(p), seed, _step_ptr(), _dt(x), _s())
+        _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, float(p), seed, lc.step_ptr(), _dt(x), _s())
         ctx.save_for_backward(x)
         ctx.params = (w, b)
         ctx.cfg = (p, seed)
@@ -855,6 +928,7 @@ class _PosConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         (x,) = ctx.saved_tensors
         w, b = ctx.params
         p, seed = ctx.cfg
@@ -863,7 +937,7 @@ class _PosConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, _step_ptr(), _dt(x), _s())
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, lc.step_ptr(), _dt(x), _s())
         return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
 
 
@@ -875,6 +949,7 @@ def pos_conv(x, w, b, p=0.0, seed=0):
 class _Trilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sd):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         B, H, W, D, C = x.shape
         y = torch.empty((B, 2 * H, 2 * W, sd * D, C), device=x.device, dtype=x.dtype)
@@ -884,6 +959,7 @@ class _Trilinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         B, H, W, D, C, sd = ctx.cfg
         g = g.contiguous()
         dx = torch.empty((B, H, W, D, C), device=g.device, dtype=g.dtype)
@@ -899,6 +975,7 @@ def trilinear_up(x, sd):
 class _RoiResample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, plan, which):
+        lc = ctx.lc = current()
         _chk(x, 'x')
         B, C = x.shape[0], x.shape[-1]
         D = x.shape[3]
@@ -914,6 +991,7 @@ class _RoiResample(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         plan, which = ctx.plan, ctx.which
         g = g.contiguous()
         B, _, _, D, C = ctx.in_shape
@@ -938,6 +1016,7 @@ def roi_unwarp(x, plan):
 class _HeadSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, C):
+        lc = ctx.lc = current()
         _chk(z, 'z')
         CP = z.shape[-1]
         M = z.numel() // CP
@@ -949,6 +1028,7 @@ class _HeadSoftmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         (p,) = ctx.saved_tensors
         C, CP, zdt = ctx.cfg
         g = g.contiguous()
@@ -965,6 +1045,7 @@ def head_softmax(z, C):
 class _FinalSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, C):
+        lc = ctx.lc = current()
         _chk(z, 'z')
         B, h, w, D, CP = z.shape
         p = torch.empty((B, 2 * h, 2 * w, D, C), device=z.device, dtype=torch.float32)
@@ -975,6 +1056,7 @@ class _FinalSoftmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         (p,) = ctx.saved_tensors
         B, h, w, D, C, CP, zdt = ctx.cfg
         g = g.contiguous()
@@ -993,6 +1075,7 @@ class _Gate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, skip, up, wx, bx, wg, bg, pw, pb, px, pg):
+        lc = ctx.lc = current()
         _chk(skip, 'skip'); _chk(up, 'up')
         B, C = skip.shape[0], skip.shape[-1]
         Cg = up.shape[-1]
@@ -1005,10 +1088,10 @@ class _Gate(torch.autograd.Function):
         wgo = pg.w[0] if pg is not None else _w_operand(wg, skip.dtype)
         _lib.call('ltu_linear_fwd', _p(skip), C, _ptr_array([wxo]), 1, _ptr_array([bx]), _p(u1), C, M, C, C, 0, dt, _s())
         _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([wgo]), 1, _ptr_array([bg]), _p(u2), C, M, C, Cg, 0, dt, _s())
-        s1 = scratch_zeros((B, C, 3), dev)
-        s2 = scratch_zeros((B, C, 3), dev)
-        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), _p(_norm_ws(dev)), B, S, C, dt, _s())
-        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), _p(_norm_ws(dev)), B, S, C, dt, _s())
+        s1 = lc.scratch_zeros((B, C, 3), dev)
+        s2 = lc.scratch_zeros((B, C, 3), dev)
+        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), _p(lc.norm_ws(dev)), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), _p(lc.norm_ws(dev)), B, S, C, dt, _s())
         a = torch.empty(M, device=dev, dtype=torch.float32)
         out = torch.empty_like(skip)
         _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, dt, _s())
@@ -1019,6 +1102,7 @@ class _Gate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lc = ctx.lc
         skip, up, u1, u2, s1, s2, a = ctx.saved_tensors
         wx, bx, wg, bg, pw, pb = ctx.params
         px, pg = ctx.prep
@@ -1032,12 +1116,12 @@ class _Gate(torch.autograd.Function):
         ds = torch.empty(M, device=dev, dtype=torch.float32)
         dpw, fpw = _grad_buf(pw)
         dpb, fpb = _grad_buf(pb)
-        bs1 = scratch_zeros((B, C, 2), dev)
-        bs2 = scratch_zeros((B, C, 2), dev)
+        bs1 = lc.scratch_zeros((B, C, 2), dev)
+        bs2 = lc.scratch_zeros((B, C, 2), dev)
         du1 = torch.empty_like(u1)
         du2 = torch.empty_like(u2)
         _lib.call('ltu_gate_bwd', _p(g), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
-                  _p(dpb), _p(bs1), _p(bs2), _p(_norm_ws(dev)), _p(du1), _p(du2), B, S, C, dt, _s())
+                  _p(dpb), _p(bs1), _p(bs2), _p(lc.norm_ws(dev)), _p(du1), _p(du2), B, S, C, dt, _s())
         # through the two 1x1x1 convs
         wxt = px.wt if px is not None else _w_transposed([wx], C, C, skip.dtype)
         wgt = pg.wt if pg is not None else _w_transposed([wg], C, Cg, skip.dtype)
@@ -1067,31 +1151,34 @@ class _LevelLoss(torch.autograd.Function):
     """Weighted sum of the losses of one decoder level; returns (total, values[1+2+C]) with values detached."""
 
     @staticmethod
-    def forward(ctx, p, label, w_ce, w_bal, w_dice):
+    def forward(ctx, p, label, w_ce, w_bal, w_dice, scale_dev):
+        lc = ctx.lc = current()
         _chk(p, 'p'); _chk(label, 'label')
         B, C = p.shape[0], p.shape[-1]
         S = p.numel() // (B * C)
         dev = p.device
-        sums = scratch_zeros((B, C, 4), dev)
+        sums = lc.scratch_zeros((B, C, 4), dev)
         values = torch.empty(8, device=dev, dtype=torch.float32)
         coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
         wd = (ctypes.c_float * 4)(*[float(w_dice[c]) if c < len(w_dice) else 0.0 for c in range(4)])
-        _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _s())
+        _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _p(scale_dev), _s())
         ctx.save_for_backward(p, label, coef)
         ctx.mark_non_differentiable(values)
         return values[0].clone(), values
 
     @staticmethod
     def backward(ctx, g, _gv):
+        lc = ctx.lc
         p, label, coef = ctx.saved_tensors
         B, C = p.shape[0], p.shape[-1]
         S = p.numel() // (B * C)
         g = g.contiguous().to(torch.float32)
         dp = torch.empty_like(p)
         _lib.call('ltu_loss_bwd', _p(p), _p(label), _p(coef), _p(g), _p(dp), B, S, C, _s())
-        return dp, None, None, None, None
+        return dp, None, None, None, None, None
 
 
-def level_loss(p, label, w_ce=0.0, w_bal=0.0, w_dice=()):
-    """p fp32 [B,...,C] channels-last probabilities, label uint8 [B,...]: weighted CE + balanced Dice + per-class Dice."""
-    return _LevelLoss.apply(p, label, w_ce, w_bal, tuple(w_dice))
+def level_loss(p, label, w_ce=0.0, w_bal=0.0, w_dice=(), scale_dev=None):
+    """p fp32 [B,...,C] channels-last probabilities, label uint8 [B,...]: weighted CE + balanced Dice + per-class Dice.
+    scale_dev: optional 1-element fp32 device tensor multiplying all weights at run time."""
+    return _LevelLoss.apply(p, label, w_ce, w_bal, tuple(w_dice), scale_dev)

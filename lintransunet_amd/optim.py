@@ -120,16 +120,23 @@ class BestCheckpoint:
     `model.state_dict()` to `<dir>/temp_model.pt` (loadable by the reference's get_model, train3D.py:104-120).  What the
     reference does not keep -- optimizer moments, step, learning rate, RNG state -- goes to a side file."""
 
-    def __init__(self, model_dir):
+    def __init__(self, model_dir, rank=None):
         self.dir = model_dir
         self.best_eval = math.inf
         self.best_train = math.inf
-        os.makedirs(model_dir, exist_ok=True)
+        if rank is None:       # data-parallel run: every rank holds the same weights, only rank 0 writes
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.rank = rank
+        if self.rank == 0:
+            os.makedirs(model_dir, exist_ok=True)
 
     def update(self, model, eval_loss, train_loss, optimizer=None):
         if eval_loss > self.best_eval:
             return False
         self.best_eval, self.best_train = eval_loss, train_loss
+        if self.rank != 0:
+            return True
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, os.path.join(self.dir, 'temp_model.pt'))
         if optimizer is not None:
             side = dict(optimizer={k: ([t.cpu() for t in v] if isinstance(v, list) and v and torch.is_tensor(v[0]) else v)

@@ -60,35 +60,45 @@ def label_pyramid(label, n_levels=5):
     return out
 
 
-def deep_supervision_loss(predict, masks, label, weights, specs=None, scale=1.0):
+def deep_supervision_loss(predict, masks, label, weights, specs=None, scale=1.0, level_scale=None):
     """Per-level fused losses (utils/utils_3D_embed_full.py:66-82).  Returns (list of weighted level totals,
-    list of {name: value}); `sum(totals)` is the reference's total_loss * scale."""
+    list of {name: value}); `sum(totals)` is the reference's total_loss * scale.
+    level_scale: optional fp32 device tensor [n_levels] that REPLACES `weights[lvl] * scale` at run time (a captured graph
+    then follows the per-epoch weights of train3D.py:122-137 and the accumulation count without re-capture)."""
     n = len(weights)
     specs = specs or level_specs(n)
     pyr = label_pyramid(label, n)
     totals, named = [], []
     for lvl in range(n):
         pred = predict if lvl == 0 else masks[-lvl]
-        crit = LevelCriterion(specs[-lvl - 1], scale=weights[lvl] * scale)
+        if level_scale is not None:
+            crit = LevelCriterion(specs[-lvl - 1], scale=1.0, scale_dev=level_scale[lvl:lvl + 1])
+        else:
+            crit = LevelCriterion(specs[-lvl - 1], scale=weights[lvl] * scale)
         tot, vals = crit(pred, pyr[lvl].unsqueeze(1))
         totals.append(tot)
         named.append(vals)
     return totals, named
 
 
-def train_step(model, images, labels, weights, step_times=1, specs=None, reducer=None):
+def train_step(model, images, labels, weights, step_times=1, specs=None, reducer=None, ctx=None, level_scale=None, reduce=True):
     """forward + 5-level loss + backward for one batch of patches (one `j` of utils_3D_embed_full.py:55-86).
-    Returns the list of weighted level losses (device scalars, no host sync)."""
-    ops.begin_step(images.device)
-    predict, masks = model(images)
-    totals, named = deep_supervision_loss(predict, masks, labels, weights, specs, scale=1.0 / step_times)
-    if reducer is not None:
-        reducer.prepare()
-    torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
-    ops.wgrad_branch_join()                 # weight-gradient branch (if one is installed) back into this stream
-    ops.flush_deferred()                    # second stages of the two-stage reductions still queued by backward
-    if reducer is not None:
-        reducer.finish()
+    Returns the list of weighted level losses (device scalars, no host sync).
+    Gradient accumulation (utils_3D_embed_full.py:85-91): call `step_times` times with reduce=False except on the last
+    micro-step; the caller zeroes the gradients before the first one."""
+    lc = ctx or ops.current()
+    with ops.use(lc):
+        lc.begin_step(images.device)
+        predict, masks = model(images)
+        totals, named = deep_supervision_loss(predict, masks, labels, weights, specs, scale=1.0 / step_times, level_scale=level_scale)
+        if reducer is not None:
+            reducer.prepare(lc, reduce=reduce)
+        one = lc.one(images.device)
+        torch.autograd.backward(totals, [one] * len(totals))
+        lc.wgrad_branch_join()               # weight-gradient branch (if one is installed) back into this stream
+        lc.flush_deferred()                  # second stages of the two-stage reductions still queued by backward
+        if reducer is not None:
+            reducer.finish()
     return totals, named
 
 
@@ -97,8 +107,12 @@ class GradReducer:
 
     Parameters are bucketed in reverse registration order (decoder tail first = the order in which
     backward produces gradients).  Each parameter's `.grad` is a view into its bucket's flat buffer; a
-    post-accumulate hook counts arrivals and launches `all_reduce(async_op=True)` when a bucket is full.
+    post-accumulate hook counts arrivals and launches `all_reduce(async_op=True)` when a bucket is full, so the
+    collective of one bucket runs while backward produces the next.  Inside a captured step (GraphedStep) the same
+    calls are captured: each bucket's RCCL kernel becomes a side branch of the HIP graph, forked where the bucket's
+    last gradient is produced and joined at the end of the step.
     Parameters that never receive a gradient (the 14 unused pos_encoders tensors) are left out.
+    With gradient accumulation only the last micro-step reduces (`prepare(reduce=False)` otherwise).
     """
 
     def __init__(self, model, bucket_mb=16.0, unused=None, group=None, fused=True):
@@ -133,6 +147,8 @@ class GradReducer:
             self.flat.append(flat)
         self.pending = [0] * len(self.buckets)
         self.active = False
+        self.reduce_now = True
+        self.ctx = None
         # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) sums and the buckets are divided afterwards
         self.avg = self.world > 1 and dist.get_backend(group) == 'nccl'
 
@@ -148,31 +164,34 @@ class GradReducer:
         for f in self.flat:
             f.zero_()
 
-    def prepare(self):
+    def prepare(self, ctx=None, reduce=True):
+        """arm the hooks for one backward; reduce=False (a non-final accumulation micro-step) only accumulates"""
         self.pending = [len(b) for b in self.buckets]
         self.handles = []
         self.active = True
+        self.reduce_now = bool(reduce) and self.world > 1
+        self.ctx = ctx or ops.current()          # the hooks run on autograd's thread: they must not look the context up there
 
     def _hook(self, p):
         if not self.active:
             return
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
-        if self.pending[bi] == 0 and self.world > 1:
-            ops.flush_deferred()            # pending second-stage reductions may still owe this bucket their sums
+        if self.pending[bi] == 0 and self.reduce_now:
+            self.ctx.flush_deferred()       # pending second-stage reductions may still owe this bucket their sums
             self.handles.append((bi, self._all_reduce(self.flat[bi])))
 
     def reduce_all(self):
-        """all-reduce every bucket now (used after a graph replay, where no hooks run)"""
+        """all-reduce every bucket now (after a graph replay that did not capture the collectives)"""
         if self.world > 1:
             hs = [self._all_reduce(f) for f in self.flat]
             for f, h in zip(self.flat, hs):
                 self._finish_bucket(f, h)
 
     def finish(self):
-        ops.flush_deferred()                # safety net for callers that ran backward without train_step
+        (self.ctx or ops.current()).flush_deferred()      # safety net for callers that ran backward without train_step
         self.active = False
-        if self.world > 1:
+        if self.reduce_now:
             launched = {bi for bi, _ in self.handles}
             for bi in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
                 if bi not in launched:
@@ -183,55 +202,114 @@ class GradReducer:
 
 
 class GraphedStep:
-    """One training step (arena reset, weight prep, forward, 5-level loss, backward into the reducer's flat gradient
-    buffers) captured once into a HIP graph and replayed: ~1 400 kernel launches become one `hipGraphLaunch`.
+    """One training micro-step (arena reset, weight prep, forward, 5-level loss, backward into the reducer's flat gradient
+    buffers, bucketed gradient all-reduce) captured once into a HIP graph and replayed: ~1 400 kernel launches become one
+    `hipGraphLaunch`.
 
-    The batch lives in static device buffers (`copy_` new data in); dropout masks stay fresh across replays because the
-    kernels mix a device-resident step counter, advanced inside the graph, into their Philox seeds.  With more than one rank
-    the gradient all-reduce runs after the replay (bucket by bucket, asynchronously) instead of from autograd hooks.
+    * The batch lives in static device buffers (`copy_` new data in); dropout masks stay fresh across replays because the
+      kernels mix a device-resident step counter, advanced inside the graph, into their seeds.
+    * all-reduce: `overlap='graph'` (default) captures the bucket collectives inside the graph - RCCL kernels on the process
+      group's stream become side branches forked where a bucket's last gradient is produced and joined at the end of the step,
+      i.e. overlapped with the rest of backward exactly as in the eager hook path.  `overlap='after'` issues them after the
+      replay (fully exposed; kept as the fallback if a runtime refuses to capture collectives).  LTU_GRAPH_ALLREDUCE overrides.
+    * accumulation (utils/utils_3D_embed_full.py:85-91, `step_times` micro-steps per optimizer step): `step(x, y, micro=j)`
+      zeroes the buckets only for j == 0 and reduces only for j == step_times - 1; each (zero, reduce) combination in use is its
+      own captured graph (they share one memory pool).
+    * per-epoch level weights (train3D.py:122-137) live in a device tensor read by the loss kernels: `set_weights(w)` updates
+      it in place, no re-capture.
+    * every replay first checks that parameter and gradient storage is where it was at capture time (e.g. an optimizer built
+      afterwards that re-homes `p.data`); if not, the step is captured again.
+    * the step owns its `ops.Context` (scratch arena frozen after capture), so other graphs / eager steps cannot move it.
     """
 
-    def __init__(self, model, images, labels, weights, reducer, step_times=1, specs=None, warmup=2):
+    def __init__(self, model, images, labels, weights, reducer, step_times=1, specs=None, warmup=2, overlap=None):
         self.model, self.reducer = model, reducer
+        self.step_times, self.specs, self.warmup = int(step_times), specs, warmup
+        self.n_levels = len(weights)
         dev = images.device
+        self.dev = dev
         self.x, self.lab = images.clone(), labels.clone()
+        self.overlap = overlap or os.environ.get('LTU_GRAPH_ALLREDUCE', 'graph')
+        if self.overlap not in ('graph', 'after'):
+            raise ValueError("overlap must be 'graph' or 'after'")
+        self.ctx = ops.Context()
         self.counter = torch.zeros(1, device=dev, dtype=torch.int64)
-        ops.set_step_counter(self.counter)
-
+        self.ctx.set_step_counter(self.counter)
+        self.level_scale = torch.empty(self.n_levels, device=dev, dtype=torch.float32)
+        self.set_weights(weights)
         # opt-in (LTU_WGRAD_BRANCH=1): measured +0.5 % only (21.09 vs 21.20 ms), see DESIGN.md section 7
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get('LTU_WGRAD_BRANCH', '0') == '1' else None
+        self.graphs = {}
+        self.pool = None
+        self._capture((True, True))
 
-        def body():
-            self.counter.add_(1)
-            reducer.zero_grad()
-            ops.wgrad_branch_install(self.wg_stream)       # projection weight gradients on a second graph branch
-            try:
-                return train_step(model, self.x, self.lab, weights, step_times=step_times, specs=specs, reducer=None)
-            finally:
-                ops.wgrad_branch_install(None)
+    def set_weights(self, weights):
+        """per-level deep-supervision weights of this epoch (divided by step_times as utils_3D_embed_full.py:85 does)"""
+        if len(weights) != self.n_levels:
+            raise ValueError('one weight per level')
+        self.weights = tuple(float(w) for w in weights)
+        self.level_scale.copy_(torch.tensor([w / self.step_times for w in self.weights], dtype=torch.float32))
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):        # warm-up on a side stream: allocator pools, arena size, weight store
-                body()
-        torch.cuda.current_stream(dev).wait_stream(side)
+    def _body(self, zero, reduce):
+        self.counter.add_(1)
+        if zero:
+            self.reducer.zero_grad()
+        self.ctx.wgrad_branch_install(self.wg_stream)       # projection weight gradients on a second graph branch
+        try:
+            return train_step(self.model, self.x, self.lab, self.weights, step_times=self.step_times, specs=self.specs,
+                              reducer=self.reducer, ctx=self.ctx, level_scale=self.level_scale,
+                              reduce=reduce and self.overlap == 'graph')
+        finally:
+            self.ctx.wgrad_branch_install(None)
+
+    def _signature(self):
+        ps = list(self.model.parameters())
+        return (tuple(p.data_ptr() for p in ps), tuple(0 if p.grad is None else p.grad.data_ptr() for p in ps),
+                tuple(f.data_ptr() for f in self.reducer.flat))
+
+    def _capture(self, key):
+        zero, reduce = key
+        dev = self.dev
+        if not self.graphs:            # first capture (or re-capture): warm up allocator pools, arena size, weight store, RCCL
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._body(True, True)
+            torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.barrier()                 # no collective in flight while the stream is capturing
             torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.totals, self.named = body()
+        kw = {} if self.pool is None else {'pool': self.pool}
+        with torch.cuda.graph(graph, capture_error_mode='thread_local', **kw):
+            totals, named = self._body(zero, reduce)
+        if self.pool is None:
+            self.pool = graph.pool()
+        self.ctx.freeze()                  # the graph holds addresses inside the scratch arena
+        self.graphs[key] = (graph, totals, named)
+        self.sig = self._signature()
 
-    def __call__(self, images=None, labels=None):
+    def __call__(self, images=None, labels=None, micro=0):
+        """replay micro-step `micro` (0 .. step_times-1) of an optimizer step on a new batch"""
+        if self._signature() != self.sig:          # parameter / gradient storage moved since capture: the graph reads stale memory
+            self.graphs = {}
+            self.pool = None
+            self.ctx.arena.frozen = False
+        key = (micro == 0, micro == self.step_times - 1)
+        if key not in self.graphs:
+            self._capture(key)
         if images is not None:
             self.x.copy_(images, non_blocking=True)
             self.lab.copy_(labels, non_blocking=True)
-        self.graph.replay()
-        self.reducer.reduce_all()
-        return self.totals, self.named
+        graph, totals, named = self.graphs[key]
+        graph.replay()
+        if key[1] and self.overlap == 'after':
+            self.reducer.reduce_all()
+        self.totals, self.named = totals, named
+        return totals, named
 
 
 UNUSED_PARAMETERS = tuple(f'decode.bridge_list.4.transformer.pos_encoders.{n}.proj.{k}'

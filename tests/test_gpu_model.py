@@ -227,7 +227,7 @@ def test_fused_gradient_path_matches_autograd_path():
 def test_graphed_step_matches_eager():
     """HIP-graph replay of the captured step: same gradients as the eager step; the device-resident step counter keeps
     dropout masks fresh across replays"""
-    from lintransunet_amd import train, ops
+    from lintransunet_amd import train
     cfg = O_net.NetConfig(**SMALL)
     x = seedgen.seeded_volume((2, 1, 32, 32, 32), 21).to(DEV)
     label = seedgen.seeded_label((2, 1, 32, 32, 32), 22).to(DEV)
@@ -236,25 +236,136 @@ def test_graphed_step_matches_eager():
     train.train_step(ref, x, label, w)
     m = build(cfg, 100)
     red = train.GradReducer(m, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
-    try:
-        g = train.GraphedStep(m, x, label, w, red)
-        for _ in range(2):
-            totals, _ = g(x, label)
+    g = train.GraphedStep(m, x, label, w, red)
+    for _ in range(2):
+        totals, _ = g(x, label)
+    torch.cuda.synchronize()
+    pr, pm = dict(ref.named_parameters()), dict(m.named_parameters())
+    for k, p in pr.items():
+        if p.grad is None:
+            continue
+        assert grads_agree(pm[k].grad, p.grad, k), k
+    # with dropout the replays must differ (fresh masks) although the captured seeds are frozen
+    md = build(cfg, 100, dropout=0.3)
+    redd = train.GradReducer(md, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
+    gd = train.GraphedStep(md, x, label, w, redd)
+    a = sum(t.item() for t in gd(x, label)[0])
+    b = sum(t.item() for t in gd(x, label)[0])
+    assert np.isfinite(a) and np.isfinite(b) and a != b
+
+
+def _flat_grads(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def test_graphed_step_accumulation_and_weights():
+    """utils/utils_3D_embed_full.py:85-91: `step_times` micro-steps accumulate (each loss divided by step_times), the buckets are
+    zeroed on the first and reduced on the last; the per-epoch level weights (train3D.py:122-137) are a device tensor, so a
+    captured graph follows `set_weights` without re-capture"""
+    from lintransunet_amd import train
+    cfg = O_net.NetConfig(**SMALL)
+    xs = [seedgen.seeded_volume((1, 1, 32, 32, 32), 41 + i).to(DEV) for i in range(2)]
+    ls = [seedgen.seeded_label((1, 1, 32, 32, 32), 51 + i).to(DEV) for i in range(2)]
+    w0, w1 = O_step.dynamic_weights(0), O_step.dynamic_weights(40)
+    assert w0 != w1
+
+    def eager(w):
+        m = build(cfg, 100)
+        red = train.GradReducer(m, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
+        red.zero_grad()
+        tot = 0.0
+        for j in range(2):
+            t, _ = train.train_step(m, xs[j], ls[j], w, step_times=2, reducer=red, reduce=(j == 1))
+            tot += sum(v.item() for v in t)
         torch.cuda.synchronize()
-        pr, pm = dict(ref.named_parameters()), dict(m.named_parameters())
-        for k, p in pr.items():
-            if p.grad is None:
-                continue
+        return _flat_grads(m), tot
+
+    m = build(cfg, 100)
+    red = train.GradReducer(m, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
+    g = train.GraphedStep(m, xs[0], ls[0], w0, red, step_times=2)
+    for w in (w0, w1, w0):                     # weights change between optimizer steps; graphs are reused
+        g.set_weights(w)
+        tot = 0.0
+        for j in range(2):
+            t, _ = g(xs[j], ls[j], micro=j)
+            tot += sum(v.item() for v in t)
+        torch.cuda.synchronize()
+        ref, ref_tot = eager(w)
+        got = _flat_grads(m)
+        assert abs(tot - ref_tot) <= 1e-5 * abs(ref_tot)
+        for k, r in ref.items():
+            assert grads_agree(got[k], r, k), k
+    assert set(g.graphs) == {(True, False), (False, True), (True, True)}
+
+
+def test_graphed_step_recaptures_when_storage_moves():
+    """an optimizer built after the capture re-homes every parameter into its flat buffers (optim.FusedAdamW): the next replay must
+    notice (data_ptr check) and capture again instead of reading the old, never-updated weights"""
+    from lintransunet_amd import train, optim
+    cfg = O_net.NetConfig(**SMALL)
+    x = seedgen.seeded_volume((1, 1, 32, 32, 32), 61).to(DEV)
+    lab = seedgen.seeded_label((1, 1, 32, 32, 32), 62).to(DEV)
+    w = O_step.dynamic_weights(0)
+    m = build(cfg, 100)
+    red = train.GradReducer(m, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
+    g = train.GraphedStep(m, x, lab, w, red)
+    l0 = sum(t.item() for t in g(x, lab)[0])
+    first = g.graphs[(True, True)][0]
+    opt = optim.FusedAdamW(red, lr=1e-2)            # moves p.data
+    opt.step()
+    l1 = sum(t.item() for t in g(x, lab)[0])
+    assert g.graphs[(True, True)][0] is not first       # re-captured
+    ref = build(cfg, 100)
+    ref.load_state_dict(m.state_dict())
+    lr = sum(t.item() for t in train.train_step(ref, x, lab, w)[0])
+    assert abs(l1 - lr) <= 1e-4 * abs(lr) and abs(l1 - l0) > 1e-6      # the replay saw the updated weights
+
+
+def test_contexts_isolate_captured_arenas():
+    """a GraphedPredictor captured while the scratch arena was small keeps working after a larger GraphedStep has been built and
+    run, and an evaluation between a training forward and its backward does not disturb that backward"""
+    from lintransunet_amd import train, infer as P
+    cfg = O_net.NetConfig(**SMALL)
+    m = build(cfg, 100)
+    win = seedgen.seeded_volume((1, 1, 32, 32, 32), 71).to(DEV)
+    m.eval()
+    pred = P.GraphedPredictor(m, 1, (32, 32, 32), win.device)
+    with torch.no_grad():
+        want = m(win).clone()
+    m.train()
+    assert torch.equal(pred(win), want)
+    x = seedgen.seeded_volume((2, 1, 64, 64, 32), 72).to(DEV)          # a larger training step: more scratch
+    lab = seedgen.seeded_label((2, 1, 64, 64, 32), 73).to(DEV)
+    w = O_step.dynamic_weights(0)
+    red = train.GradReducer(m, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
+    g = train.GraphedStep(m, x, lab, w, red)
+    g(x, lab)
+    torch.cuda.synchronize()
+    assert torch.equal(pred(win), want)                                 # the predictor's arena was not moved or overwritten
+    # eval between forward and backward of an eager step
+    ref = build(cfg, 100)
+    train.train_step(ref, x, lab, w)
+    m2 = build(cfg, 100)
+    with ops_use_default():
+        predict, masks = m2(x)
+        totals, _ = train.deep_supervision_loss(predict, masks, lab, w)
+        m2.eval()
+        with torch.no_grad():
+            m2(win)
+        m2.train()
+        torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    torch.cuda.synchronize()
+    pr, pm = dict(ref.named_parameters()), dict(m2.named_parameters())
+    for k, p in pr.items():
+        if p.grad is not None:
             assert grads_agree(pm[k].grad, p.grad, k), k
-        # with dropout the replays must differ (fresh masks) although the captured seeds are frozen
-        md = build(cfg, 100, dropout=0.3)
-        redd = train.GradReducer(md, bucket_mb=0.5, unused=train.UNUSED_PARAMETERS)
-        gd = train.GraphedStep(md, x, label, w, redd)
-        a = sum(t.item() for t in gd(x, label)[0])
-        b = sum(t.item() for t in gd(x, label)[0])
-        assert np.isfinite(a) and np.isfinite(b) and a != b
-    finally:
-        ops.set_step_counter(None)
+
+
+def ops_use_default():
+    from lintransunet_amd import ops
+    ctx = ops.Context()
+    ctx.begin_step(torch.device(DEV))
+    return ops.use(ctx)
 
 
 def test_smoke_entry():

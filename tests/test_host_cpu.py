@@ -103,6 +103,17 @@ def _reducer_worker(rank, world, port, out):
     ((net[:5](x[shard]) - y[shard]) ** 2).mean().backward()
     red.finish()
     assert all(torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(after_replay, list(net.parameters())[:6]))
+    # gradient accumulation (utils/utils_3D_embed_full.py:85-91): two micro-steps of half a shard each, every loss divided by
+    # step_times = 2; the first only accumulates (no collective may start), the last one reduces
+    red.zero_grad()
+    for j in range(2):
+        red.prepare(reduce=(j == 1))
+        sl = slice(rank * 4 + 2 * j, rank * 4 + 2 * j + 2)
+        (((net[:5](x[sl]) - y[sl]) ** 2).mean() / 2).backward()
+        if j == 0:
+            assert not red.handles
+        red.finish()
+    assert all(torch.allclose(a, p.grad, atol=1e-6) for a, p in zip(after_replay, list(net.parameters())[:6]))
     if rank == 0:
         ref = torch.nn.Sequential(*[m for m in list(net.children())[:5]])
         grads = [p.grad.clone() for p in list(net.parameters())[:6]]
@@ -128,3 +139,40 @@ def test_grad_reducer_world2_gloo():
         assert p.exitcode == 0
     assert err < 1e-6
     assert unused_none
+
+
+def _run_bench(args, env_extra=None, timeout=180):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_self_launch_dry_run_world2():
+    """`python bench.py --gpus 2` with no launcher environment (the form of the driver's command): the parent starts one child per
+    rank before touching the GPU, the ranks rendezvous on 127.0.0.1 (gloo stub of the RCCL path), rank 0 prints ONE JSON line"""
+    import json
+    r = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['config']['parallelism'] == 'dp2'
+
+
+def test_bench_self_launch_propagates_failure():
+    """a rank that dies takes the launch down with a non-zero exit code (no hang on the survivors' barrier)"""
+    r = _run_bench(['--gpus', '2', '--dry-run', '--steps', '-1'], env_extra={'LTU_BENCH_FAIL_RANK': '1'}, timeout=120)
+    assert r.returncode != 0
+
+
+def test_bench_parent_does_not_import_torch_before_launch():
+    """the self-launching parent must not initialise HIP: it forks its children before importing torch at all"""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    head = src[:src.index('def main():')]
+    assert not re.search(r'^import torch|^from torch', head, flags=re.M)
+    body = src[src.index('def main():'):]
+    assert body.index('self_launch(args)') < body.index('import torch')
