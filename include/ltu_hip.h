@@ -237,10 +237,11 @@ int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, floa
 
 /* ---- dynamic ROI: model/Unet_3Dblock.py:821-873, 37-49 (box), 51-82 (index maps), 985-1117 (warps) ----
  * prob f32 [B,H,W,D,C]: foreground = (1 - prob[...,0]) >= thr.  Writes box [B][6] = (x0,y0,0,x1,y1,D-1)
- * and the sampling plans (sizes from ltu_roi_plan_size) used by ltu_roi_resample. */
-int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n_int, long long* n_float);
+ * and the sampling plans (sizes from ltu_roi_plan_size) used by ltu_roi_resample.  hist: n_hist ints of zero-filled scratch
+ * (foreground histograms; the library issues no memsets of its own, see csrc/roi.hip). */
+int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n_int, long long* n_float, long long* n_hist);
 int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C, int roi_size, float thr, float* box, int* plan_i,
-                 float* plan_f, ltu_stream_t s);
+                 float* plan_f, int* hist, ltu_stream_t s);
 /* which = 0: image [B,H,W,D,C] -> ROI grid [B,eh,ew,D,C] (roi_alignment2); which = 1: ROI grid -> image
  * (post_processing2).  adjoint != 0 applies the transposed operator to a gradient (in has the shape of the
  * forward output, out the shape of the forward input). */

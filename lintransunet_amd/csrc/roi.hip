@@ -212,16 +212,19 @@ static void carve_all(RoiArgs& a, int B, int H, int W, int eval_h, int eval_w, i
   *ni = io; *nf = fo;
 }
 
-extern "C" int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n_int, long long* n_float) {
+extern "C" int ltu_roi_plan_size(int B, int H, int W, int roi_size, long long* n_int, long long* n_float, long long* n_hist) {
   RoiArgs a;
   const int eval_h = (int)(1.2 * roi_size), eval_w = (int)(eval_h * 0.6);
   carve_all(a, B, H, W, eval_h, eval_w, nullptr, nullptr, n_int, n_float);
-  *n_int += (long long)B * 2 * ROI_MAX_LEN;      // foreground histograms (tail of the int buffer)
+  *n_hist = (long long)B * 2 * ROI_MAX_LEN;      // foreground histograms: a separate, zero-filled scratch buffer
   return LTU_OK;
 }
 
+// hist: B * 2 * ROI_MAX_LEN ints, ZERO on entry (caller-provided scratch, like the loss sums).  It used to be the tail of plan_i,
+// cleared here with hipMemsetAsync; inside a captured HIP graph that memset node was not reliably ordered before the histogram
+// kernel on replays (the plan then saw an empty histogram and fell back to the empty-mask box), so the library issues no memsets.
 extern "C" int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C, int roi_size, float thr, float* box, int* plan_i,
-                            float* plan_f, ltu_stream_t s) {
+                            float* plan_f, int* hist, ltu_stream_t s) {
   if (H > ROI_MAX_LEN || W > ROI_MAX_LEN) return LTU_E_SHAPE;
   RoiArgs a;
   a.prob = prob; a.B = B; a.H = H; a.W = W; a.D = D; a.C = C; a.thr = thr; a.box = box;
@@ -233,9 +236,7 @@ extern "C" int ltu_roi_plan(const float* prob, int B, int H, int W, int D, int C
   a.min_w = a.eval_w / 2;
   long long ni, nf;
   carve_all(a, B, H, W, a.eval_h, a.eval_w, plan_i, plan_f, &ni, &nf);
-  int* hist = plan_i + ni;
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)B * 2 * ROI_MAX_LEN * sizeof(int), (hipStream_t)s);
-  if (e != hipSuccess) return (int)e;
+  if (hist == nullptr) return LTU_E_ARG;
   const long long n = (long long)H * W * D;
   const int nblk = (int)(n / 4096 < 1 ? 1 : (n / 4096 > 256 ? 256 : n / 4096));
   hipLaunchKernelGGL(roi_hist_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)s, prob, H, W, D, C, thr, hist);

@@ -372,8 +372,8 @@ class RoiPlan:
     def __init__(self, prob, roi_size, thr=0.5):
         _chk(prob, 'prob')
         B, H, W, D, C = prob.shape
-        ni, nf = ctypes.c_longlong(0), ctypes.c_longlong(0)
-        _lib.call('ltu_roi_plan_size', B, H, W, roi_size, ctypes.byref(ni), ctypes.byref(nf))
+        ni, nf, nh = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        _lib.call('ltu_roi_plan_size', B, H, W, roi_size, ctypes.byref(ni), ctypes.byref(nf), ctypes.byref(nh))
         self.B, self.H, self.W, self.D, self.roi_size = B, H, W, D, roi_size
         self.eval_h = int(1.2 * roi_size)
         self.eval_w = int(self.eval_h * 0.6)
@@ -381,7 +381,9 @@ class RoiPlan:
         self.ibuf = torch.empty(ni.value, device=prob.device, dtype=torch.int32)
         self.fbuf = torch.empty(nf.value, device=prob.device, dtype=torch.float32)
         self.box = torch.empty((B, 6), device=prob.device, dtype=torch.float32)
-        _lib.call('ltu_roi_plan', _p(prob), B, H, W, D, C, roi_size, float(thr), _p(self.box), _p(self.ibuf), _p(self.fbuf), _s())
+        hist = current().scratch_zeros((nh.value,), prob.device)          # zero bits: read as int32 by the kernels
+        _lib.call('ltu_roi_plan', _p(prob), B, H, W, D, C, roi_size, float(thr), _p(self.box), _p(self.ibuf), _p(self.fbuf),
+                  _p(hist), _s())
 
 
 # ---------------------------------------------------------------------------------------------- conv / linear

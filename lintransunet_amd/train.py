@@ -283,7 +283,7 @@ class GraphedStep:
             torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
-        kw = {} if self.pool is None else {'pool': self.pool}
+        kw = {} if (self.pool is None or os.environ.get('LTU_GRAPH_SHARE_POOL', '1') == '0') else {'pool': self.pool}
         with torch.cuda.graph(graph, capture_error_mode='thread_local', **kw):
             totals, named = self._body(zero, reduce)
         if self.pool is None:
