@@ -8,6 +8,7 @@ from autograd hooks so that it overlaps the rest of backward.
 """
 import math
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -278,9 +279,16 @@ class GraphedStep:
                     self._body(True, True)
             torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.barrier()                 # no collective in flight while the stream is capturing
-            torch.cuda.synchronize(dev)
+        if dist.is_initialized():
+            if dist.get_world_size() > 1:
+                dist.barrier()             # no collective in flight while the stream is capturing
+                torch.cuda.synchronize(dev)
+            # The process group's watchdog thread polls the completion events of every eagerly issued collective (warm-up, the
+            # barrier above) until it has retired them, in a 100 ms loop.  Once the captured collectives have pulled the group's
+            # RCCL stream into the capture, such a poll fails with hipErrorCapturedEvent and the watchdog aborts the process
+            # (observed with ROCm 7.0 / torch 2.10).  All eager collectives are complete here, so give the watchdog a few loop
+            # periods to empty its list; nothing is enqueued during the capture itself (captured works are never handed to it).
+            time.sleep(0.5)
         graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
         kw = {} if (self.pool is None or os.environ.get('LTU_GRAPH_SHARE_POOL', '1') == '0') else {'pool': self.pool}

@@ -16,13 +16,16 @@ from oracle import seedgen, step as O_step
 
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
+# fp32 storage: run-to-run differences are 1e-6 (bf16 storage turns the last-bit noise of atomic sums into 1e-2 gradient differences)
+DT = torch.bfloat16 if 'bf16' in sys.argv else torch.float32
+CYCLES = int(os.environ.get('CYCLES', '1'))
 dist.init_process_group('nccl', device_id=dev)
 
 
 def build():
     torch.manual_seed(5)
     m = get_model_dict('MaskTransUnet')([8, 8, 8, 16, 32], [20, 12, 9, 10, 6], [False, True, True, True, True], 1, 2,
-                                        dropout=0.0, act_dtype=torch.bfloat16).to(dev).train()
+                                        dropout=0.0, act_dtype=DT).to(dev).train()
     train.broadcast_parameters(m)
     red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS)
     red.world = 2           # force the collective path
@@ -37,8 +40,16 @@ calls = {'n': 0}
 orig = dist.all_reduce
 
 
+import threading
+seen = set()
+
+
 def counting(*a, **k):
     calls['n'] += 1
+    key = (threading.current_thread().name, torch.cuda.is_current_stream_capturing(), torch.cuda.current_stream().cuda_stream)
+    if key not in seen:
+        seen.add(key)
+        print('all_reduce from', key, flush=True)
     return orig(*a, **k)
 
 
@@ -73,7 +84,7 @@ results['eager'] = [f.clone() for f in red.flat]
 for mode in ('after', 'eager'):
     worst = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(results['graph'], results[mode]))
     print(f'gradients graph vs {mode}: worst bucket rel-L2 {worst:.2e}')
-    assert worst < 5e-3
+    assert worst < (5e-2 if DT == torch.bfloat16 else 1e-4)
 # accumulation: 2 micro-steps, collectives only inside the last one's graph
 m, red = build()
 calls['n'] = 0
@@ -84,7 +95,16 @@ torch.cuda.synchronize()
 acc = [f.clone() for f in red.flat]
 worst = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(acc, results['graph']))
 print(f'2 accumulated half-weight micro-steps vs one step: worst bucket rel-L2 {worst:.2e}; graphs {sorted(step.graphs)}')
-assert worst < 5e-3
+assert worst < (5e-2 if DT == torch.bfloat16 else 1e-4)
+# repeated build / capture / replay cycles: the watchdog must survive every capture
+for c in range(CYCLES - 1):
+    m, red = build()
+    step = train.GraphedStep(m, x, lab, w, red, overlap='graph')
+    for _ in range(3):
+        step(x, lab)
+    torch.cuda.synchronize()
+    time.sleep(0.15)
+print('cycles', CYCLES)
 dist.barrier()
 print('ok')
 dist.destroy_process_group()
