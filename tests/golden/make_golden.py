@@ -415,6 +415,63 @@ def fx_infer512():
     print(f'infer512.npz written (mean class-1 vote {out[:, 1].mean().item():.6f})')
 
 
+def heldout_batch(batch, seed, size=(64, 64, 32)):
+    """the generator of tools/train_heldout.py (bright seeded ellipsoids + noise), restated so that this script and the tests
+    rebuild the held-out volumes from a seed"""
+    lab = seedgen.seeded_label((batch, 1) + size, seed, n_blobs=2)
+    noise = seedgen.seeded_volume((batch, 1) + size, seed + 1)
+    return 0.6 * noise + 1.2 * lab.float() - 0.3, lab
+
+
+def fx_heldout():
+    """north_star: "Dice parity to the reference on a held-out synthetic volume" with NON-random weights.
+    gpurun_out/heldout_small.pt is the reference-loadable checkpoint (`model.state_dict()`, train3D.py:268) that
+    tools/train_heldout.py wrote on the GPU box after 400 graph-replayed steps + fused AdamW on synthetic ellipsoids.  Here the
+    REFERENCE loads it (strict, train3D.py:113-117: the checkpoint round trip) and runs (a) a train-mode forward on a held-out
+    patch and (b) its sliding-window evaluation (inference_embed_attn.py:141-150; window driver = the oracle's restatement of
+    monai's) on a held-out 96x80x48 scan.  The weights travel with the fixture (652 044 fp32 values)."""
+    ck = os.path.join(ROOT, 'gpurun_out', 'heldout_small.pt')
+    sd = torch.load(ck)
+    cfg = O_net.NetConfig(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
+    Model = get_model_dict('MaskTransUnet')
+    model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
+                  dim_input=1, dim_output=2, kernel_size=3)
+    model.load_state_dict(sd, strict=True)
+    kill_dropout(model)
+    model.train()
+    boxes = []
+    for m in model.modules():
+        if isinstance(m, R_ub.ROIBridge):
+            orig = m.get_mask_boundary2
+            m.get_mask_boundary2 = (lambda o: (lambda mask: (boxes.append(o(mask)), boxes[-1])[1]))(orig)
+    x, lab = heldout_batch(1, 999001)
+    with torch.no_grad():
+        predict, masks = model(x)
+    patch_boxes = [b.clone() for b in boxes]
+    dice = R_loss.DiceClassLoss()(predict, lab.long())
+    o_pred, _ = O_net.forward({k: v for k, v in sd.items()}, cfg, x, True, [])
+    close(o_pred, predict, 'heldout.out')
+    # whole-scan evaluation: eval-mode one-hot windows, overlap 0.6, threshold 0.5, the four metrics of the driver
+    xs, labs = heldout_batch(1, 999101, (96, 80, 48))
+    model.eval()
+    with torch.no_grad():
+        votes = O_infer.sliding_window_inference(xs, (64, 64, 32), 4, model, overlap=0.6)
+    pred2 = (votes >= 0.5).float()
+    metrics = [R_loss.DiceClassLoss()(pred2, labs.long()), R_loss.Recall()(pred2, labs.long()), R_loss.Precision()(pred2, labs.long()),
+               R_loss.LocalizationLoss()(pred2, labs.long())]
+    flat = predict.flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 8192).long()
+    out = {'w::' + k: np32(v) for k, v in sd.items()}
+    out.update(dice=np.float64(dice.item()), out_idx=idx.numpy(), out_sample=np32(flat[idx]),
+               scan_votes=np32(votes[0, 1]),
+               scan_metrics=np.array([m.item() for m in metrics], np.float64))
+    for i, b in enumerate(patch_boxes):
+        out[f'box{i}'] = np32(b)
+    np.savez_compressed(os.path.join(HERE, 'heldout_small.npz'), **out)
+    print(f'heldout_small.npz: patch Dice loss {dice.item():.6f} (foreground Dice {1 - dice.item():.4f}); scan metrics '
+          f'{[round(m.item(), 6) for m in metrics]}; vote values {torch.unique(votes).tolist()}')
+
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
@@ -429,6 +486,9 @@ def main():
         fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)
         fx_model('full96', O_net.NetConfig(), (96, 96, 96), 2, 600, full_arrays=False)
         fx_model('win512', O_net.NetConfig(), (512, 512, 32), 1, 800, full_arrays=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'heldout':      # needs gpurun_out/heldout_small.pt (tools/train_heldout.py on the GPU box)
+        fx_heldout()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'infer512':     # only the config-5 window fixture (~1 min)
         fx_infer512()

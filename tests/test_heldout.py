@@ -1,0 +1,95 @@
+"""Dice parity with the reference on a held-out synthetic volume, with TRAINED weights (north_star, SURVEY 8d "Parity gates").
+
+tests/golden/heldout_small.npz holds a checkpoint that tools/train_heldout.py trained on the GPU box (small configuration, 400
+graph-replayed steps + fused AdamW on bright synthetic ellipsoids, foreground Dice 0.97) and what the REFERENCE computes from it
+(tests/golden/make_golden.py heldout: strict load of our `state_dict` into the reference model = the checkpoint round trip of
+train3D.py:113-117 / 268, a train-mode forward on a held-out patch, and the sliding-window evaluation of
+inference_embed_attn.py:141-150 on a held-out scan)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import net as O_net
+from oracle import seedgen
+
+SMALL = dict(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
+DEV = 'cuda'
+
+
+def heldout_batch(batch, seed, size=(64, 64, 32)):
+    lab = seedgen.seeded_label((batch, 1) + size, seed, n_blobs=2)
+    noise = seedgen.seeded_volume((batch, 1) + size, seed + 1)
+    return 0.6 * noise + 1.2 * lab.float() - 0.3, lab
+
+
+def _weights(G):
+    return {k[3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith('w::')}
+
+
+def test_oracle_on_trained_checkpoint(golden_dir):
+    """CPU: the oracle restatement reproduces the reference's held-out Dice from the same checkpoint"""
+    from oracle import losses as O_loss
+    G = np.load(os.path.join(golden_dir, 'heldout_small.npz'))
+    cfg = O_net.NetConfig(**SMALL)
+    P = _weights(G)
+    assert set(P) == set(O_net.param_shapes(cfg))
+    x, lab = heldout_batch(1, 999001)
+    with torch.no_grad():
+        pred, _ = O_net.forward(P, cfg, x, True, [])
+    assert abs(O_loss.dice_class(pred, lab.long()).item() - float(G['dice'])) <= 1e-6
+    assert float(G['dice']) < 0.05          # the checkpoint really segments (foreground Dice > 0.95), unlike random weights
+
+
+def _model(G, dtype):
+    from lintransunet_amd.model import get_model_dict
+    cfg = O_net.NetConfig(**SMALL)
+    m = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, 2, dropout=0.0, act_dtype=dtype)
+    m.load_state_dict(_weights(G), strict=True)
+    return m.to(DEV).train()
+
+
+# fp32 storage: the 1e-4 gate of north_star.  bf16 storage (the benchmarked dtype): the same 1e-4 gate; the reference's own
+# bf16-autocast vs fp32 pair differs by 8e-5.
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,dice_tol,out_tol', [(torch.float32, 1e-4, 1e-3), (torch.bfloat16, 1e-4, None)])
+def test_heldout_patch_dice(golden_dir, dtype, dice_tol, out_tol):
+    from lintransunet_amd import losses as L
+    G = np.load(os.path.join(golden_dir, 'heldout_small.npz'))
+    model = _model(G, dtype)
+    x, lab = heldout_batch(1, 999001)
+    predict, masks = model(x.to(DEV))
+    dice = L.DiceClassLoss()(predict.detach(), lab.to(DEV)).item()
+    flat = predict.detach().cpu().flatten()[torch.from_numpy(G['out_idx'])].double()
+    ref = torch.from_numpy(G['out_sample']).double()
+    err = (flat - ref).abs().max().item() / ref.abs().max().item()
+    print(f'[heldout {dtype}] Dice loss {dice:.6f} vs reference {float(G["dice"]):.6f} (d {dice - float(G["dice"]):+.2e}); '
+          f'sampled max-rel err {err:.2e}; boxes equal {[torch.equal(b.cpu(), torch.from_numpy(G[f"box{i}"])) for i, b in enumerate(model.last_boxes)]}')
+    assert abs(dice - float(G['dice'])) <= dice_tol
+    if out_tol is not None:
+        assert err <= out_tol
+        for i, b in enumerate(model.last_boxes):
+            assert torch.equal(b.cpu(), torch.from_numpy(G[f'box{i}'])), f'box{i}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1e-3)])
+def test_heldout_scan_evaluation(golden_dir, dtype, tol):
+    """the inference driver (infer.infer_volume + infer.evaluate = inference_embed_attn.py:141-150) on a held-out 96x80x48 scan:
+    Dice / Recall / Precision / LocalizationLoss of the thresholded votes against the reference's"""
+    from lintransunet_amd import infer as P
+    G = np.load(os.path.join(golden_dir, 'heldout_small.npz'))
+    model = _model(G, dtype)
+    xs, labs = heldout_batch(1, 999101, (96, 80, 48))
+    votes = P.infer_volume(model, xs.to(DEV), depth_size=32, roi_xy=64, sw_batch_size=4, overlap=0.6)
+    vals = P.evaluate(votes, labs.to(DEV), threshold=0.5)
+    got = [vals[n].item() for n in P.METRIC_NAMES]
+    ref_votes = torch.from_numpy(G['scan_votes'])
+    mism = ((votes[0, 1].cpu() >= 0.5) != (ref_votes >= 0.5)).float().mean().item()
+    print(f'[heldout scan {dtype}] metrics {["%.6f" % v for v in got]} vs reference {["%.6f" % v for v in G["scan_metrics"]]}; '
+          f'thresholded voxels that differ {mism:.2e}')
+    for name, v, r in zip(P.METRIC_NAMES, got, G['scan_metrics']):
+        assert abs(v - r) <= tol, name
+    if dtype == torch.float32:
+        assert mism <= 1e-5
