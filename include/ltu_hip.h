@@ -104,6 +104,21 @@ int ltu_reduce_batch(const ltu_reduce_job* jobs, int njobs, ltu_stream_t s);   /
 long long ltu_wgrad_ws_floats(long long M, int N, int K);
 int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw, int M, int N,
                      int K, float* ws, ltu_reduce_job* defer, int dtype, ltu_stream_t s);
+/* Several of the above in ONE launch + ONE fold: the weight / bias gradients of the four projections of a transformer layer
+ * (model/trans_block.py:144,156,166,187,189: q,k,v as one job with nw = 3, out, linear1, linear2).  Together they offer 8-32
+ * output tiles, so a few row splits per tile fill the chip and the fp32 partial tiles shrink 4x against four separate calls.
+ * jobs: host array (<= LTU_WGRAD_GROUP_MAX); ws: ltu_linear_wgrad_group_ws_floats() floats (0 = this group is not handled:
+ * use ltu_linear_wgrad per job; bf16 storage, N and K multiples of 128, M a multiple of 32 and >= 1024). */
+#define LTU_WGRAD_GROUP_MAX 8
+typedef struct ltu_wgrad_job {
+  const void* grad;    /* g [M][ldg] */
+  const void* a;       /* a [M][lda] */
+  float* dw[3];        /* nw gradient blocks [N/nw][K] (+=) */
+  float* db[3];        /* nw bias-gradient blocks (nullable) */
+  int ldg, lda, nw, M, N, K;
+} ltu_wgrad_job;
+long long ltu_linear_wgrad_group_ws_floats(const ltu_wgrad_job* jobs, int njobs);
+int ltu_linear_wgrad_group(const ltu_wgrad_job* jobs, int njobs, float* ws, int dtype, ltu_stream_t s);
 
 /* Workspace (floats) that ltu_upconv_wgrad needs for M = B*H*W*D coarse voxels (bf16 path; sub-pixel un-embedding of
  * model/Unet_3Dblock.py:419-432). */

@@ -19,6 +19,12 @@ class ReduceJob(ctypes.Structure):
                 ('out', c_void_p * 3), ('outb', c_void_p * 3), ('mode', c_int)]
 
 
+class WgradJob(ctypes.Structure):
+    """struct ltu_wgrad_job (include/ltu_hip.h)"""
+    _fields_ = [('grad', c_void_p), ('a', c_void_p), ('dw', c_void_p * 3), ('db', c_void_p * 3),
+                ('ldg', c_int), ('lda', c_int), ('nw', c_int), ('M', c_int), ('N', c_int), ('K', c_int)]
+
+
 # name -> argument types (return type is always int).  Mirrors include/ltu_hip.h one to one.
 SIGNATURES = {
     'ltu_version': [],
@@ -33,6 +39,8 @@ SIGNATURES = {
     'ltu_upconv_wgrad_ws_floats': [L, I, I],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
     'ltu_reduce_batch': [P, I, P],
+    'ltu_linear_wgrad_group_ws_floats': [P, I],
+    'ltu_linear_wgrad_group': [P, I, P, I, P],
     'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
     'ltu_conv3d_ws_floats': [I, I, I, I, I, I],
     'ltu_conv3d_pair_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, P, I, P],

@@ -450,6 +450,15 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
   return LTU_OK;
 }
 
+extern "C" long long ltu_linear_wgrad_group_ws_floats(const ltu_wgrad_job* jobs, int njobs) {
+  return tn_ring_group_ws_floats(jobs, njobs);
+}
+extern "C" int ltu_linear_wgrad_group(const ltu_wgrad_job* jobs, int njobs, float* ws, int dtype, ltu_stream_t s) {
+  if (dtype != LTU_BF16) return LTU_E_DTYPE;
+  const int rc = launch_tn_ring_group_bf16(jobs, njobs, ws, (hipStream_t)s);
+  return rc == 1 ? LTU_E_SHAPE : rc;
+}
+
 static bool use_halo() {
   int v = -1;
   v = ltu_knob("LTU_NO_HALO", 0) ? 0 : 1;

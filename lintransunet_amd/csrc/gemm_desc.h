@@ -157,7 +157,10 @@ int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st);
 bool tn_ring_shape_ok(long long M, int N, int K);
 long long tn_ring_ws_floats(long long M, int N, int K);
 int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out = nullptr);   // LTU_OK / hipError, or 1 = shape not handled
-int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled (also: gelu_out set and no ring)
+int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);
+// several dense weight gradients in one launch + one fold launch; 0 floats / 1 = group not handled
+long long tn_ring_group_ws_floats(const ltu_wgrad_job* jobs, int njobs);
+int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled (also: gelu_out set and no ring)
 
 // class convolutions on an LDS halo brick (conv_halo.hip): fine voxel o = m q + p gets sum_e [cls_e == class(p)] x[q + d_e] . W_e^T
 struct ClsEntry {

@@ -44,17 +44,15 @@ __device__ __forceinline__ void ring_sync() {
 // dW[n][k] = sum_m G[m][n] X[m][k] for one 128 x 128 tile over the rows of one split.  Unit = 32 rows: G [32][128] then
 // X [32][128] bf16 (256-byte rows, 16 chunks); chunk c of row r sits at slot c ^ ((r & 3) << 2), which makes the 4-row x
 // 64-byte footprint of a transposing read (ds_read_b64_tr_b16) cover all 64 banks.  4 waves as 2 (n) x 2 (k), 64 x 64 each.
+// One 128 x 128 tile of dW over rows [m_begin, m_end): partial tile to pz [npad][kpad] (+ bias partial row to bz [npad] from the
+// workgroups with k_blk == 0).
 template <int R>
-__global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa) {
-  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];      // [R][2][32][128]
+__device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ grad, int ldg, const uint16_t* __restrict__ x, int lda,
+                                                long long m_begin, long long m_end, int n_blk, int k_blk, float* __restrict__ pz,
+                                                float* __restrict__ bz, int kpad, uint16_t* smem) {
   constexpr int UNIT = 2 * 32 * 128;                                     // elements
-  const IGemmArgs& g = wa.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int k_blk = blockIdx.x * 128, n_blk = blockIdx.y * 128;
-  const long long m_begin = (long long)blockIdx.z * wa.rows_per_split;
-  long long m_end = m_begin + wa.rows_per_split;
-  if (m_end > g.M) m_end = g.M;
   const int niter = m_end > m_begin ? (int)((m_end - m_begin) >> 5) : 0;
 
   f32x16 acc[2][2];
@@ -69,9 +67,9 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
   // LDS-DMA sources: wave w fills pieces w and w + 4 (4 rows x 256 B each) of G and of X; lane -> (row = lane >> 4, slot = lane & 15)
   const int prow = 4 * wave + (lane >> 4);
   const int lchunk = (lane & 15) ^ ((lane >> 4) << 2);
-  const uint16_t* gsrc = reinterpret_cast<const uint16_t*>(wa.grad) + (m_begin + prow) * wa.ldg + n_blk + lchunk * 8;
-  const uint16_t* xsrc = reinterpret_cast<const uint16_t*>(g.a0) + (m_begin + prow) * g.lda0 + k_blk + lchunk * 8;
-  const long long gstep16 = 16LL * wa.ldg, xstep16 = 16LL * g.lda0;
+  const uint16_t* gsrc = grad + (m_begin + prow) * ldg + n_blk + lchunk * 8;
+  const uint16_t* xsrc = x + (m_begin + prow) * lda + k_blk + lchunk * 8;
+  const long long gstep16 = 16LL * ldg, xstep16 = 16LL * lda;
   auto issue = [&](int slot) {
     uint16_t* base = smem + slot * UNIT + wave * 512;
     glds16(gsrc, base);
@@ -92,7 +90,7 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
     acol[i] = ((((wm * 2 + i) * 4 + (tcol >> 3)) ^ (tq << 2)) << 3) + (tcol & 7);
     bcol[i] = ((((wn * 2 + i) * 4 + (tcol >> 3)) ^ (tq << 2)) << 3) + (tcol & 7);
   }
-  const bool do_bias = blockIdx.x == 0 && wn == 0;
+  const bool do_bias = k_blk == 0 && wn == 0;
 
   for (int u = 0; u < R - 1 && u < niter; ++u) issue(u);
   for (int it = 0; it < niter; ++it) {
@@ -133,12 +131,11 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
   }
 
   const int li = lane & 31, lh = lane >> 5;
-  float* pz = wa.part + (long long)blockIdx.z * wa.npad * wa.kpad;
   if (do_bias) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float t = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (lh == 0) wa.bpart[(long long)blockIdx.z * wa.npad + n_blk + (wm * 2 + i) * 32 + li] = t;
+      if (lh == 0) bz[n_blk + (wm * 2 + i) * 32 + li] = t;
     }
   }
 #pragma unroll
@@ -149,9 +146,57 @@ __global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n_blk + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        pz[(long long)n * wa.kpad + k] = acc[i][j][r];
+        pz[(long long)n * kpad + k] = acc[i][j][r];
       }
   }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) wgrad_ring_bf16_kernel(const WGradArgs wa) {
+  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];      // [R][2][32][128]
+  const IGemmArgs& g = wa.g;
+  const long long m_begin = (long long)blockIdx.z * wa.rows_per_split;
+  long long m_end = m_begin + wa.rows_per_split;
+  if (m_end > g.M) m_end = g.M;
+  wgrad_ring_tile<R>(reinterpret_cast<const uint16_t*>(wa.grad), wa.ldg, reinterpret_cast<const uint16_t*>(g.a0), g.lda0, m_begin, m_end,
+                     blockIdx.y * 128, blockIdx.x * 128, wa.part + (long long)blockIdx.z * wa.npad * wa.kpad,
+                     wa.bpart + (long long)blockIdx.z * wa.npad, wa.kpad, smem);
+}
+
+// Several weight gradients in ONE launch (the four projections of a transformer layer: qkv, out, ffn1, ffn2).  Launched
+// one by one each of them spreads its one to six 128 x 128 tiles over ~256 workgroups, i.e. 40-240 row splits whose fp32 partial
+// tiles (16 MB per call) have to be written and folded; together they offer 8-32 tiles, so 8-32 splits fill the chip: a quarter of
+// the partial traffic, one launch instead of four, one fold (ltu_reduce_batch) instead of four.
+struct WGroupJob {
+  const uint16_t* grad;
+  const uint16_t* x;
+  float* part;          // [nsplit][N][K] followed by the bias partials [nsplit][N]
+  long long M;
+  int ldg, lda, N, K, nk, rows, nsplit;
+  int blk_begin;        // first workgroup of this job; its workgroups are ordered (split, n tile, k tile)
+};
+struct WGroupArgs {
+  WGroupJob j[LTU_WGRAD_GROUP_MAX];
+  int njobs;
+};
+template <int R>
+__global__ void __launch_bounds__(256) wgrad_group_ring_bf16_kernel(const WGroupArgs ga) {
+  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
+  int ji = 0;
+#pragma unroll
+  for (int t = 1; t < LTU_WGRAD_GROUP_MAX; ++t)
+    if (t < ga.njobs && (int)blockIdx.x >= ga.j[t].blk_begin) ji = t;
+  const WGroupJob& jb = ga.j[ji];
+  const int local = (int)blockIdx.x - jb.blk_begin;
+  const int tiles = (jb.N >> 7) * jb.nk;
+  const int split = local / tiles, t = local - split * tiles;
+  const int nb = t / jb.nk, kb = t - nb * jb.nk;
+  const long long m_begin = (long long)split * jb.rows;
+  long long m_end = m_begin + jb.rows;
+  if (m_end > jb.M) m_end = jb.M;
+  float* bpart = jb.part + (long long)jb.nsplit * jb.N * jb.K;
+  wgrad_ring_tile<R>(jb.grad, jb.ldg, jb.x, jb.lda, m_begin, m_end, nb * 128, kb * 128, jb.part + (long long)split * jb.N * jb.K,
+                     bpart + (long long)split * jb.N, jb.K, smem);
 }
 
 // ------------------------------------------------------------------------------------------------ NT (projection)
@@ -449,4 +494,148 @@ int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out) {
   if (rc) return rc;
   if (nsplit_out != nullptr) { *nsplit_out = t.nsplit; return LTU_OK; }
   return launch_wgrad_reduce(wa, t.nsplit, st);
+}
+
+// ---- grouped weight gradients ---------------------------------------------------------------------------------------------
+// Fold of the group's partial tiles: dW[seg][n][k] += sum_split part[split][n][k], db likewise.  A workgroup owns 64 float4 outputs;
+// its 4 thread groups each sum a quarter of the splits with 16-byte loads (all of a thread's loads are independent: several in
+// flight), combine through LDS, and group 0 adds the result to the gradient.  The partials were written just before and are
+// mostly still in L2 / MALL.
+struct WFoldJob {
+  const float* part;
+  float* out[3];
+  float* outb[3];
+  int nsplit, N, K, nseg;
+  int blk_begin, wblocks;      // workgroups [blk_begin, blk_begin + wblocks) fold weights, the following ones the bias rows
+};
+struct WFoldArgs {
+  WFoldJob j[LTU_WGRAD_GROUP_MAX];
+  int njobs;
+};
+__global__ void __launch_bounds__(256) wgroup_fold_kernel(const WFoldArgs fa) {
+  __shared__ float4 red[3][64];
+  int ji = 0;
+#pragma unroll
+  for (int t = 1; t < LTU_WGRAD_GROUP_MAX; ++t)
+    if (t < fa.njobs && (int)blockIdx.x >= fa.j[t].blk_begin) ji = t;
+  const WFoldJob& jb = fa.j[ji];
+  const int local = (int)blockIdx.x - jb.blk_begin;
+  const int nper = jb.N / jb.nseg;
+  const long long nk = (long long)jb.N * jb.K;
+  if (local < jb.wblocks) {
+    const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long e = ((long long)local * 64 + lane64) * 4;          // first of 4 consecutive k of one row n (K % 128 == 0)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < nk) {
+      const float* p = jb.part + e;
+#pragma unroll 4
+      for (int sp = grp; sp < jb.nsplit; sp += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long long)sp * nk);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    if (grp > 0) red[grp - 1][lane64] = acc;
+    __syncthreads();
+    if (grp == 0 && e < nk) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 v = red[q][lane64];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      const int n = (int)(e / jb.K), k = (int)(e - (long long)n * jb.K);
+      const int seg = n / nper;
+      float* o = (seg == 0 ? jb.out[0] : (seg == 1 ? jb.out[1] : jb.out[2])) + (long long)(n - seg * nper) * jb.K + k;
+      float4 cur = *reinterpret_cast<float4*>(o);
+      cur.x += acc.x; cur.y += acc.y; cur.z += acc.z; cur.w += acc.w;
+      *reinterpret_cast<float4*>(o) = cur;
+    }
+  } else {
+    const int n = (local - jb.wblocks) * 256 + (int)threadIdx.x;
+    if (n < jb.N) {
+      const float* bp = jb.part + (long long)jb.nsplit * nk + n;
+      float a = 0.f;
+#pragma unroll 4
+      for (int sp = 0; sp < jb.nsplit; ++sp) a += bp[(long long)sp * jb.N];
+      const int seg = n / nper;
+      float* o = seg == 0 ? jb.outb[0] : (seg == 1 ? jb.outb[1] : jb.outb[2]);
+      if (o != nullptr) o[n - seg * nper] += a;
+    }
+  }
+}
+
+static void wgroup_geometry(const ltu_wgrad_job* jobs, int njobs, WGroupArgs& ga, long long* part_off, long long* ws_floats) {
+  int tiles = 0;
+  for (int i = 0; i < njobs; ++i) tiles += (jobs[i].N / 128) * (jobs[i].K / 128);
+  const int budget = ltu_knob_pos("LTU_WGROUP_BLOCKS", 256);
+  long long off = 0;
+  int blk = 0;
+  ga.njobs = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    WGroupJob& j = ga.j[i];
+    const long long M = jobs[i].M;
+    long long want = budget / (tiles > 0 ? tiles : 1);
+    if (want < 1) want = 1;
+    long long rows = (M + want - 1) / want;
+    if (rows < 128) rows = 128;
+    rows = (rows + 31) / 32 * 32;
+    j.M = M; j.N = jobs[i].N; j.K = jobs[i].K; j.nk = jobs[i].K / 128;
+    j.ldg = jobs[i].ldg; j.lda = jobs[i].lda;
+    j.rows = (int)rows;
+    j.nsplit = (int)((M + rows - 1) / rows);
+    j.blk_begin = blk;
+    blk += j.nsplit * (j.N / 128) * j.nk;
+    part_off[i] = off;
+    off += (long long)j.nsplit * j.N * ((long long)j.K + 1);
+  }
+  *ws_floats = off;
+}
+static bool wgroup_ok(const ltu_wgrad_job* jobs, int njobs) {
+  if (njobs < 1 || njobs > LTU_WGRAD_GROUP_MAX || !ring_enabled() || ltu_knob("LTU_NO_WGROUP", 0)) return false;
+  for (int i = 0; i < njobs; ++i) {
+    const ltu_wgrad_job& j = jobs[i];
+    if (!tn_ring_shape_ok(j.M, j.N, j.K) || j.lda % 8 || j.ldg % 8 || j.nw < 1 || j.nw > 3 || j.N % j.nw) return false;
+    if (((uintptr_t)j.a | (uintptr_t)j.grad) & 15) return false;
+  }
+  return true;
+}
+long long tn_ring_group_ws_floats(const ltu_wgrad_job* jobs, int njobs) {
+  if (!wgroup_ok(jobs, njobs)) return 0;
+  WGroupArgs ga;
+  long long n = 0, off[LTU_WGRAD_GROUP_MAX];
+  wgroup_geometry(jobs, njobs, ga, off, &n);
+  return n;
+}
+// launches the grouped kernel and its fold; returns 1 when the group is not handled
+int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, hipStream_t st) {
+  if (!wgroup_ok(jobs, njobs) || ws == nullptr) return 1;
+  WGroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  long long n = 0, off[LTU_WGRAD_GROUP_MAX];
+  wgroup_geometry(jobs, njobs, ga, off, &n);
+  int blocks = 0, fblocks = 0;
+  WFoldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.njobs = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    WGroupJob& j = ga.j[i];
+    j.part = ws + off[i];
+    j.grad = reinterpret_cast<const uint16_t*>(jobs[i].grad);
+    j.x = reinterpret_cast<const uint16_t*>(jobs[i].a);
+    blocks = j.blk_begin + j.nsplit * (j.N / 128) * j.nk;
+    WFoldJob& f = fa.j[i];
+    f.part = j.part; f.nsplit = j.nsplit; f.N = j.N; f.K = j.K; f.nseg = jobs[i].nw;
+    for (int s = 0; s < 3; ++s) { f.out[s] = s < jobs[i].nw ? jobs[i].dw[s] : nullptr; f.outb[s] = s < jobs[i].nw ? jobs[i].db[s] : nullptr; }
+    f.blk_begin = fblocks;
+    f.wblocks = (int)(((long long)j.N * j.K / 4 + 63) / 64);
+    fblocks += f.wblocks + (j.N + 255) / 256;
+  }
+  constexpr int smem_bytes = TN_RING * 2 * 32 * 128 * 2;
+  static LtuDevOnce attr_once;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_ring_bf16_kernel<TN_RING>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              smem_bytes);
+  }
+  hipLaunchKernelGGL((wgrad_group_ring_bf16_kernel<TN_RING>), dim3(blocks), dim3(256), smem_bytes, st, ga);
+  hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fa);
+  return ltu_check_launch();
 }

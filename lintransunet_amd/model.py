@@ -112,7 +112,7 @@ class _WeightStore:
         self.raw.append((conv_a, conv_b, n1, wf, wd, bias))
         self.pair[key] = ops.PairPrep(wf, wd, bias, Ca, n1)
 
-    def add_linear(self, key, weights):
+    def add_linear(self, key, weights, group=None):
         """weights: list of [N,K(,1,1,1)] parameters sharing K (a fused q,k,v group or a single projection)"""
         N, K = weights[0].shape[0], weights[0].shape[1]
         if self.dtype == torch.float32:
@@ -126,7 +126,7 @@ class _WeightStore:
         wt = torch.empty((K, N * len(weights)), device=self.device, dtype=self.dtype)
         for i, w in enumerate(weights):
             self.recs.append((w, wt, 1, N, K, N * len(weights), i * N))
-        self.lin[key] = ops.LinPrep(fw, wt)
+        self.lin[key] = ops.LinPrep(fw, wt, group)
 
     def finalize(self):
         import numpy as np
@@ -262,10 +262,11 @@ class MaskTransUnet(nn.Module):
                 st.add_upconv(tr.up_embed.module_list[0][1])
             for lay in tr.layers:
                 lin = lay.self_attn.linears
-                st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight])
-                st.add_linear((id(lay), 'o'), [lin[3].weight])
-                st.add_linear((id(lay), 'f1'), [lay.linear1.weight])
-                st.add_linear((id(lay), 'f2'), [lay.linear2.weight])
+                # weight gradients of a layer's projections go out as one group, launched by the qkv backward (the layer's last)
+                st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight], group='flush')
+                st.add_linear((id(lay), 'o'), [lin[3].weight], group='collect')
+                st.add_linear((id(lay), 'f1'), [lay.linear1.weight], group='collect')
+                st.add_linear((id(lay), 'f2'), [lay.linear2.weight], group='collect')
         st.finalize()
         self._store = st
         return st

@@ -109,6 +109,7 @@ class Context:
         self.wg_branch = None       # {'side': torch.cuda.Stream, 'jobs': [(fn, tensors)]}
         self.norm_ws_by_dev = {}
         self.ones = {}
+        self.wg_group = []          # pending projection weight gradients of the current transformer layer (see wgrad_group_push)
 
     def one(self, device):
         """a cached fp32 scalar 1 (the seed gradient of each level loss: no fill launch per level and step)"""
@@ -155,8 +156,39 @@ class Context:
             if len(self.deferred) >= self._DEFER_MAX:
                 self.flush_deferred()
 
+    # -- grouped projection weight gradients: the four projections of a transformer layer (qkv, out, ffn1, ffn2) hand their
+    # weight-gradient jobs in here during the layer's backward; the layer's last one (qkv) flushes them as ONE launch + ONE fold
+    # (ltu_linear_wgrad_group).  Only gradients that live in a reducer's flat buffer take part (nothing reads those before
+    # flush_deferred, which also flushes a group left open).
+    def wgrad_group_push(self, g, x, dws, dbs, M, N, K, flush):
+        self.wg_group.append((g, x, dws, dbs, M, N, K))
+        if flush or len(self.wg_group) >= 8:
+            self.wgrad_group_flush()
+
+    def wgrad_group_flush(self):
+        jobs = self.wg_group
+        if not jobs:
+            return
+        self.wg_group = []
+        arr = (_lib.WgradJob * len(jobs))()
+        for r, (g, x, dws, dbs, M, N, K) in zip(arr, jobs):
+            r.grad, r.a, r.ldg, r.lda, r.nw, r.M, r.N, r.K = g.data_ptr(), x.data_ptr(), N, K, len(dws), M, N, K
+            for i, (dw, db) in enumerate(zip(dws, dbs)):
+                r.dw[i], r.db[i] = dw.data_ptr(), db.data_ptr()
+        lib = _lib.load()
+        n = lib.ltu_linear_wgrad_group_ws_floats(ctypes.addressof(arr), len(jobs))
+        if n > 0:
+            ws = torch.empty(n, device=jobs[0][0].device, dtype=torch.float32)
+            _lib.call('ltu_linear_wgrad_group', ctypes.addressof(arr), len(jobs), _p(ws), BF16, _s())
+            return
+        for g, x, dws, dbs, M, N, K in jobs:            # shapes the grouped kernel does not take: one call each
+            wsb = _wgrad_ws(M, N, K, x)
+            _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(dws), M, N, K, _p(wsb), 0,
+                      _dt(x), _s())
+
     def flush_deferred(self):
         """fold every pending partial-sum workspace into its gradient (stream-ordered; call before gradients are consumed)"""
+        self.wgrad_group_flush()
         if not self.deferred:
             return
         arr = (_lib.ReduceJob * len(self.deferred))(*[j for j, _ in self.deferred])
@@ -280,6 +312,7 @@ def _w_transposed(ws, rows, cols, dtype):
 
 
 DEFER_WGRAD = False
+GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_linear_wgrad_group)
 import os as _os
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
 
@@ -332,11 +365,14 @@ class ConvPrep:
 
 
 class LinPrep:
-    """prepared operands of a (group of) Linear / 1x1x1 conv weights: forward operands and cat(W)^T"""
-    __slots__ = ('w', 'wt')
+    """prepared operands of a (group of) Linear / 1x1x1 conv weights: forward operands and cat(W)^T.
+    group: None = the weight gradient is launched by the op's backward; 'collect' = handed to the context's weight-gradient group
+    (a transformer layer's out / ffn projections); 'flush' = handed in and the group launched (the layer's qkv projection, whose
+    backward is the last of the layer)."""
+    __slots__ = ('w', 'wt', 'group')
 
-    def __init__(self, w, wt):
-        self.w, self.wt = w, wt
+    def __init__(self, w, wt, group=None):
+        self.w, self.wt, self.group = w, wt, group
 
 
 # ---------------------------------------------------------------------------------------------- no-grad helpers
@@ -671,6 +707,13 @@ class _Linear(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(g), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
         gw = [_grad_buf(w) for w in ws]
         gb = [_grad_buf(b) for b in bs]
+        grp = ctx.prep.group if ctx.prep is not None else None
+        if (grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16 and lc.wg_branch is None
+                and all(f for _, f in gw) and all(f for _, f in gb)):
+            lc.wgrad_group_push(g, x, [t for t, _ in gw], [t for t, _ in gb], M, N, K, grp == 'flush')
+            dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
+            dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
+            return (dx, None, *dws, *dbs)
         if lc.wg_branch is not None and all(f for _, f in gw) and all(f for _, f in gb):
             def launch(g=g, x=x, gw=gw, gb=gb):
                 wsb = _wgrad_ws(M, N, K, x)
@@ -741,7 +784,10 @@ class _LinearGelu(torch.autograd.Function):
         def launch(g=g, x=x):
             wsb = _wgrad_ws(M, N, K, x)
             _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
-        if lc.wg_branch is not None and fw and fb:
+        grp = ctx.prep.group if ctx.prep is not None else None
+        if grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16 and lc.wg_branch is None and fw and fb:
+            lc.wgrad_group_push(g, x, [dw], [db], M, N, K, grp == 'flush')
+        elif lc.wg_branch is not None and fw and fb:
             lc.wg_branch['jobs'].append((launch, (g, x)))
         else:
             launch()

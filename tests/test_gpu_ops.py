@@ -384,6 +384,31 @@ def test_dropout_masks(ops):
     assert torch.equal(y2 != 0, keep)
 
 
+@pytest.mark.parametrize('M,d', [(4320, 256), (2048, 128), (21504, 256), (1024, 256)])
+def test_linear_wgrad_group(ops, M, d):
+    """the four projection weight gradients of a transformer layer (qkv with 3 blocks, out, ffn1, ffn2) as ONE grouped launch +
+    ONE fold against torch fp32 (G^T X and column sums of G on the bf16-rounded operands), accumulated onto existing values"""
+    g = G(31)
+    bf = lambda t: t.bfloat16()
+    shapes = [(3 * d, d, 3), (d, d, 1), (2 * d, d, 1), (d, 2 * d, 1)]          # (N, K, nw)
+    lc = ops.Context()
+    want, bufs = [], []
+    for N, K, nw in shapes:
+        gr, x = bf(torch.randn(M, N, generator=g) * 0.1).to(DEV), bf(torch.randn(M, K, generator=g)).to(DEV)
+        dws = [torch.full((N // nw, K), 0.5, device=DEV) for _ in range(nw)]      # += semantics: start from a non-zero value
+        dbs = [torch.full((N // nw,), -0.25, device=DEV) for _ in range(nw)]
+        lc.wgrad_group_push(gr, x, dws, dbs, M, N, K, False)
+        dw = gr.float().t() @ x.float()
+        want.append((dw + 0.5, gr.float().sum(0) - 0.25))
+        bufs.append((dws, dbs))
+    assert len(lc.wg_group) == 4
+    lc.flush_deferred()
+    assert not lc.wg_group
+    for (dw_ref, db_ref), (dws, dbs) in zip(want, bufs):
+        dw, db = torch.cat(dws, 0), torch.cat(dbs, 0)
+        assert rel_err(dw, dw_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
+
+
 # ---------------------------------------------------------------------------------------------- linear attention
 def _qkv_pack(q, k, v):
     B, h, N, dk = q.shape
