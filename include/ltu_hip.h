@@ -65,7 +65,10 @@ int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_str
  * 1 = transpose ([R][C] -> dst[c*p0 + p1 + r]), 2 = pack wf ([R=Co][C=Ci][27] -> [p0=CoP][27][p1=CiP]),
  * 3 = pack wd (-> [p1=CiP][27][p0=CoP]), 4 = fp32 copy of R*C elements (padded biases), 5 / 6 = the sub-pixel
  * operands of ltu_upconv_* ([8][CoP][8][CiP] and [CiP][64][CoP]), 7 = pack wd of one member of a fused conv group: columns
- * [off, off+cnt) of dst [p1=CiP][27][p0=stride], pad = off << 16 | cnt (its wf rows are a kind-2 record at a row offset). */
+ * [off, off+cnt) of dst [p1=CiP][27][p0=stride], pad = off << 16 | cnt (its wf rows are a kind-2 record at a row offset),
+ * 8 / 9 = MFMA fragment order of a dense weight [R][C] for the row-block chain kernels (ltu_layer_tail_*): element
+ * ((ct * KS + ks) * 64 + lane) * 8 + j = W[ct*32 + lane%32][ks*16 + 8*(lane/32) + j] (kind 8, KS = C/16: outputs = rows) or
+ * W[ks*16 + 8*(lane/32) + j][ct*32 + lane%32] (kind 9, KS = R/16: outputs = columns); R*C destination elements. */
 int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
 /* The same with the work dealt out in chunks of LTU_WPREP_CHUNK destination elements: chunks = nchunks device-resident
  * { int record; int first_element / LTU_WPREP_CHUNK } pairs, one workgroup each (a model has hundreds of records of very
@@ -84,6 +87,19 @@ int ltu_linear_fwd(const void* a, int lda, const void* const* w, int nw, const f
  * ltu_gelu_dropout_fwd run back to back with identical results.  ltu_gelu_dropout_bwd(dh, u, ...) is the matching backward. */
 int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias, void* u, void* h, int M, int N, int K, float p,
                         uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+/* ---- post-attention half of a transformer layer as ONE launch (model/trans_block.py:203-211), bf16 storage, d = 128 | 256 ----
+ *   z1 = x + drop(a Wo^T + bo); t1 = LN1(z1); u = t1 W1^T + b1; h = drop(gelu(u)); z2 = t1 + drop(h W2^T + b2); y = LN2(z2)
+ * for the small token levels, where the five separate launches (projection, LayerNorm, projection + GELU, projection,
+ * LayerNorm) are latency- rather than bandwidth-bound: a workgroup carries 64 token rows through the whole chain in LDS.
+ * wo / w1 / w2: bf16 weights in MFMA fragment order (ltu_weight_prep kind 8 of the [out][in] fp32 masters).  All intermediate
+ * tensors the backward pass needs are written (z1, t1, u, h, z2: bf16; stat1 / stat2 [M][2] = mean, rstd).  Rounding points and
+ * dropout masks are those of the op-by-op path (ltu_linear_fwd, ltu_layernorm_fwd, ltu_linear_gelu_fwd). */
+int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void* w1, const void* w2, const float* bo,
+                       const float* b1, const float* b2, const float* g1, const float* be1, const float* g2, const float* be2,
+                       void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1, float* stat2, long long M, int d,
+                       float eps, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int dtype,
+                       ltu_stream_t s);
+
 /* ---- deferred second stage of the two-stage reductions ------------------------------------------
  * ltu_linear_wgrad / ltu_layernorm_bwd can leave the folding of their per-split partial sums to the caller: pass a job
  * record, collect a few, and fold them with ONE launch (ltu_reduce_batch) before the gradients are read.  A record whose

@@ -597,52 +597,62 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
 }
 
 // second stage: gradient[n][k] += sum over splits of part[z][n][k]; db[n] += sum_z bpart[z][n].
-// A workgroup owns 32 consecutive elements; its 8 thread groups each sum every 8th split (coalesced 128-byte reads),
-// then combine through LDS.  Element e < N*K is (n = e / K, k = e % K); the last N elements are the bias sums.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, int nsplit) {
-  __shared__ float red[8][33];
+// Workgroups [0, wblocks) fold weights: each owns 64 groups of 4 consecutive k (16-byte loads; K and kpad are multiples of 4), its
+// 4 thread groups sum every 4th split with independent loads in flight and combine through LDS; the remaining workgroups fold the
+// bias rows.  The scatter into the PyTorch conv layout ([Co][Ci][27]: stride-27 writes) is per element.
+__device__ __forceinline__ void wgrad_reduce_put(const WGradArgs& wa, int n, int k, float v) {
   const IGemmArgs& g = wa.g;
-  const long long nk = (long long)g.N * g.K;
-  const long long total = nk + g.N;
-  const long long zs = (long long)wa.npad * wa.kpad;
-  const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
-  const long long e = (long long)blockIdx.x * 32 + el;
-  float a0 = 0.f, a1 = 0.f;
-  int n = 0, k = 0;
-  if (e < total) {
-    if (e < nk) {
-      n = (int)(e / g.K); k = (int)(e % g.K);
-      const float* p = wa.part + (long long)n * wa.kpad + k;
-      int z = zq;
-      float a2 = 0.f, a3 = 0.f;
-      for (; z + 24 < nsplit; z += 32) { a0 += p[z * zs]; a1 += p[(z + 8) * zs]; a2 += p[(z + 16) * zs]; a3 += p[(z + 24) * zs]; }
-      for (; z < nsplit; z += 8) a0 += p[z * zs];
-      a0 += a2; a1 += a3;
-    } else {
-      n = (int)(e - nk);
-      for (int z = zq; z < nsplit; z += 8) a0 += wa.bpart[(long long)z * wa.npad + n];
-    }
-  }
-  red[zq][el] = a0 + a1;
-  __syncthreads();
-  if (zq != 0 || e >= total) return;
-  float v = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) v += red[q][el];
-  if (e < nk) {
-    if (wa.t_co) {
-      const int slot = k / g.C, c = k - slot * g.C;
-      if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
-      else if (wa.dw2 != nullptr && n >= wa.n0_2 && n - wa.n0_2 < wa.t_co2 && c < wa.t_ci)
-        wa.dw2[((long long)(n - wa.n0_2) * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
-    } else if (wa.nseg_w > 1) {
-      const int nper = g.N / wa.nseg_w, seg = n / nper;
-      wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
-    } else {
-      const int slot = k / g.C, c = k - slot * g.C;
-      wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
-    }
+  if (wa.t_co) {
+    const int slot = k / g.C, c = k - slot * g.C;
+    if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
+    else if (wa.dw2 != nullptr && n >= wa.n0_2 && n - wa.n0_2 < wa.t_co2 && c < wa.t_ci)
+      wa.dw2[((long long)(n - wa.n0_2) * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
   } else if (wa.nseg_w > 1) {
+    const int nper = g.N / wa.nseg_w, seg = n / nper;
+    wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
+  } else {
+    const int slot = k / g.C, c = k - slot * g.C;
+    wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
+  }
+}
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, int nsplit, int wblocks) {
+  __shared__ float4 red[3][64];
+  const IGemmArgs& g = wa.g;
+  const long long zs = (long long)wa.npad * wa.kpad;
+  if ((int)blockIdx.x < wblocks) {
+    const int l64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int kq = g.K >> 2;                                       // float4 groups per row
+    const long long q = (long long)blockIdx.x * 64 + l64;
+    const int n = (int)(q / kq), k = (int)(q - (long long)n * kq) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < g.N) {
+      const float* p = wa.part + (long long)n * wa.kpad + k;
+#pragma unroll 4
+      for (int z = grp; z < nsplit; z += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + z * zs);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    if (grp > 0) red[grp - 1][l64] = acc;
+    __syncthreads();
+    if (grp != 0 || n >= g.N) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float4 v = red[r][l64];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    wgrad_reduce_put(wa, n, k, acc.x);
+    wgrad_reduce_put(wa, n, k + 1, acc.y);
+    wgrad_reduce_put(wa, n, k + 2, acc.z);
+    wgrad_reduce_put(wa, n, k + 3, acc.w);
+    return;
+  }
+  const int n = ((int)blockIdx.x - wblocks) * 256 + (int)threadIdx.x;
+  if (n >= g.N) return;
+  float v = 0.f;
+#pragma unroll 4
+  for (int z = 0; z < nsplit; ++z) v += wa.bpart[(long long)z * wa.npad + n];
+  if (wa.nseg_w > 1) {
     const int nper = g.N / wa.nseg_w, seg = n / nper;
     if (wa.dbseg[seg]) wa.dbseg[seg][n - seg * nper] += v;
   } else if (wa.db && n < (wa.t_co ? wa.t_co : g.N)) {
@@ -653,8 +663,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
 }
 
 int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st) {
-  const long long total = (long long)wa.g.N * wa.g.K + wa.g.N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, wa, nsplit);
+  if (wa.g.K % 4 || wa.kpad % 4) return LTU_E_SHAPE;
+  const int wblocks = (int)(((long long)wa.g.N * (wa.g.K / 4) + 63) / 64);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + (wa.g.N + 255) / 256)), dim3(256), 0, st, wa, nsplit, wblocks);
   return ltu_check_launch();
 }
 
@@ -678,9 +689,6 @@ int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   if (g.N > 64) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, wa);
   else if (g.N > 32) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, 4, 2, 1>), grid, dim3(256), 0, st, wa);
   else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, 4, 1, 1>), grid, dim3(256), 0, st, wa);
-  if (wa.part != nullptr) {
-    const long long total = (long long)g.N * g.K + g.N;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, wa, t.nsplit);
-  }
+  if (wa.part != nullptr) return launch_wgrad_reduce(wa, t.nsplit, st);
   return ltu_check_launch();
 }

@@ -104,6 +104,21 @@ __device__ __forceinline__ void weight_prep_range(const WPrep& d, unsigned t0, u
       }
       st1<TW>(dst + i, v);
     }
+  } else if (d.kind == 8 || d.kind == 9) {
+    // MFMA fragment order of a dense weight for the row-block chain kernels (tlayer.hip): the 16 bytes lane l of a wave feeds to
+    // v_mfma_f32_32x32x16_bf16 for output tile ct (32 outputs) and reduction step ks (16 terms) sit at ((ct * KS + ks) * 64 + l) * 8,
+    // so a wave's operand is one coalesced 1 KiB load.  kind 8: outputs = rows of src [R][C] (forward: y = x W^T);
+    // kind 9: outputs = columns of src (data gradient: dx = g W), reduction over its rows.
+    const unsigned n = (unsigned)d.R * (unsigned)d.C;
+    if (t1 > n) t1 = n;
+    const unsigned KS = (d.kind == 8 ? (unsigned)d.C : (unsigned)d.R) >> 4;
+    for (unsigned i = t0; i < t1; i += stride) {
+      const unsigned j = i & 7u, l = (i >> 3) & 63u, t = i >> 9;
+      const unsigned ks = t % KS, ct = t / KS;
+      const unsigned o = ct * 32u + (l & 31u), r = ks * 16u + 8u * (l >> 5) + j;
+      const float v = d.kind == 8 ? d.src[(size_t)o * d.C + r] : d.src[(size_t)r * d.C + o];
+      st1<TW>(dst + i, v);
+    }
   } else if (d.kind == 7) {
     // pack wd of one member of a fused conv group: columns [off, off+cnt) of dst [CiP][27][stride]; pad = off << 16 | cnt
     const unsigned stride_c = (unsigned)d.p0, CiP = (unsigned)d.p1, off = (unsigned)d.pad >> 16, cnt = (unsigned)d.pad & 0xffffu;

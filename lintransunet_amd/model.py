@@ -112,7 +112,7 @@ class _WeightStore:
         self.raw.append((conv_a, conv_b, n1, wf, wd, bias))
         self.pair[key] = ops.PairPrep(wf, wd, bias, Ca, n1)
 
-    def add_linear(self, key, weights, group=None):
+    def add_linear(self, key, weights, group=None, frag=False):
         """weights: list of [N,K(,1,1,1)] parameters sharing K (a fused q,k,v group or a single projection)"""
         N, K = weights[0].shape[0], weights[0].shape[1]
         if self.dtype == torch.float32:
@@ -126,7 +126,12 @@ class _WeightStore:
         wt = torch.empty((K, N * len(weights)), device=self.device, dtype=self.dtype)
         for i, w in enumerate(weights):
             self.recs.append((w, wt, 1, N, K, N * len(weights), i * N))
-        self.lin[key] = ops.LinPrep(fw, wt, group)
+        fr = None
+        if frag and self.dtype == torch.bfloat16 and N % 32 == 0 and K % 16 == 0:
+            fr = torch.empty(N * len(weights) * K, device=self.device, dtype=self.dtype)     # MFMA fragment order (kind 8)
+            for i, w in enumerate(weights):
+                self.recs.append((w, fr[i * N * K:(i + 1) * N * K], 8, N, K, 0, 0))
+        self.lin[key] = ops.LinPrep(fw, wt, group, fr)
 
     def finalize(self):
         import numpy as np
@@ -143,7 +148,7 @@ class _WeightStore:
         # work list: (record, chunk) pairs of WPREP_CHUNK destination elements, one workgroup each
         chunks = []
         for i, (_, _, kind, R, C, p0, p1, pad) in enumerate(rows):
-            if kind in (0, 1, 4):
+            if kind in (0, 1, 4, 8, 9):
                 n = R * C
             elif kind in (2, 3):
                 n = p0 * 27 * p1
@@ -264,9 +269,9 @@ class MaskTransUnet(nn.Module):
                 lin = lay.self_attn.linears
                 # weight gradients of a layer's projections go out as one group, launched by the qkv backward (the layer's last)
                 st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight], group='flush')
-                st.add_linear((id(lay), 'o'), [lin[3].weight], group='collect')
-                st.add_linear((id(lay), 'f1'), [lay.linear1.weight], group='collect')
-                st.add_linear((id(lay), 'f2'), [lay.linear2.weight], group='collect')
+                st.add_linear((id(lay), 'o'), [lin[3].weight], group='collect', frag=True)
+                st.add_linear((id(lay), 'f1'), [lay.linear1.weight], group='collect', frag=True)
+                st.add_linear((id(lay), 'f2'), [lay.linear2.weight], group='collect', frag=True)
         st.finalize()
         self._store = st
         return st
@@ -286,6 +291,15 @@ class MaskTransUnet(nn.Module):
         qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
                          prep=wl[(id(lay), 'qkv')])
         a = ops.linear_attention(qkv, B, N, d)
+        po, p1, p2 = wl[(id(lay), 'o')], wl[(id(lay), 'f1')], wl[(id(lay), 'f2')]
+        if (po is not None and po.frag is not None and d in (128, 256) and B * N <= ops.TAIL_MAX_TOKENS and B * N >= 64
+                and ops.USE_LAYER_TAIL):
+            # small token levels: the rest of the layer as one launch (csrc/tlayer.hip)
+            s1, sg, s2 = ((seeds.next(), seeds.next(), seeds.next()) if p > 0 else (0, 0, 0))
+            out = ops.layer_tail(a, tres, (lin[3].weight, lin[3].bias, lay.linear1.weight, lay.linear1.bias, lay.linear2.weight,
+                                           lay.linear2.bias, lay.layer_norm1.weight, lay.layer_norm1.bias, lay.layer_norm2.weight,
+                                           lay.layer_norm2.bias), (po, p1, p2), 1e-6, p, (s1, sg, s2), fork=not last)
+            return out if not last else (out, out)
         a = ops.linear(a, [lin[3].weight], [lin[3].bias], prep=wl[(id(lay), 'o')])
         t, tres = ops.res_layernorm(tres, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0,
                                     fork=True)

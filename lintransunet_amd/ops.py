@@ -369,10 +369,11 @@ class LinPrep:
     group: None = the weight gradient is launched by the op's backward; 'collect' = handed to the context's weight-gradient group
     (a transformer layer's out / ffn projections); 'flush' = handed in and the group launched (the layer's qkv projection, whose
     backward is the last of the layer)."""
-    __slots__ = ('w', 'wt', 'group')
+    __slots__ = ('w', 'wt', 'group', 'frag')
 
-    def __init__(self, w, wt, group=None):
+    def __init__(self, w, wt, group=None, frag=None):
         self.w, self.wt, self.group = w, wt, group
+        self.frag = frag          # cat(W) in MFMA fragment order (weight-prep kind 8) for the row-block chain kernels, or None
 
 
 # ---------------------------------------------------------------------------------------------- no-grad helpers
@@ -915,6 +916,104 @@ class _GeluDropout(torch.autograd.Function):
 
 def gelu_dropout(u, p=0.0, seed=0):
     return _GeluDropout.apply(u, p, seed)
+
+
+# ---------------------------------------------------------------------------------------------- transformer layer tail
+# the row-block chain kernel wins at every token level of the 128^3 step (micro-benchmark tools/bench_tail.py: 20 / 35 / 58 / 120 us
+# against 27 / 51 / 72 / 130 us for the five launches at 1 024 / 8 640 / 21 504 / 114 816 tokens); LTU_TAIL_MAX_TOKENS caps it
+USE_LAYER_TAIL = _os.environ.get('LTU_NO_LAYER_TAIL', '') == ''
+TAIL_MAX_TOKENS = int(_os.environ.get('LTU_TAIL_MAX_TOKENS', '1000000000'))      # the row-block chain kernel serves the small token levels (measured; the 115 k-token level keeps the
+                             # streaming ring kernels, which are bandwidth- rather than latency-bound)
+
+
+def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):
+    """weight / bias gradients of y = x W^T + b given g = dL/dy: into the layer's group when the gradients are fused buffers,
+    otherwise computed here; returns the values autograd expects (None for fused buffers)"""
+    gw = [_grad_buf(w) for w in ws]
+    gb = [_grad_buf(b) for b in bs]
+    dws, dbs = [t for t, _ in gw], [t for t, _ in gb]
+    if GROUP_WGRAD and lc.wg_branch is None and all(f for _, f in gw) and all(f for _, f in gb):
+        lc.wgrad_group_push(g, x, dws, dbs, M, N, K, False)
+    else:
+        _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(ws), M, N, K,
+                  _p(_wgrad_ws(M, N, K, x)), 0, _dt(x), _s())
+    return [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)], [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
+
+
+class _LayerTail(torch.autograd.Function):
+    """the post-attention half of a transformer layer (model/trans_block.py:203-211) as one launch (csrc/tlayer.hip):
+    y = LN2(t1 + drop(W2 drop(gelu(W1 t1)))),  t1 = LN1(x + drop(Wo a)).  Backward: the op-by-op kernels on the saved tensors."""
+
+    @staticmethod
+    def forward(ctx, a, x, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, preps, eps, p, seeds, fork):
+        lc = ctx.lc = current()
+        _chk(a, 'a'); _chk(x, 'x')
+        M, d = a.shape
+        dev, dt = a.device, a.dtype
+        po, p1, p2 = preps
+        z1, t1, z2, y = (torch.empty((M, d), device=dev, dtype=dt) for _ in range(4))
+        u, h = (torch.empty((M, 2 * d), device=dev, dtype=dt) for _ in range(2))
+        stat1, stat2 = (torch.empty((M, 2), device=dev, dtype=torch.float32) for _ in range(2))
+        _lib.call('ltu_layer_tail_fwd', _p(a), _p(x), _p(po.frag), _p(p1.frag), _p(p2.frag), _p(bo), _p(b1), _p(b2), _p(g1), _p(be1),
+                  _p(g2), _p(be2), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(stat1), _p(stat2), M, d, float(eps), float(p),
+                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), _dt(a), _s())
+        ctx.save_for_backward(a, z1, stat1, t1, u, h, z2, stat2)
+        ctx.params = (wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
+        ctx.cfg = (preps, p, seeds)
+        return (y, y.view_as(y)) if fork else y
+
+    @staticmethod
+    def backward(ctx, g, g2=None):
+        lc = ctx.lc
+        a, z1, stat1, t1, u, h, z2, stat2 = ctx.saved_tensors
+        wo, bo, w1, b1, w2, b2, gm1, be1, gm2, be2 = ctx.params
+        (po, p1, p2), p, seeds = ctx.cfg
+        if g is None:
+            g, g2 = g2, None
+        g = g.contiguous()
+        if g2 is not None:
+            g2 = g2.contiguous()
+        M, d = a.shape
+        dev, dt = a.device, _dt(a)
+
+        def ln_bwd(gy, gy2, z, stat, gamma, beta, seed):
+            dz = torch.empty_like(z)
+            dr = torch.empty_like(z) if p > 0 else dz
+            dg, fg = _grad_buf(gamma)
+            db, fb = _grad_buf(beta)
+            job, ws = None, lc.norm_ws(dev)
+            if fg and fb:
+                job = _defer_job()
+                ws = torch.empty(2048 * 2 * d, device=dev, dtype=torch.float32)
+            _lib.call('ltu_layernorm_bwd', _p(gy), _p(gy2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(ws),
+                      ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, lc.step_ptr(), dt, _s())
+            if job is not None:
+                lc.defer_push(job, ws)
+            return dz, dr, _grad_done(gamma, dg, fg), _grad_done(beta, db, fb)
+
+        def dgrad(gy, prep, w, N, K):        # gy [M,N] . W [N,K] -> [M,K]
+            wt = prep.wt if prep is not None else _w_transposed([w], N, K, a.dtype)
+            dx = torch.empty((M, K), device=dev, dtype=a.dtype)
+            _lib.call('ltu_linear_fwd', _p(gy), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
+            return dx
+
+        dz2, dr2, dgm2, dbe2 = ln_bwd(g, g2, z2, stat2, gm2, be2, seeds[2])
+        dh = dgrad(dr2, p2, w2, d, 2 * d)
+        (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)
+        du = torch.empty_like(u)
+        _lib.call('ltu_gelu_dropout_bwd', _p(dh), _p(u), _p(du), u.numel(), float(p), seeds[1], lc.step_ptr(), dt, _s())
+        dt1 = dgrad(du, p1, w1, 2 * d, d)
+        (dw1,), (db1,) = _wgrad_now_or_group(lc, du, t1, [w1], [b1], M, 2 * d, d)
+        dz1, dr1, dgm1, dbe1 = ln_bwd(dt1, dz2, z1, stat1, gm1, be1, seeds[0])
+        da = dgrad(dr1, po, wo, d, d)
+        (dwo,), (dbo,) = _wgrad_now_or_group(lc, dr1, a, [wo], [bo], M, d, d)
+        return da, dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None
+
+
+def layer_tail(a, x, lay_params, preps, eps, p, seeds, fork):
+    """a: attention output [M,d], x: layer input [M,d]; lay_params = (Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2);
+    preps = LinPrep of (out, linear1, linear2) with fragment-ordered operands; seeds = dropout sites (LN1, GELU, LN2)"""
+    return _LayerTail.apply(a, x, *lay_params, preps, eps, p, tuple(seeds), fork)
 
 
 # ---------------------------------------------------------------------------------------------- linear attention

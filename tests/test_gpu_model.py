@@ -368,6 +368,56 @@ def ops_use_default():
     return ops.use(ctx)
 
 
+@pytest.mark.parametrize('dropout', [0.0, 0.3])
+def test_layer_tail_matches_op_by_op(dropout):
+    """the row-block chain kernel (csrc/tlayer.hip: out projection, LayerNorm, FFN, LayerNorm of a transformer layer in one launch,
+    used on the small token levels) against the op-by-op path on the same weights, inputs and dropout masks: the full channel
+    configuration at 32^3 x 2 runs it at d = 128 (28 704 tokens) and d = 256 (5 376 / 2 160 tokens).
+    Yardstick: this random-weight network amplifies bf16 rounding noise, so both bf16 paths sit ~0.15 (relative L2 of the whole
+    gradient) away from the fp32-storage run with the same masks; the two paths must agree far better than that."""
+    from lintransunet_amd import train, ops
+    cfg = O_net.NetConfig()
+    x = seedgen.seeded_volume((2, 1, 32, 32, 32), 81).to(DEV)
+    label = seedgen.seeded_label((2, 1, 32, 32, 32), 82).to(DEV)
+    w = O_step.dynamic_weights(0)
+    calls = {'n': 0}
+    orig = ops._LayerTail.forward
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+
+    def run(dtype, tail):
+        ops.USE_LAYER_TAIL = tail
+        torch.manual_seed(99)
+        m = build(cfg, 300, dtype, dropout=dropout)
+        t, _ = train.train_step(m, x, label, w)
+        torch.cuda.synchronize()
+        return (sum(v.item() for v in t), {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None and not exact_zero_grad(k)},
+                [b.clone() for b in m.last_boxes])
+
+    def dist(a, b):
+        num = sum(((a[k] - b[k]) ** 2).sum().item() for k in b) ** 0.5
+        return num / sum((b[k] ** 2).sum().item() for k in b) ** 0.5
+
+    ops._LayerTail.forward = staticmethod(counting)
+    try:
+        la, ga, ba = run(torch.bfloat16, True)
+        assert calls['n'] == 24                 # 3 ROI transformers x 8 layers (the 16-token bottleneck keeps the op-by-op path)
+        lb, gb, bb = run(torch.bfloat16, False)
+        assert calls['n'] == 24
+        lf, gf, bf_ = run(torch.float32, False)
+    finally:
+        ops.USE_LAYER_TAIL = True
+        ops._LayerTail.forward = staticmethod(orig)
+    assert all(torch.equal(p, q) for p, q in zip(ba, bb))
+    assert abs(la - lb) <= 2e-4 * abs(lb), (la, lb)
+    d_paths, d_ref = dist(ga, gb), dist(gb, gf)
+    print(f'[layer tail, dropout {dropout}] loss {la:.6f} vs {lb:.6f} (fp32 {lf:.6f}); gradient rel-L2 chain vs op-by-op {d_paths:.2e}, '
+          f'op-by-op vs fp32 storage {d_ref:.2e}, chain vs fp32 storage {dist(ga, gf):.2e}')
+    assert d_paths <= 0.3 * d_ref and abs(dist(ga, gf) - d_ref) <= 0.1 * d_ref
+
+
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
