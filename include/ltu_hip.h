@@ -286,8 +286,10 @@ int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W
 
 /* ---- deep-supervision losses of one level: loss/criterions.py:35-70,416-442,696-735;
  *      loss/multi_criterions.py:58-110,594-615 ------------------------------------------------------
- * p f32 [B][S][C] probabilities, label u8 [B][S].  total = w_ce*CE + w_bal*BalancedDice + sum_c w_dice[c]*Dice_c.
- * values[0] = total, [1] = CE, [2] = balanced Dice, [3+c] = Dice_c;  sums [B][C][4] zero-filled scratch;
+ * p f32 [B][S][C] probabilities, label u8 [B][S].  total = w_ce*CE + w_bal*BalancedDice + sum_c w_dice[c]*Dice_c
+ * + w_dice[4]*Dice of the foreground union (1 - p_0 vs label != 0: multi_criterions.py:30-56, DiceClassLoss0); w_dice: 5 host floats.
+ * values (9 floats): [0] = total, [1] = CE, [2] = balanced Dice, [3+c] = Dice_c, [7] = union Dice, [8] = total again;
+ * sums [B][C][4] zero-filled scratch;
  * coef [B][C][3] feeds ltu_loss_bwd: dp = gscale[0] * dTotal/dp.  scale_dev (nullable): device-resident factor on all three
  * weights, read at run time (the per-epoch level weight of train3D.py:122-137 divided by the accumulation count of
  * utils/utils_3D_embed_full.py:85, so a captured graph follows both without re-capture). */

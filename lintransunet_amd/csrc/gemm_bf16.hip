@@ -615,20 +615,25 @@ __device__ __forceinline__ void wgrad_reduce_put(const WGradArgs& wa, int n, int
     wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
   }
 }
+// SG = thread groups that share the splits of one output quad (256 / SG quads per workgroup): 4 for large gradients, 16 for the
+// small ones with hundreds of splits (conv weights of the first levels: a few thousand elements), which would otherwise be a
+// grid of a few dozen workgroups walking long serial loops.
+template <int SG>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, int nsplit, int wblocks) {
-  __shared__ float4 red[3][64];
+  constexpr int NQ = 256 / SG;
+  __shared__ float4 red[SG - 1][NQ];
   const IGemmArgs& g = wa.g;
   const long long zs = (long long)wa.npad * wa.kpad;
   if ((int)blockIdx.x < wblocks) {
-    const int l64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int l64 = threadIdx.x % NQ, grp = threadIdx.x / NQ;
     const int kq = g.K >> 2;                                       // float4 groups per row
-    const long long q = (long long)blockIdx.x * 64 + l64;
+    const long long q = (long long)blockIdx.x * NQ + l64;
     const int n = (int)(q / kq), k = (int)(q - (long long)n * kq) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < g.N) {
       const float* p = wa.part + (long long)n * wa.kpad + k;
 #pragma unroll 4
-      for (int z = grp; z < nsplit; z += 4) {
+      for (int z = grp; z < nsplit; z += SG) {
         const float4 v = *reinterpret_cast<const float4*>(p + z * zs);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
@@ -637,7 +642,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
     __syncthreads();
     if (grp != 0 || n >= g.N) return;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < SG - 1; ++r) {
       const float4 v = red[r][l64];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -664,8 +669,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
 
 int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st) {
   if (wa.g.K % 4 || wa.kpad % 4) return LTU_E_SHAPE;
-  const int wblocks = (int)(((long long)wa.g.N * (wa.g.K / 4) + 63) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + (wa.g.N + 255) / 256)), dim3(256), 0, st, wa, nsplit, wblocks);
+  const long long quads = (long long)wa.g.N * (wa.g.K / 4);
+  if (quads < 256 * 64 && nsplit >= 32) {
+    const int wblocks = (int)((quads + 15) / 16);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)(wblocks + (wa.g.N + 255) / 256)), dim3(256), 0, st, wa, nsplit, wblocks);
+  } else {
+    const int wblocks = (int)((quads + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(wblocks + (wa.g.N + 255) / 256)), dim3(256), 0, st, wa, nsplit, wblocks);
+  }
   return ltu_check_launch();
 }
 

@@ -72,7 +72,8 @@ __global__ void vote_finalize_kernel(const float* __restrict__ votes, const floa
   }
 }
 
-// rows [B][3][H]: per h the sums over (W, D) of p, t and p*t, with p = [pred[b][ci] >= thr] and t = target (0/1)
+// rows [B][3][H]: per h the sums over (W, D) of p, t and p*t, with p = [pred[b][ci] >= thr] (thr < 0: p = pred[b][ci] itself,
+// the un-thresholded probabilities the evaluation losses of train3D.py:143 see) and t = target (0/1)
 __global__ void __launch_bounds__(256) seg_row_sums_kernel(const float* __restrict__ pred, const uint8_t* __restrict__ target,
                                                            float* __restrict__ rows, int C, int ci, int H, long long WD, float thr) {
   __shared__ float red[3][256];
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(256) seg_row_sums_kernel(const float* __restri
   const uint8_t* t = target + ((long long)b * H + hh) * WD;
   float sp = 0.f, st = 0.f, spt = 0.f;
   for (long long i = threadIdx.x; i < WD; i += 256) {
-    const float pv = p[i] >= thr ? 1.f : 0.f, tv = (float)t[i];
+    const float pv = thr < 0.f ? p[i] : (p[i] >= thr ? 1.f : 0.f), tv = (float)t[i];
     sp += pv; st += tv; spt += pv * tv;
   }
   red[0][threadIdx.x] = sp; red[1][threadIdx.x] = st; red[2][threadIdx.x] = spt;

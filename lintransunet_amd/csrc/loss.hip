@@ -58,9 +58,10 @@ __global__ void loss_sums_kernel(const float* __restrict__ p, const uint8_t* __r
 }
 
 // weights: w_ce, w_bal, w_dice[c] (standard per-class Dice on class c).  values out: [0]=total, [1]=ce, [2]=bal,
-// [3+c]=dice_c.  coef [B][C][3] = alpha, beta, gamma (already multiplied by the loss weights).
+// [3+c]=dice_c, [7]=foreground-union dice, [8]=total again.  coef [B][C][3] = alpha, beta, gamma (already multiplied by the loss weights).
 struct LossCfg {
   float w_ce, w_bal, w_dice[LOSS_MAXC];
+  float w_fg;          // Dice of the foreground union, p' = 1 - p_0 against t' = 1 - t_0 (loss/multi_criterions.py:30-56, DiceClassLoss0)
 };
 
 // scale_dev (nullable): a device-resident factor applied to all loss weights of this level (the per-epoch deep-supervision weight
@@ -70,9 +71,10 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (scale_dev != nullptr) {
     const float sc = scale_dev[0];
-    cfg.w_ce *= sc; cfg.w_bal *= sc;
+    cfg.w_ce *= sc; cfg.w_bal *= sc; cfg.w_fg *= sc;
     for (int c = 0; c < LOSS_MAXC; ++c) cfg.w_dice[c] *= sc;
   }
+  float fg = 0.f;
   float ce = 0.f, bal = 0.f, dice[LOSS_MAXC] = {0.f, 0.f, 0.f, 0.f};
   const float Z = (float)B * (float)S * (float)C;
   for (int b = 0; b < B; ++b) {
@@ -105,6 +107,15 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
       // balanced Dice
       alpha += cfg.w_bal * Nb * wc[c] / ((float)B * Db * Db);
       beta += -cfg.w_bal * 2.f * wc[c] / ((float)B * Db);
+      if (c == 0) {
+        // foreground union: P' = S - P, T' = S - T, I' = S - P - T + I;  L = 1 - (1/B) N'/D', N' = 2 I' + eps, D' = P' + T' + eps
+        //   dL/dp_0 = (1/B) (2 (1 - t_0) / D' - N' / D'^2)
+        const float Sf = (float)S;
+        const float Nf = 2.f * (Sf - P - T + I) + 1e-9f, Df = (Sf - P) + (Sf - T) + 1e-9f;
+        fg += Nf / Df;
+        alpha += cfg.w_fg * (2.f / Df - Nf / (Df * Df)) / (float)B;
+        beta += -cfg.w_fg * 2.f / ((float)B * Df);
+      }
       float* o = coef + ((long long)b * C + c) * 3;
       o[0] = alpha; o[1] = beta; o[2] = gamma;
     }
@@ -119,7 +130,11 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
     values[3 + c] = dv;
     total += cfg.w_dice[c] * dv;
   }
+  const float fgv = 1.f - fg / (float)B;
+  values[7] = fgv;
+  total += cfg.w_fg * fgv;
   values[0] = total;
+  values[8] = total;      // a second copy: the autograd wrapper exposes [8] as the differentiable scalar and [0..7] as the report
 }
 
 // dp[s,c] = gscale * (alpha + t (beta + gamma f'(p)))
@@ -153,6 +168,7 @@ extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, f
   LossCfg cfg;
   cfg.w_ce = w_ce; cfg.w_bal = w_bal;
   for (int c = 0; c < LOSS_MAXC; ++c) cfg.w_dice[c] = (c < C && w_dice) ? w_dice[c] : 0.f;
+  cfg.w_fg = w_dice ? w_dice[LOSS_MAXC] : 0.f;
   hipLaunchKernelGGL(loss_sums_kernel, dim3(cdiv(S, rows), B), dim3(256), 0, (hipStream_t)s, p, label, sums, S, C, (int)rows);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, sums, values, coef, B, S, C, cfg, scale_dev);
   return ltu_check_launch();

@@ -32,10 +32,10 @@ class LevelCriterion(nn.Module):
     """Weighted sum of CE / balanced Dice / per-class Dice on one prediction, one kernel pass.
 
     spec: {'CrossEntroLoss': w, 'BalanceDiceLoss': w, 'DiceClassLoss': w (class 1), 'DiceClassLoss2': w (class 2),
-           'DiceClassLoss0c': w (class 0)}.  Returns (total, {name: w * value}) with values detached: what the reference
+           'DiceClassLoss0c': w (class 0), 'DiceClassLoss0': w (foreground union 1 - class 0, multi_criterions.py:30-56)}.  Returns (total, {name: w * value}) with values detached: what the reference
     scripts log (`criterions_w * l(...)`, utils_3D_multi_class.py:85; all weights are 1 in the single-class script).
     """
-    _DICE = {'DiceClassLoss': 1, 'DiceClassLoss2': 2, 'DiceClassLoss0c': 0}
+    _DICE = {'DiceClassLoss': 1, 'DiceClassLoss2': 2, 'DiceClassLoss0c': 0, 'DiceClassLoss0': 4}      # 4 = foreground union
 
     def __init__(self, spec: dict, scale: float = 1.0, scale_dev=None):
         super().__init__()
@@ -51,7 +51,7 @@ class LevelCriterion(nn.Module):
         C = p.shape[-1]
         lab = _labels(target, C)
         sc = self.scale
-        wd = [0.0] * 4
+        wd = [0.0] * 5
         for name, cls in self._DICE.items():
             if name in self.spec:
                 wd[cls] += self.spec[name] * sc
@@ -100,11 +100,47 @@ class BalanceDiceLoss(_Single):
     NAME = 'BalanceDiceLoss'
 
 
+class DiceClassLoss0(_Single):
+    """loss/multi_criterions.py:30-56: Dice of the foreground union (1 - class 0 on both sides)"""
+    NAME = 'DiceClassLoss0'
+
+
+class _EvalMetric(nn.Module):
+    """the evaluation losses train3D.py:143 requests besides the Dice losses (`eval_list`): computed on the un-thresholded class
+    probabilities by the metric kernels of the inference driver (csrc/infer.hip); evaluation only, no gradient"""
+    INDEX, COMPLEMENT = 0, False
+
+    def forward(self, predict, target):
+        from . import infer
+        with torch.no_grad():
+            v = infer.evaluate(predict, target, threshold=-1.0)[infer.METRIC_NAMES[self.INDEX]]
+        return 1.0 - v if self.COMPLEMENT else v
+
+
+class RecallLoss(_EvalMetric):
+    """loss/criterions.py:314-345: 1 - mean_b (sum p t + 1e-5) / (sum t + 1e-5)"""
+    INDEX, COMPLEMENT = 1, True
+
+
+class PrecisionLoss(_EvalMetric):
+    """loss/criterions.py:382-413: 1 - mean_b (sum p t + 1e-5) / (sum p + 1e-5)"""
+    INDEX, COMPLEMENT = 2, True
+
+
+class LocalizationLoss(_EvalMetric):
+    """loss/criterions.py:179-241 (as written there: all three "axes" reduce to the H profile)"""
+    INDEX = 3
+
+
 Loss_Dict = {
     'CrossEntroLoss': CrossEntroLoss,
     'DiceClassLoss': DiceClassLoss,
+    'DiceClassLoss0': DiceClassLoss0,
     'DiceClassLoss2': DiceClassLoss2,
     'BalanceDiceLoss': BalanceDiceLoss,
+    'RecallLoss': RecallLoss,
+    'PrecisionLoss': PrecisionLoss,
+    'LocalizationLoss': LocalizationLoss,
 }
 
 

@@ -1305,13 +1305,15 @@ class _LevelLoss(torch.autograd.Function):
         S = p.numel() // (B * C)
         dev = p.device
         sums = lc.scratch_zeros((B, C, 4), dev)
-        values = torch.empty(8, device=dev, dtype=torch.float32)
-        coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
-        wd = (ctypes.c_float * 4)(*[float(w_dice[c]) if c < len(w_dice) else 0.0 for c in range(4)])
+        buf = torch.empty(9, device=dev, dtype=torch.float32)
+        values = buf[:8]                 # the report (non-differentiable); buf[8] repeats the total as the differentiable output, so
+        coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)          # no copy kernel is needed to separate the two
+        wd = (ctypes.c_float * 5)(*[float(w_dice[c]) if c < len(w_dice) else 0.0 for c in range(5)])
         _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _p(scale_dev), _s())
         ctx.save_for_backward(p, label, coef)
         ctx.mark_non_differentiable(values)
-        return values[0].clone(), values
+        ctx.set_materialize_grads(False)         # no zero-filled gradient tensor for the report output
+        return buf[8], values
 
     @staticmethod
     def backward(ctx, g, _gv):
@@ -1319,6 +1321,8 @@ class _LevelLoss(torch.autograd.Function):
         p, label, coef = ctx.saved_tensors
         B, C = p.shape[0], p.shape[-1]
         S = p.numel() // (B * C)
+        if g is None:
+            return None, None, None, None, None, None
         g = g.contiguous().to(torch.float32)
         dp = torch.empty_like(p)
         _lib.call('ltu_loss_bwd', _p(p), _p(label), _p(coef), _p(g), _p(dp), B, S, C, _s())
@@ -1326,6 +1330,7 @@ class _LevelLoss(torch.autograd.Function):
 
 
 def level_loss(p, label, w_ce=0.0, w_bal=0.0, w_dice=(), scale_dev=None):
-    """p fp32 [B,...,C] channels-last probabilities, label uint8 [B,...]: weighted CE + balanced Dice + per-class Dice.
+    """p fp32 [B,...,C] channels-last probabilities, label uint8 [B,...]: weighted CE + balanced Dice + per-class Dice
+    (w_dice[c], c < 4) + Dice of the foreground union (w_dice[4]).
     scale_dev: optional 1-element fp32 device tensor multiplying all weights at run time."""
     return _LevelLoss.apply(p, label, w_ce, w_bal, tuple(w_dice), scale_dev)

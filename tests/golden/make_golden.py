@@ -177,6 +177,15 @@ def fx_losses():
                 v.backward()
                 close(my_fn(p.detach(), lab), v, name)
                 out[f'c2_{name}'], out[f'c2_{name}_dp'] = np32(v), np32(p.grad)
+            # the evaluation losses of train3D.py:143 (eval_list) on the same un-thresholded probabilities
+            with torch.no_grad():
+                ev = {'RecallLoss': R_loss.RecallLoss()(p, lab), 'PrecisionLoss': R_loss.PrecisionLoss()(p, lab),
+                      'LocalizationLoss': R_loss.LocalizationLoss()(p, lab.float())}
+                close(1 - O_infer.recall(p, lab), ev['RecallLoss'], 'RecallLoss')
+                close(1 - O_infer.precision(p, lab), ev['PrecisionLoss'], 'PrecisionLoss')
+                close(O_infer.localization_loss(p, lab.float()), ev['LocalizationLoss'], 'LocalizationLoss')
+            for name, v in ev.items():
+                out[f'c2_{name}'] = np32(v)
         else:
             onehot = torch.nn.functional.one_hot(lab[:, 0], C).permute(0, 4, 1, 2, 3).contiguous()
             pairs = [('CrossEntroLoss', R_mloss.CrossEntroLoss(), lambda a, t: O_loss.weighted_ce(a, None, onehot=t)),
@@ -486,6 +495,9 @@ def main():
         fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)
         fx_model('full96', O_net.NetConfig(), (96, 96, 96), 2, 600, full_arrays=False)
         fx_model('win512', O_net.NetConfig(), (512, 512, 32), 1, 800, full_arrays=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'losses':
+        fx_losses()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'heldout':      # needs gpurun_out/heldout_small.pt (tools/train_heldout.py on the GPU box)
         fx_heldout()

@@ -706,7 +706,7 @@ def test_losses_golden(ops, golden_dir):
         assert rel_err(from_cl(pd.grad), torch.from_numpy(Gd[f'c2_{name}_dp'])) < 1e-4, name
     p3 = torch.from_numpy(Gd['c3_p'])
     lab3 = torch.from_numpy(Gd['c3_lab'])
-    for name in ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'):
+    for name in ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2', 'DiceClassLoss0'):
         pd = to_cl(p3).requires_grad_(True)
         v = L.get_criterions([name])[name](pd.permute(0, 4, 1, 2, 3), lab3.to(DEV))
         v.backward()
@@ -717,6 +717,17 @@ def test_losses_golden(ops, golden_dir):
     tot, named = L.LevelCriterion({'CrossEntroLoss': 1.0, 'BalanceDiceLoss': 1.0}, scale=0.4)(pd.permute(0, 4, 1, 2, 3), lab.to(DEV))
     want = 0.4 * (float(Gd['c2_CrossEntroLoss']) + float(Gd['c2_BalanceDiceLoss']))
     assert abs(tot.item() - want) < 1e-5
+    # a device-resident run-time scale multiplies the same total and gradient (captured graphs follow per-epoch level weights)
+    pd2 = to_cl(p).requires_grad_(True)
+    sc = torch.tensor([0.4], device=DEV)
+    tot2, _ = L.LevelCriterion({'CrossEntroLoss': 1.0, 'BalanceDiceLoss': 1.0}, scale_dev=sc)(pd2.permute(0, 4, 1, 2, 3), lab.to(DEV))
+    tot.backward(); tot2.backward()
+    assert abs(tot2.item() - want) < 1e-5 and rel_err(pd2.grad, pd.grad) < 1e-6
+    # the evaluation losses train3D.py:143 asks get_criterions for (eval_list), on un-thresholded probabilities
+    ev = L.get_criterions(['BalanceDiceLoss', 'DiceClassLoss', 'RecallLoss', 'PrecisionLoss', 'LocalizationLoss'])
+    for name in ('RecallLoss', 'PrecisionLoss', 'LocalizationLoss'):
+        v = ev[name](to_cl(p).permute(0, 4, 1, 2, 3), lab.to(DEV))
+        assert abs(v.item() - float(Gd[f'c2_{name}'])) < 1e-5 * max(1.0, abs(float(Gd[f'c2_{name}']))), name
 
 
 def test_label_pyramid(ops):

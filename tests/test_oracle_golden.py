@@ -81,6 +81,12 @@ def test_losses(golden_dir):
     _close(v.detach(), G['c3_CrossEntroLoss'])
     _close(p.grad, G['c3_CrossEntroLoss_dp'])
     _close(O_loss.dice_class_onehot(p.detach(), onehot, 2), G['c3_DiceClassLoss2'])
+    _close(O_loss.dice_class0_onehot(p.detach(), onehot), G['c3_DiceClassLoss0'])
+    from oracle import infer as O_infer
+    p2, lab2 = torch.from_numpy(G['c2_p']), torch.from_numpy(G['c2_lab']).long()
+    _close(1 - O_infer.recall(p2, lab2), G['c2_RecallLoss'])
+    _close(1 - O_infer.precision(p2, lab2), G['c2_PrecisionLoss'])
+    _close(O_infer.localization_loss(p2, lab2.float()), G['c2_LocalizationLoss'])
 
 
 def _run_model(cfg, size, batch, wseed):
