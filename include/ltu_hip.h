@@ -213,9 +213,11 @@ long long ltu_norm_ws_floats(void);
 int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s);
 int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C, int act,
                        float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
-/* dx from dy; bsums [B][C][2] zero-filled scratch */
-int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, float* ws, void* dx, int B, long long S, int C,
-                     int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+/* dx from dy (+ dy2 + dy3, nullable: the gradients of further consumers of y, summed on load instead of by a stand-alone add pass:
+ * the skip tensors of the U-Net and the transformer inputs have two or three consumers); bsums [B][C][2] zero-filled scratch */
+int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3, const void* x, const float* sums, float* bsums, float* ws,
+                     void* dx, int B, long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step,
+                     int dtype, ltu_stream_t s);
 
 /* ---- residual LayerNorm: model/trans_block.py:205-206,209-210 -----------------------------------
  * y = LN(x + dropout(r)) * gamma + beta over rows of d in {32,64,128,256}; r is OVERWRITTEN with the
@@ -262,9 +264,9 @@ int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* 
  * axes (D,H,W); nn.Dropout3d draws one keep/drop per (sample, channel). */
 int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C, float p,
                    uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
-/* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller) */
-int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int B, int H, int W,
-                   int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+/* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller); dy2 (nullable): gradient of a second consumer, summed on load */
+int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dw, float* db, int B, int H,
+                   int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- dynamic ROI: model/Unet_3Dblock.py:821-873, 37-49 (box), 51-82 (index maps), 985-1117 (warps) ----
  * prob f32 [B,H,W,D,C]: foreground = (1 - prob[...,0]) >= thr.  Writes box [B][6] = (x0,y0,0,x1,y1,D-1)
@@ -280,8 +282,9 @@ int ltu_roi_resample(const void* in, void* out, int* plan_i, float* plan_f, int 
                      int D, int C, int roi_size, int dtype, ltu_stream_t s);
 
 /* ---- trilinear x(2,2,sd) upsampling, align_corners=True: model/Unet_3Dblock.py:1341-1345,1375-1378 ----
- * forward: in [B,H,W,D,C] -> out [B,2H,2W,sd*D,C]; adjoint != 0: in = gradient of the output. */
-int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
+ * forward: in [B,H,W,D,C] -> out [B,2H,2W,sd*D,C]; adjoint != 0: in = gradient of the output, in2 (nullable, adjoint only) =
+ * gradient of a second consumer of the output, summed on load. */
+int ltu_trilinear_up(const void* in, const void* in2, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
                      ltu_stream_t s);
 
 /* ---- deep-supervision losses of one level: loss/criterions.py:35-70,416-442,696-735;

@@ -74,7 +74,7 @@ SIGNATURES = {
     'ltu_norm_ws_floats': [],
     'ltu_instnorm_stats': [P, P, P, I, L, I, I, P],
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
-    'ltu_instnorm_bwd': [P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_instnorm_bwd': [P, P, P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
     'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
     'ltu_gelu_dropout_fwd': [P, P, L, F, U, P, I, P],
@@ -87,11 +87,11 @@ SIGNATURES = {
     'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, P, I, P],
-    'ltu_dwconv_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
+    'ltu_dwconv_bwd': [P, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
     'ltu_roi_plan_size': [I, I, I, I, P, P, P],
     'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P, P],
     'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    'ltu_trilinear_up': [P, P, I, I, I, I, I, I, I, I, P],
+    'ltu_trilinear_up': [P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P, P],
     'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
     'ltu_label_maxpool': [P, P, I, I, I, I, I, P],

@@ -173,8 +173,19 @@ __global__ void __launch_bounds__(256) instnorm_apply_fixedc_kernel(const T* __r
   }
 }
 
+// A tensor with several consumers receives one gradient per consumer.  Instead of a stand-alone add pass (one more read-modify-
+// write of an activation-sized tensor) the backward kernels of the PRODUCER take up to three gradient tensors and sum on load.
 template <typename T>
-__global__ void __launch_bounds__(256) instnorm_bwd_apply_fixedc_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__device__ __forceinline__ float4 load_grad3(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3, long long e) {
+  float4 g = Vec4<T>::load(dy + e);
+  if (dy2 != nullptr) { const float4 t = Vec4<T>::load(dy2 + e); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+  if (dy3 != nullptr) { const float4 t = Vec4<T>::load(dy3 + e); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+  return g;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_bwd_apply_fixedc_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                                        const T* __restrict__ dy3, const T* __restrict__ x,
                                                                         const float* __restrict__ sums,
                                                                         const float* __restrict__ bsums, T* __restrict__ dx,
                                                                         long long S, int C, int act, float slope, float p,
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_fixedc_kernel(const T*
   for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < per_b; j += (long long)gridDim.x * 256) {
     const long long i = base + j;
     const float4 xv = Vec4<T>::load(x + i * 4);
-    const float4 g = Vec4<T>::load(dy + i * 4);
+    const float4 g = load_grad3<T>(dy, dy2, dy3, i * 4);
     const float4 mk = dropmask4(dc, (uint64_t)i);
     float4 o;
 #pragma unroll
@@ -212,7 +223,8 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_fixedc_kernel(const T*
 
 // backward reductions: bsums[b][c][2] += { sum g, sum g*xhat },  g = dy*mask*act'(xhat)
 template <typename T>
-__global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
+__global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3,
+                                          const T* __restrict__ x, const float* __restrict__ sums,
                                           float* __restrict__ bsums, float* __restrict__ ws, long long S, int C,
                                           int rows_per_block, int act, float slope, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];
@@ -233,7 +245,7 @@ __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __r
     for (long long r = r0 + rg; r < r1; r += nrg) {
       const long long e = ((long long)b * S + r) * C + v * 4;
       const float4 xv = Vec4<T>::load(x + e);
-      float4 g = Vec4<T>::load(dy + e);
+      float4 g = load_grad3<T>(dy, dy2, dy3, e);
       const float4 mk = dropmask4(dc, (uint64_t)(e >> 2));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -257,7 +269,8 @@ __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __r
 }
 
 template <typename T>
-__global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sums,
+__global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3,
+                                          const T* __restrict__ x, const float* __restrict__ sums,
                                           const float* __restrict__ bsums, T* __restrict__ dx, long long S, int C, int B,
                                           int act, float slope, float p, uint64_t seed, const uint64_t* step) {
   const long long nvec = (long long)B * S * C / 4;
@@ -268,7 +281,7 @@ __global__ void instnorm_bwd_apply_kernel(const T* __restrict__ dy, const T* __r
     const int b = (int)(i / per_b);
     const int c = (int)((i * 4) % C);
     const float4 xv = Vec4<T>::load(x + i * 4);
-    const float4 g = Vec4<T>::load(dy + i * 4);
+    const float4 g = load_grad3<T>(dy, dy2, dy3, i * 4);
     const float4 mk = dropmask4(dc, (uint64_t)i);
     float4 o;
 #pragma unroll
@@ -490,7 +503,8 @@ extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* 
   return ltu_check_launch();
 }
 
-extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums, float* bsums, float* ws, void* dx, int B,
+extern "C" int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3, const void* x, const float* sums, float* bsums,
+                                float* ws, void* dx, int B,
                                 long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype,
                                 ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
@@ -504,14 +518,15 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* x, const float* sums
   LTU_DISPATCH_T(dtype, {
     if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
     hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)dy,
-                       (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
+                       (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
     if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, bsums, nullptr, 0, (hipStream_t)s);
     if (1024 % C == 0)
       hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T>), dim3(per_sample_grid(S * C / 4, B), B), dim3(256), 0,
-                         (hipStream_t)s, (const T*)dy, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope, p, seed, step);
+                         (hipStream_t)s, (const T*)dy, (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope,
+                         p, seed, step);
     else
       hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
-                         (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
+                         (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
   });
   return ltu_check_launch();
 }

@@ -627,8 +627,29 @@ extern "C" int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, co
 //   MODE 0: y = mask * (x + conv(x) + bias)      MODE 1: dx = mask * (dy + conv_flipped(dy))
 //   MODE 2: dw[c][t] += sum g' x[v + off_t], db[c] += sum g'   (g' = mask * dy; block-level LDS reduction, then atomics)
 #define DWH_VOX 360
+// 16 bytes of T (4 floats / 8 bf16) plus the same of a second tensor: the backward modes take the gradients of two consumers
+// of the layer's output and sum them while staging (no stand-alone add pass)
+template <typename T>
+__device__ __forceinline__ uint4 add16(uint4 a, uint4 b);
+template <>
+__device__ __forceinline__ uint4 add16<float>(uint4 a, uint4 b) {
+  return make_uint4(__float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x)), __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y)),
+                    __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z)), __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w)));
+}
+template <>
+__device__ __forceinline__ uint4 add16<bf16_t>(uint4 a, uint4 b) {
+  const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = pack_bf16x2(__uint_as_float(av[i] << 16) + __uint_as_float(bv[i] << 16),
+                       __uint_as_float(av[i] & 0xffff0000u) + __uint_as_float(bv[i] & 0xffff0000u));
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// x2 / g2 (nullable): second gradient tensors summed onto x (MODE 1) / g (MODE 2)
 template <typename T, int MODE>
-__global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ x, const T* __restrict__ g,
+__global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ x, const T* __restrict__ x2, const T* __restrict__ g,
+                                                          const T* __restrict__ g2,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           T* __restrict__ y, float* __restrict__ dwt, float* __restrict__ db, int B,
                                                           int H, int W, int D, int C, int bricks, int bricks_per_block, float p,
@@ -684,8 +705,11 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
       const int h = h0 - 1 + hh, ww = w0 - 1 + hw, d = d0 - 1 + hd;
       const int cc = blockIdx.x * CC + part * (16 / (int)sizeof(T));
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W && (unsigned)d < (unsigned)D && cc < C)
-        v = *reinterpret_cast<const uint4*>(x + ((((long long)b * H + h) * W + ww) * D + d) * C + cc);
+      if ((unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W && (unsigned)d < (unsigned)D && cc < C) {
+        const long long off = ((((long long)b * H + h) * W + ww) * D + d) * C + cc;
+        v = *reinterpret_cast<const uint4*>(x + off);
+        if (MODE == 1 && x2 != nullptr) v = add16<T>(v, *reinterpret_cast<const uint4*>(x2 + off));
+      }
       *reinterpret_cast<uint4*>(reinterpret_cast<char*>(halo) + hv * 128 + part * 16) = v;
     }
     if (MODE == 2) {                                // the brick's output gradients: 128 voxels x 128 bytes
@@ -694,8 +718,11 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
         const int h = h0 + (ov >> 5), ww = w0 + ((ov >> 3) & 3), d = d0 + (ov & 7);
         const int cc = blockIdx.x * CC + part * (16 / (int)sizeof(T));
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (h < H && ww < W && d < D && cc < C)
-          v = *reinterpret_cast<const uint4*>(g + ((((long long)b * H + h) * W + ww) * D + d) * C + cc);
+        if (h < H && ww < W && d < D && cc < C) {
+          const long long off = ((((long long)b * H + h) * W + ww) * D + d) * C + cc;
+          v = *reinterpret_cast<const uint4*>(g + off);
+          if (g2 != nullptr) v = add16<T>(v, *reinterpret_cast<const uint4*>(g2 + off));
+        }
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gl) + ov * 128 + part * 16) = v;
       }
     }
@@ -765,8 +792,9 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
 }
 
 template <typename T, int MODE>
-static void launch_dwconv_halo(const void* x, const void* g, const float* w, const float* bias, void* y, float* dwt, float* db, int B,
-                               int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, hipStream_t st) {
+static void launch_dwconv_halo(const void* x, const void* x2, const void* g, const void* g2, const float* w, const float* bias, void* y,
+                               float* dwt, float* db, int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step,
+                               hipStream_t st) {
   constexpr int CC = 128 / (int)sizeof(T);
   const int nchunk = cdiv(C, CC);
   const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
@@ -775,22 +803,22 @@ static void launch_dwconv_halo(const void* x, const void* g, const float* w, con
   if (nblk > bricks) nblk = bricks;
   const int bpb = (int)((bricks + nblk - 1) / nblk);
   nblk = (bricks + bpb - 1) / bpb;
-  hipLaunchKernelGGL((dwconv_halo_kernel<T, MODE>), dim3(nchunk, (unsigned)nblk), dim3(256), 0, st, (const T*)x, (const T*)g, w, bias,
-                     (T*)y, dwt, db, B, H, W, D, C, (int)bricks, bpb, p, seed, step);
+  hipLaunchKernelGGL((dwconv_halo_kernel<T, MODE>), dim3(nchunk, (unsigned)nblk), dim3(256), 0, st, (const T*)x, (const T*)x2, (const T*)g,
+                     (const T*)g2, w, bias, (T*)y, dwt, db, B, H, W, D, C, (int)bricks, bpb, p, seed, step);
 }
 
 extern "C" int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C,
                               float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { launch_dwconv_halo<T, 0>(x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s); });
+  LTU_DISPATCH_T(dtype, { launch_dwconv_halo<T, 0>(x, nullptr, nullptr, nullptr, w, bias, y, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s); });
   return ltu_check_launch();
 }
-extern "C" int ltu_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dwt, float* db, int B, int H,
-                              int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+extern "C" int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dwt, float* db, int B,
+                              int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
   LTU_DISPATCH_T(dtype, {
-    launch_dwconv_halo<T, 1>(dy, nullptr, w, nullptr, dx, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s);
-    launch_dwconv_halo<T, 2>(x, dy, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s);
+    launch_dwconv_halo<T, 1>(dy, dy2, nullptr, nullptr, w, nullptr, dx, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s);
+    launch_dwconv_halo<T, 2>(x, nullptr, dy, dy2, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s);
   });
   return ltu_check_launch();
 }

@@ -413,8 +413,8 @@ __device__ __forceinline__ int tri_cands(int i, int in, int out, float scale, fl
 
 // grid (blocks, B*H)
 template <typename T>
-__global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int D,
-                                                            int C, int Ho, int Wo, int Do, TriScale sc) {
+__global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, T* __restrict__ dx, int B,
+                                                            int H, int W, int D, int C, int Ho, int Wo, int Do, TriScale sc) {
   const unsigned cv = C / 4;
   const unsigned b = blockIdx.y / (unsigned)H, h = blockIdx.y - b * (unsigned)H;
   int oh[8], ow[8], od[8];
@@ -422,6 +422,7 @@ __global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict_
   const int nh = tri_cands((int)h, H, Ho, sc.h, sc.ih, oh, wh);
   const unsigned n = (unsigned)W * D * cv;
   const T* gb = dy + (long long)b * Ho * Wo * Do * C;
+  const T* gb2 = dy2 != nullptr ? dy2 + (long long)b * Ho * Wo * Do * C : nullptr;      // second consumer's gradient: summed on load
   T* xb = dx + ((long long)b * H + h) * n * 4;
   for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
     const unsigned r = t / cv, v = t - r * cv;
@@ -432,7 +433,9 @@ __global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict_
       for (int e = 0; e < nw; ++e)
         for (int f = 0; f < nd; ++f) {
           const float wgt = wh[a] * ww[e] * wd[f];
-          const float4 q = Vec4<T>::load(gb + (((long long)oh[a] * Wo + ow[e]) * Do + od[f]) * C + v * 4);
+          const long long off = (((long long)oh[a] * Wo + ow[e]) * Do + od[f]) * C + v * 4;
+          float4 q = Vec4<T>::load(gb + off);
+          if (gb2 != nullptr) { const float4 q2 = Vec4<T>::load(gb2 + off); q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w; }
           acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
         }
     Vec4<T>::store(xb + (long long)t * 4, acc);
@@ -443,8 +446,8 @@ __global__ void __launch_bounds__(256) trilinear_bwd_kernel(const T* __restrict_
 // ~150 instructions per output vector re-deriving them.
 #define TRI_TAB 256
 template <typename T>
-__global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
-                                                                int D, int C, int Ho, int Wo, int Do, TriScale sc) {
+__global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, T* __restrict__ dx,
+                                                                int B, int H, int W, int D, int C, int Ho, int Wo, int Do, TriScale sc) {
   __shared__ int t_n[2][TRI_TAB];
   __shared__ int t_o[2][TRI_TAB][8];
   __shared__ float t_w[2][TRI_TAB][8];
@@ -464,6 +467,7 @@ __global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restr
   __syncthreads();
   const unsigned n = (unsigned)W * D * cv;
   const T* gb = dy + (long long)b * Ho * Wo * Do * C;
+  const T* gb2 = dy2 != nullptr ? dy2 + (long long)b * Ho * Wo * Do * C : nullptr;
   T* xb = dx + ((long long)b * H + h) * n * 4;
   for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
     const unsigned r = t / cv, v = t - r * cv;
@@ -473,10 +477,12 @@ __global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restr
     for (int a = 0; a < nh; ++a)
       for (int e = 0; e < nw; ++e) {
         const float whw = wh[a] * t_w[0][w][e];
-        const T* row = gb + ((long long)oh[a] * Wo + t_o[0][w][e]) * Do * C + v * 4;
+        const long long roff = ((long long)oh[a] * Wo + t_o[0][w][e]) * Do * C + v * 4;
         for (int f = 0; f < nd; ++f) {
           const float wgt = whw * t_w[1][d][f];
-          const float4 q = Vec4<T>::load(row + (long long)t_o[1][d][f] * C);
+          const long long off = roff + (long long)t_o[1][d][f] * C;
+          float4 q = Vec4<T>::load(gb + off);
+          if (gb2 != nullptr) { const float4 q2 = Vec4<T>::load(gb2 + off); q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w; }
           acc.x += q.x * wgt; acc.y += q.y * wgt; acc.z += q.z * wgt; acc.w += q.w * wgt;
         }
       }
@@ -487,8 +493,9 @@ __global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restr
 static float tri_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 static float tri_inv(int in, int out) { return (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1); }
 
-extern "C" int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
-                                ltu_stream_t s) {
+extern "C" int ltu_trilinear_up(const void* in, const void* in2, void* out, int adjoint, int B, int H, int W, int D, int C, int sd,
+                                int dtype, ltu_stream_t s) {
+  if (in2 != nullptr && !adjoint) return LTU_E_ARG;      // a second (summed) input exists for gradients only
   if (C % 4 || (sd != 1 && sd != 2)) return LTU_E_SHAPE;
   const int Ho = 2 * H, Wo = 2 * W, Do = sd * D;
   if ((long long)Wo * Do * (C / 4) >= (1LL << 31) || (long long)B * Ho >= 65536) return LTU_E_SHAPE;
@@ -505,11 +512,11 @@ extern "C" int ltu_trilinear_up(const void* in, void* out, int adjoint, int B, i
       const long long n = (long long)W * D * (C / 4);
       const unsigned gx = (unsigned)((n + 511) / 512 < 1 ? 1 : (n + 511) / 512);
       if (W <= TRI_TAB && D <= TRI_TAB)
-        hipLaunchKernelGGL((trilinear_bwd_tab_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H,
+        hipLaunchKernelGGL((trilinear_bwd_tab_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (const T*)in2, (T*)out, B, H,
                            W, D, C, Ho, Wo, Do, sc);
       else
-        hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (T*)out, B, H, W,
-                           D, C, Ho, Wo, Do, sc);
+        hipLaunchKernelGGL((trilinear_bwd_kernel<T>), dim3(gx, B * H), dim3(256), 0, (hipStream_t)s, (const T*)in, (const T*)in2, (T*)out,
+                           B, H, W, D, C, Ho, Wo, Do, sc);
     }
   });
   return ltu_check_launch();

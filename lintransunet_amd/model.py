@@ -277,9 +277,11 @@ class MaskTransUnet(nn.Module):
         return st
 
     # ------------------------------------------------------------------ pieces
-    def _conv_in_act(self, x, conv, stride=(1, 1, 1), res=None, p=0.0, seeds=None, x1=None, ups=False):
+    def _conv_in_act(self, x, conv, stride=(1, 1, 1), res=None, p=0.0, seeds=None, x1=None, ups=False, fork=1, res_dup=None):
+        """conv + InstanceNorm + LeakyReLU (+ residual, + dropout).  fork: output ports, one per consumer of the result (their
+        gradients are summed inside the InstanceNorm backward kernel instead of by stand-alone add passes)"""
         y = ops.conv3d(x, conv.weight, conv.bias, stride=stride, x1=x1, ups=ups, prep=self._store.conv[id(conv)])
-        return ops.instnorm_act(y, res=res, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0)
+        return ops.instnorm_act(y, res=res, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0, fork=fork, res_dup=res_dup)
 
     def _layer(self, lay, t, tres, B, N, d, p, seeds, last):
         """post-norm transformer layer on tokens t [B*N, d] (model/trans_block.py:148-166, 203-211).  `t` feeds the
@@ -309,19 +311,21 @@ class MaskTransUnet(nn.Module):
                                 fork=not last)
         return out if not last else (out, out)
 
-    def _token_transformer(self, layers, pos, x, p, seeds):
+    def _token_transformer(self, layers, pos, x, p, seeds, x_res=None):
         """8 layers over the voxels of x [B,H,W,D,d]; positional conv after layer 0.  Token order does not
-        matter to the layers (per-token ops + a set reduction over tokens), so voxels stay in place."""
+        matter to the layers (per-token ops + a set reduction over tokens), so voxels stay in place.
+        x_res: a second port of x for the residual path of layer 0 (see ops._ports)."""
         B, H, W, D, d = x.shape
         N = H * W * D
         x = ops.wgrad_flush_point(x)         # backward: the transformer's weight gradients go out as one branch from here
-        t = tres = x.reshape(B * N, d)
+        t = x.reshape(B * N, d)
+        tres = t if x_res is None else x_res.reshape(B * N, d)
         for n, lay in enumerate(layers):
             # the positional conv after layer 0 consumes a single tensor; so does whatever follows the last layer
             t, tres = self._layer(lay, t, tres, B, N, d, p, seeds, last=(n == 0 or n == len(layers) - 1))
             if n == 0:
-                g = ops.pos_conv(t.view(B, H, W, D, d), pos.proj.weight, pos.proj.bias, p, seeds.next() if p > 0 else 0)
-                t = tres = g.view(B * N, d)
+                g, g_res = ops.pos_conv(t.view(B, H, W, D, d), pos.proj.weight, pos.proj.bias, p, seeds.next() if p > 0 else 0, fork=2)
+                t, tres = g.view(B * N, d), g_res.view(B * N, d)
         return t.view(B, H, W, D, d)
 
     def _roi_bridge(self, br, skip, mask, roi_size, p, seeds):
@@ -330,8 +334,8 @@ class MaskTransUnet(nn.Module):
         self.last_boxes.append(plan.box)
         tr = br.transformer
         g = ops.roi_warp(skip, plan)
-        e = self._conv_in_act(g, tr.down_embed.module_list[0][0], stride=(2, 2, 2), p=p, seeds=seeds)
-        e = self._token_transformer(tr.layers, tr.pos_encoder, e, p, seeds)
+        e, e_res = self._conv_in_act(g, tr.down_embed.module_list[0][0], stride=(2, 2, 2), p=p, seeds=seeds, fork=2)
+        e = self._token_transformer(tr.layers, tr.pos_encoder, e, p, seeds, x_res=e_res)
         up = tr.up_embed.module_list[0][1]       # nearest x2 + conv as a sub-pixel conv (3.4x fewer multiply-adds)
         e = ops.upconv3d(e, up.weight, up.bias, prep=self._store.conv[id(up)])
         e = ops.instnorm_act(e, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0)
@@ -369,27 +373,35 @@ class MaskTransUnet(nn.Module):
         store = self._weights(x.device)
         store.refresh()                      # one launch: every cast / transposed / repacked weight of this step
 
+        # Tensors with several consumers are produced with one output port per consumer (ops._ports): a block input feeds the
+        # block's conv1 and its residual (whose gradient arrives in two parts, because the block output itself has two consumers:
+        # the strided conv2 and the decoder's attention gate), the encoder output feeds the bottleneck transformer's first
+        # projection and its first residual.
         t = ops.window_embed(x.contiguous().float(), self.act_dtype)
-        t = self._conv_in_act(t, enc.input_block, seeds=seeds)
+        t, t_r, t_r2 = self._conv_in_act(t, enc.input_block, seeds=seeds, fork=3)
         skips = []
+        nblk = len(enc.block_list)
         for i, blk in enumerate(enc.block_list):
-            s = self._conv_in_act(t, blk.conv1, res=t, seeds=seeds)
-            t = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds)
-            skips.append(s)
+            s, s_skip = self._conv_in_act(t, blk.conv1, res=t_r, res_dup=t_r2, seeds=seeds, fork=2)
+            if i < nblk - 1:
+                t, t_r, t_r2 = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds, fork=3)
+            else:
+                t, t_r = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds, fork=2)
+            skips.append(s_skip)
 
         bt = dec.bridge_list[nl - 1].transformer
-        t = self._token_transformer(bt.layers, bt.pos_encoders[0], t, p, seeds)
+        t = self._token_transformer(bt.layers, bt.pos_encoders[0], t, p, seeds, x_res=t_r)
         masks = []
         for i in range(1, nl):
             lvl = nl - 1 - i
-            t = ops.trilinear_up(t, 2 if (nl - i) % 2 == 0 else 1)
+            t, t_gate = ops.trilinear_up(t, 2 if (nl - i) % 2 == 0 else 1, fork=2)      # consumers: the conv pair and the attention gate
             mc = dec.mask_conv_list[lvl]
             blk = dec.block_list[i - 1]
             t1, zm = ops.conv3d_pair(t, blk.conv1.weight, blk.conv1.bias, mc.weight, mc.bias, store.pair[lvl])
             m = ops.head_softmax(zm, C)
             masks.append(m)
             ag = dec.att_conv_list[lvl]
-            skip = ops.attention_gate(skips[-i], t, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,
+            skip = ops.attention_gate(skips[-i], t_gate, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,
                                       ag.psi[0].weight, ag.psi[0].bias, store.lin[id(ag.W_x[0])], store.lin[id(ag.W_g[0])])
             if self.is_roi_list[lvl]:
                 skip = self._roi_bridge(dec.bridge_list[lvl], skip, m.detach(), self.roi_size_list[lvl], p, seeds)

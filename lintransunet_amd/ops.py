@@ -802,9 +802,21 @@ def linear_gelu(x, weight, bias, p=0.0, seed=0, prep=None):
 
 # ---------------------------------------------------------------------------------------------- norms
 
+def _ports(y, fork):
+    """`fork` autograd outputs over one buffer: each consumer then delivers its own gradient tensor to backward, which hands all of
+    them to ONE kernel that sums on load (no stand-alone add pass over an activation-sized tensor)"""
+    return y if fork <= 1 else (y,) + tuple(y.view_as(y) for _ in range(fork - 1))
+
+
+def _grads(gs):
+    """the non-None incoming gradients (contiguous), padded with None to three"""
+    out = [g.contiguous() for g in gs if g is not None]
+    return out + [None] * (3 - len(out))
+
+
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, act, p, seed):
+    def forward(ctx, x, res, res_dup, act, p, seed, fork):
         lc = ctx.lc = current()
         _chk(x, 'x')
         B, C = x.shape[0], x.shape[-1]
@@ -815,27 +827,37 @@ class _InstNormAct(torch.autograd.Function):
         y = torch.empty_like(x)
         _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, lc.step_ptr(), dt, _s())
         ctx.save_for_backward(x, sums)
-        ctx.cfg = (act, p, seed, res is not None)
-        return y
+        ctx.cfg = (act, p, seed, res is not None, res_dup is not None)
+        return _ports(y, fork)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         lc = ctx.lc
         x, sums = ctx.saved_tensors
-        act, p, seed, has_res = ctx.cfg
-        g = g.contiguous()
+        act, p, seed, has_res, has_dup = ctx.cfg
+        g, g2, g3 = _grads(gs)
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
         bsums = lc.scratch_zeros((B, C, 2), x.device)
         dx = torch.empty_like(x)
-        _lib.call('ltu_instnorm_bwd', _p(g), _p(x), _p(sums), _p(bsums), _p(lc.norm_ws(x.device)), _p(dx), B, S, C, act, LRELU_SLOPE, float(p), seed,
-                  lc.step_ptr(), _dt(x), _s())
-        return dx, (g if has_res else None), None, None, None
+        _lib.call('ltu_instnorm_bwd', _p(g), _p(g2), _p(g3), _p(x), _p(sums), _p(bsums), _p(lc.norm_ws(x.device)), _p(dx), B, S, C, act,
+                  LRELU_SLOPE, float(p), seed, lc.step_ptr(), _dt(x), _s())
+        # the residual passes the output gradient through.  With two output ports and a duplicate residual port the two gradient
+        # tensors travel on separately (the producer of the residual sums them on load); otherwise they have to be added here.
+        dres = ddup = None
+        if has_res:
+            if has_dup and g2 is not None and g3 is None:
+                dres, ddup = g, g2
+            else:
+                dres = g if g2 is None else (g + g2 if g3 is None else g + g2 + g3)
+        return dx, dres, ddup, None, None, None, None
 
 
-def instnorm_act(x, res=None, act=ACT_LRELU, p=0.0, seed=0):
-    """y = dropout(act(InstanceNorm(x))) + res over channels-last x [B,...,C]."""
-    return _InstNormAct.apply(x, res, act, p, seed)
+def instnorm_act(x, res=None, act=ACT_LRELU, p=0.0, seed=0, fork=1, res_dup=None):
+    """y = dropout(act(InstanceNorm(x))) + res over channels-last x [B,...,C].  fork > 1 returns that many ports of y (one per
+    consumer); res_dup: a second port of the SAME residual tensor (values are read from `res`), which receives the gradient of
+    the second output port."""
+    return _InstNormAct.apply(x, res, res_dup, act, p, seed, fork)
 
 
 class _ResLayerNorm(torch.autograd.Function):
@@ -1062,7 +1084,7 @@ def linear_attention(qkv, B, N, d):
 
 class _PosConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, p, seed):
+    def forward(ctx, x, w, b, p, seed, fork):
         lc = ctx.lc = current()
         _chk(x, 'x')
         B, H, W, D, C = x.shape
@@ -1071,52 +1093,54 @@ class _PosConv(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.params = (w, b)
         ctx.cfg = (p, seed)
-        return y
+        return _ports(y, fork)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         lc = ctx.lc
         (x,) = ctx.saved_tensors
         w, b = ctx.params
         p, seed = ctx.cfg
-        g = g.contiguous()
+        g, g2, _ = _grads(gs)
         B, H, W, D, C = x.shape
         dx = torch.empty_like(x)
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        _lib.call('ltu_dwconv_bwd', _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, lc.step_ptr(), _dt(x), _s())
-        return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, lc.step_ptr(),
+                  _dt(x), _s())
+        return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None, None
 
 
-def pos_conv(x, w, b, p=0.0, seed=0):
-    """chan_dropout(x + depthwise3x3x3(x) + b) on channels-last x; w [C,1,3,3,3] in the reference's (D,H,W) kernel order."""
-    return _PosConv.apply(x, w, b, p, seed)
+def pos_conv(x, w, b, p=0.0, seed=0, fork=1):
+    """chan_dropout(x + depthwise3x3x3(x) + b) on channels-last x; w [C,1,3,3,3] in the reference's (D,H,W) kernel order.
+    fork = 2 returns two ports of the result (one per consumer; their gradients are summed inside the backward kernel)."""
+    return _PosConv.apply(x, w, b, p, seed, fork)
 
 
 class _Trilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, sd):
+    def forward(ctx, x, sd, fork):
         lc = ctx.lc = current()
         _chk(x, 'x')
         B, H, W, D, C = x.shape
         y = torch.empty((B, 2 * H, 2 * W, sd * D, C), device=x.device, dtype=x.dtype)
-        _lib.call('ltu_trilinear_up', _p(x), _p(y), 0, B, H, W, D, C, sd, _dt(x), _s())
+        _lib.call('ltu_trilinear_up', _p(x), 0, _p(y), 0, B, H, W, D, C, sd, _dt(x), _s())
         ctx.cfg = (B, H, W, D, C, sd)
-        return y
+        return _ports(y, fork)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         lc = ctx.lc
         B, H, W, D, C, sd = ctx.cfg
-        g = g.contiguous()
+        g, g2, _ = _grads(gs)
         dx = torch.empty((B, H, W, D, C), device=g.device, dtype=g.dtype)
-        _lib.call('ltu_trilinear_up', _p(g), _p(dx), 1, B, H, W, D, C, sd, _dt(g), _s())
-        return dx, None
+        _lib.call('ltu_trilinear_up', _p(g), _p(g2), _p(dx), 1, B, H, W, D, C, sd, _dt(g), _s())
+        return dx, None, None
 
 
-def trilinear_up(x, sd):
-    """Trilinear x(2,2,sd) upsampling, align_corners=True."""
-    return _Trilinear.apply(x, sd)
+def trilinear_up(x, sd, fork=1):
+    """Trilinear x(2,2,sd) upsampling, align_corners=True; fork = 2 returns two ports (one per consumer)."""
+    return _Trilinear.apply(x, sd, fork)
 
 
 class _RoiResample(torch.autograd.Function):

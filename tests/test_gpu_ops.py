@@ -636,6 +636,46 @@ def test_roi_golden(ops, golden_dir):
         assert rel_err(from_cl(rin.grad)[:, :2], torch.from_numpy(Gd[f'{name}_droi_in'])) < 1e-4, name
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_output_ports_sum_gradients_in_kernel(ops, dtype):
+    """a tensor with several consumers is produced with one autograd port per consumer; the producer's backward kernel receives all
+    gradient tensors and sums them on load.  Equivalent to one consumer that receives the summed gradient."""
+    g = G(41)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    B, H, W, D, C = 2, 6, 5, 8, 32
+    x = torch.randn(B, H, W, D, C, generator=g).to(DEV, dtype)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV, dtype)
+    # trilinear: two ports
+    c1, c2 = mk(B, 2 * H, 2 * W, 2 * D, C), mk(B, 2 * H, 2 * W, 2 * D, C)
+    xa = x.clone().requires_grad_(True)
+    ya, yb = ops.trilinear_up(xa, 2, fork=2)
+    ((ya * c1).float().sum() + (yb * c2).float().sum()).backward()
+    xb = x.clone().requires_grad_(True)
+    (ops.trilinear_up(xb, 2) * (c1.float() + c2.float()).to(dtype)).float().sum().backward()
+    assert rel_err(xa.grad.float(), xb.grad.float()) < tol
+    # positional conv: two ports
+    w, b = (torch.randn(C, 1, 3, 3, 3, generator=g) * 0.2).to(DEV), torch.zeros(C, device=DEV)
+    c1, c2 = mk(B, H, W, D, C), mk(B, H, W, D, C)
+    wa, wb = w.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xa = x.clone().requires_grad_(True)
+    ya, yb = ops.pos_conv(xa, wa, b.clone().requires_grad_(True), fork=2)
+    ((ya * c1).float().sum() + (yb * c2).float().sum()).backward()
+    xb = x.clone().requires_grad_(True)
+    (ops.pos_conv(xb, wb, b.clone().requires_grad_(True)) * (c1.float() + c2.float()).to(dtype)).float().sum().backward()
+    assert rel_err(xa.grad.float(), xb.grad.float()) < tol and rel_err(wa.grad, wb.grad) < tol
+    # InstanceNorm + LeakyReLU + residual: three ports of the block input (conv branch, residual, residual duplicate), two ports
+    # of the block output -- the encoder's pattern
+    c1, c2 = mk(B, H, W, D, C), mk(B, H, W, D, C)
+    src = x.clone().requires_grad_(True)
+    t, t_r, t_r2 = ops.instnorm_act(src, fork=3)
+    s1, s2 = ops.instnorm_act(t * 1.5, res=t_r, res_dup=t_r2, fork=2)
+    ((s1 * c1).float().sum() + (s2 * c2).float().sum()).backward()
+    ref = x.clone().requires_grad_(True)
+    t0 = ops.instnorm_act(ref)
+    (ops.instnorm_act(t0 * 1.5, res=t0) * (c1.float() + c2.float()).to(dtype)).float().sum().backward()
+    assert rel_err(src.grad.float(), ref.grad.float()) < tol
+
+
 # ---------------------------------------------------------------------------------------------- heads, gate, losses
 def test_softmax_heads(ops):
     g = G(11)

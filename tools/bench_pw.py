@@ -35,7 +35,7 @@ def inorm(B, S, C):
     sums = torch.zeros(B, C, 3, device='cuda'); bs = torch.zeros(B, C, 2, device='cuda')
     st = lambda: _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(WS), B, S, C, 1, _s())
     ap = lambda: _lib.call('ltu_instnorm_apply', _p(x), _p(sums), 0, _p(y), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
-    bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
+    bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), 0, 0, _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
     t1, t2, t3 = timed(st), timed(ap), timed(bw)
     mb = B * S * C * 2 / 1e6
     print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.1f} TB/s)  apply {t2:6.1f} us ({2 * mb / t2:.1f} TB/s)  '
