@@ -100,6 +100,18 @@ int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void*
                        float eps, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int dtype,
                        ltu_stream_t s);
 
+/* The backward of the same chain as ONE launch: LayerNorm 2 backward, data gradients through linear2 / GELU + dropout / linear1,
+ * LayerNorm 1 backward (on dt1 + dz2), data gradient through the out projection.  dy2 (nullable): second gradient of y, summed on
+ * load.  w2t / w1t / wot: fragment-ordered TRANSPOSED weights (ltu_weight_prep kind 9 of the fp32 masters).  Outputs: da, dz1
+ * (gradient of the residual input x) and dr2 / du / dr1 = the G operands of the three weight gradients (ltu_linear_wgrad_group
+ * with X = h / t1 / a).  lnws2 / lnws1: ltu_layer_tail_blocks(M) x 2d floats each = per-workgroup (gamma, beta) column sums,
+ * interleaved, folded by ltu_reduce_batch (mode 1). */
+long long ltu_layer_tail_blocks(long long M);
+int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z2, const void* z1, const void* u, const float* stat2,
+                       const float* stat1, const float* g2, const float* g1, const void* w2t, const void* w1t, const void* wot,
+                       void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1, long long M, int d, float p,
+                       uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int dtype, ltu_stream_t s);
+
 /* ---- deferred second stage of the two-stage reductions ------------------------------------------
  * ltu_linear_wgrad / ltu_layernorm_bwd can leave the folding of their per-split partial sums to the caller: pass a job
  * record, collect a few, and fold them with ONE launch (ltu_reduce_batch) before the gradients are read.  A record whose

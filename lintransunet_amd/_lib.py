@@ -39,6 +39,8 @@ SIGNATURES = {
     'ltu_upconv_wgrad_ws_floats': [L, I, I],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
     'ltu_layer_tail_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, U, U, U, P, I, P],
+    'ltu_layer_tail_blocks': [L],
+    'ltu_layer_tail_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, U, U, P, I, P],
     'ltu_reduce_batch': [P, I, P],
     'ltu_linear_wgrad_group_ws_floats': [P, I],
     'ltu_linear_wgrad_group': [P, I, P, I, P],
@@ -119,7 +121,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
-        fn.restype = c_longlong if name.endswith('_ws_floats') else c_int
+        fn.restype = c_longlong if (name.endswith('_ws_floats') or name == 'ltu_layer_tail_blocks') else c_int
     _lib = lib
     return lib
 

@@ -213,6 +213,207 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
   tl_layernorm<D, true, false>(TB, XA, nullptr, nullptr, LD, ta.g2, ta.be2, ta.z2, ta.y, ta.stat2, row0, ta.M, ta.eps, dc2, tid);
 }
 
+// ------------------------------------------------------------------------------------------------ backward chain
+// dy (+ dy2) -> LN2 backward -> dr2 -> (W2) -> dh -> GELU / dropout backward -> du -> (W1) -> dt1 -> LN1 backward (dt1 + dz2)
+// -> dz1 (residual gradient of the layer input), dr1 -> (Wo) -> da (gradient of the attention output).
+// dr2, du, dr1 are also the G operands of the three weight gradients and are written out; the per-workgroup column sums of the
+// two LayerNorms (gamma / beta gradients) go to lnws2 / lnws1 [nblocks][2 d] (interleaved gamma, beta) for the batched fold.
+struct TailBwdArgs {
+  const uint16_t* dy;     // [M][d] gradient of the layer output
+  const uint16_t* dy2;    // second gradient of the layer output (nullable)
+  const uint16_t* z2;
+  const uint16_t* z1;
+  const uint16_t* u;      // [M][2d]
+  const float* stat2;
+  const float* stat1;
+  const float* g2;        // LayerNorm weights
+  const float* g1;
+  const uint16_t* w2t;    // fragment-ordered transposes (kind 9): linear2 -> outputs 2d over d, linear1 -> d over 2d, out -> d over d
+  const uint16_t* w1t;
+  const uint16_t* wot;
+  uint16_t* dr2;          // [M][d]
+  uint16_t* du;           // [M][2d]
+  uint16_t* dr1;          // [M][d]
+  uint16_t* dz1;          // [M][d]
+  uint16_t* da;           // [M][d]
+  float* lnws2;
+  float* lnws1;
+  long long M;
+  float p;
+  uint64_t seed1, seedg, seed2;
+  const uint64_t* step;
+};
+
+// LayerNorm backward over the block's rows.  g = gl (LDS, nullable) + gg1 (global, nullable) + gg2 (global, nullable); writes dz to
+// dzl (LDS, nullable) / dzg (global, nullable), dr = dz * dropout mask to drl (LDS) and drg (global); column sums to lnws.
+template <int D, int NTHR, bool G_LDS, bool G2_LDS, bool DZ_LDS, bool DZ_GLOBAL>
+__device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint16_t* gl2_, const uint16_t* gg1, const uint16_t* gg2,
+                                                 const uint16_t* __restrict__ zg, const float* __restrict__ stat,
+                                                 const float* __restrict__ gamma, uint16_t* dzl, uint16_t* dzg, uint16_t* drl,
+                                                 uint16_t* drg, float* __restrict__ lnws, float* red, int LD, long long row0,
+                                                 long long M, const DropCfg& dc, int tid) {
+  constexpr int G = D / 4, RPP = NTHR / G;
+  const int gl = tid % G, rgp = tid / G;
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = rgp; r < TL_ROWS; r += RPP) {
+    const long long row = row0 + r;
+    const bool ok = row < M;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (G_LDS) g = unpack_quad(*reinterpret_cast<const uint2*>(gl_ + r * LD + gl * 4));
+    if constexpr (G2_LDS) {
+      const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gl2_ + r * LD + gl * 4));
+      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+    }
+    if (gg1 != nullptr && ok) {
+      const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gg1 + row * D + gl * 4));
+      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+    }
+    if (gg2 != nullptr && ok) {
+      const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gg2 + row * D + gl * 4));
+      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+    }
+    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mean = 0.f, rstd = 0.f;
+    if (ok) {
+      zv = unpack_quad(*reinterpret_cast<const uint2*>(zg + row * D + gl * 4));
+      mean = stat[row * 2]; rstd = stat[row * 2 + 1];
+    }
+    const float gv[4] = {g.x, g.y, g.z, g.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    float h[4] = {(zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd};
+    float gg[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (ok) { ab[k] += gv[k]; ag[k] += gv[k] * h[k]; }
+      gg[k] = gv[k] * gmv[k];
+      s1 += gg[k]; s2 += gg[k] * h[k];
+    }
+    const float m1 = group_sum<G>(s1) / (float)D, m2 = group_sum<G>(s2) / (float)D;
+    const float4 dz = make_float4(rstd * (gg[0] - m1 - h[0] * m2), rstd * (gg[1] - m1 - h[1] * m2), rstd * (gg[2] - m1 - h[2] * m2),
+                                  rstd * (gg[3] - m1 - h[3] * m2));
+    const uint2 dzq = pack_quad(dz.x, dz.y, dz.z, dz.w);
+    const float4 dr = drop4(dc, (unsigned long long)((row * D + gl * 4) >> 2), dz);
+    const uint2 drq = pack_quad(dr.x, dr.y, dr.z, dr.w);
+    if constexpr (DZ_LDS) *reinterpret_cast<uint2*>(dzl + r * LD + gl * 4) = dzq;
+    *reinterpret_cast<uint2*>(drl + r * LD + gl * 4) = drq;
+    if (ok) {
+      if constexpr (DZ_GLOBAL) *reinterpret_cast<uint2*>(dzg + row * D + gl * 4) = dzq;
+      *reinterpret_cast<uint2*>(drg + row * D + gl * 4) = drq;
+    }
+  }
+  // column sums of the block: row groups meet in LDS (red: [RPP][2 D] floats)
+  float* dst = red + ((long long)rgp * D + gl * 4) * 2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { dst[2 * k] = ag[k]; dst[2 * k + 1] = ab[k]; }
+  __syncthreads();
+  for (int i = tid; i < 2 * D; i += NTHR) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPP; ++q) acc += red[(long long)q * 2 * D + i];
+    lnws[(long long)blockIdx.x * 2 * D + i] = acc;
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const TailBwdArgs ta) {
+  constexpr int LD = D + 8, LDH = 2 * D + 8;
+  constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* RB = smem;                                // [32][LD]   dr2, later dt1 and (in place) dr1
+  uint16_t* ZB = RB + TL_ROWS * LD;                   // [32][LD]   dz2
+  uint16_t* UB = ZB + TL_ROWS * LD;                   // [32][LDH]  du
+  float* red = reinterpret_cast<float*>(UB + TL_ROWS * LDH);      // [NTHR / (D/4)][2 D] column-sum scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long row0 = (long long)blockIdx.x * TL_ROWS;
+  const DropCfg dc1 = make_drop(ta.p, ta.seed1, ta.step), dcg = make_drop(ta.p, ta.seedg, ta.step), dc2 = make_drop(ta.p, ta.seed2, ta.step);
+  constexpr int NT1 = D / 32, NT2 = 2 * D / 32;
+
+  // stage 0: LayerNorm 2 backward: dz2 -> ZB, dr2 -> RB + global
+  tl_layernorm_bwd<D, NTHR, false, false, true, false>(nullptr, nullptr, ta.dy, ta.dy2, ta.z2, ta.stat2, ta.g2, ZB, nullptr, RB, ta.dr2,
+                                                      ta.lnws2, red, LD, row0, ta.M, dc2, tid);
+  __syncthreads();
+  // stage 1: dh = dr2 W2, du = dh * dropout mask * gelu'(u) -> UB + global
+  for (int ct = wave; ct < NT2; ct += NW) {
+    f32x16 acc[1];
+    tl_tile<1>(ta.w2t, D / 16, ct, 0, RB, LD, lane, acc);
+    const long long row = row0 + li;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = ct * 32 + 8 * q + 4 * lh;
+      const float4 dh = unpack_quad(pack_quad(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]));   // bf16-rounded, as stored by the op-by-op path
+      float4 uf = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < ta.M) uf = unpack_quad(*reinterpret_cast<const uint2*>(ta.u + row * (2 * D) + n));
+      const float4 mk = dropmask4(dcg, (unsigned long long)((row * (2 * D) + n) >> 2));
+      const uint2 dq = pack_quad(dh.x * mk.x * gelu_erf_grad(uf.x), dh.y * mk.y * gelu_erf_grad(uf.y), dh.z * mk.z * gelu_erf_grad(uf.z),
+                                 dh.w * mk.w * gelu_erf_grad(uf.w));
+      *reinterpret_cast<uint2*>(UB + li * LDH + n) = dq;
+      if (row < ta.M) *reinterpret_cast<uint2*>(ta.du + row * (2 * D) + n) = dq;
+    }
+  }
+  __syncthreads();
+  // stage 2: dt1 = du W1 -> RB (dr2 is no longer needed)
+  for (int ct = wave; ct < NT1; ct += NW) {
+    f32x16 acc[1];
+    tl_tile<1>(ta.w1t, 2 * D / 16, ct, 0, UB, LDH, lane, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = ct * 32 + 8 * q + 4 * lh;
+      *reinterpret_cast<uint2*>(RB + li * LD + n) = pack_quad(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]);
+    }
+  }
+  __syncthreads();
+  // stage 3: LayerNorm 1 backward on dt1 + dz2: dz1 -> global, dr1 -> RB (in place) + global
+  tl_layernorm_bwd<D, NTHR, true, true, false, true>(RB, ZB, nullptr, nullptr, ta.z1, ta.stat1, ta.g1, nullptr, ta.dz1, RB, ta.dr1, ta.lnws1,
+                                                    red, LD, row0, ta.M, dc1, tid);
+  __syncthreads();
+  // stage 4: da = dr1 Wo
+  for (int ct = wave; ct < NT1; ct += NW) {
+    f32x16 acc[1];
+    tl_tile<1>(ta.wot, D / 16, ct, 0, RB, LD, lane, acc);
+    const long long row = row0 + li;
+    if (row < ta.M) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = ct * 32 + 8 * q + 4 * lh;
+        *reinterpret_cast<uint2*>(ta.da + row * D + n) = pack_quad(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]);
+      }
+    }
+  }
+}
+
+extern "C" long long ltu_layer_tail_blocks(long long M) { return (M + TL_ROWS - 1) / TL_ROWS; }
+
+extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z2, const void* z1, const void* u, const float* stat2,
+                                  const float* stat1, const float* g2, const float* g1, const void* w2t, const void* w1t,
+                                  const void* wot, void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1,
+                                  long long M, int d, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step,
+                                  int dtype, ltu_stream_t s) {
+  if (dtype != LTU_BF16) return LTU_E_DTYPE;
+  if (d != 128 && d != 256) return LTU_E_SHAPE;
+  if (M <= 0) return LTU_OK;
+  TailBwdArgs ta;
+  ta.dy = (const uint16_t*)dy; ta.dy2 = (const uint16_t*)dy2; ta.z2 = (const uint16_t*)z2; ta.z1 = (const uint16_t*)z1;
+  ta.u = (const uint16_t*)u; ta.stat2 = stat2; ta.stat1 = stat1; ta.g2 = g2; ta.g1 = g1;
+  ta.w2t = (const uint16_t*)w2t; ta.w1t = (const uint16_t*)w1t; ta.wot = (const uint16_t*)wot;
+  ta.dr2 = (uint16_t*)dr2; ta.du = (uint16_t*)du; ta.dr1 = (uint16_t*)dr1; ta.dz1 = (uint16_t*)dz1; ta.da = (uint16_t*)da;
+  ta.lnws2 = lnws2; ta.lnws1 = lnws1;
+  ta.M = M; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
+  const unsigned blocks = cdiv(M, TL_ROWS);
+  const int rpp = (d >= 256 ? 512 : 256) / (d / 4);
+  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)rpp * 2 * d * sizeof(float);
+  if (d == 256) {
+    static LtuDevOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((tail_bwd_kernel<256>), dim3(blocks), dim3(512), lds, (hipStream_t)s, ta);
+  } else {
+    static LtuDevOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((tail_bwd_kernel<128>), dim3(blocks), dim3(256), lds, (hipStream_t)s, ta);
+  }
+  return ltu_check_launch();
+}
+
 extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void* w1, const void* w2, const float* bo,
                                   const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
                                   const float* be2, void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1,

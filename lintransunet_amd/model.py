@@ -126,12 +126,13 @@ class _WeightStore:
         wt = torch.empty((K, N * len(weights)), device=self.device, dtype=self.dtype)
         for i, w in enumerate(weights):
             self.recs.append((w, wt, 1, N, K, N * len(weights), i * N))
-        fr = None
-        if frag and self.dtype == torch.bfloat16 and N % 32 == 0 and K % 16 == 0:
-            fr = torch.empty(N * len(weights) * K, device=self.device, dtype=self.dtype)     # MFMA fragment order (kind 8)
-            for i, w in enumerate(weights):
-                self.recs.append((w, fr[i * N * K:(i + 1) * N * K], 8, N, K, 0, 0))
-        self.lin[key] = ops.LinPrep(fw, wt, group, fr)
+        fr = frT = None
+        if frag and self.dtype == torch.bfloat16 and N % 32 == 0 and K % 32 == 0 and len(weights) == 1:
+            fr = torch.empty(N * K, device=self.device, dtype=self.dtype)      # MFMA fragment order (kind 8) ...
+            frT = torch.empty(N * K, device=self.device, dtype=self.dtype)     # ... and of the transpose (kind 9)
+            self.recs.append((weights[0], fr, 8, N, K, 0, 0))
+            self.recs.append((weights[0], frT, 9, N, K, 0, 0))
+        self.lin[key] = ops.LinPrep(fw, wt, group, fr, frT)
 
     def finalize(self):
         import numpy as np

@@ -369,11 +369,12 @@ class LinPrep:
     group: None = the weight gradient is launched by the op's backward; 'collect' = handed to the context's weight-gradient group
     (a transformer layer's out / ffn projections); 'flush' = handed in and the group launched (the layer's qkv projection, whose
     backward is the last of the layer)."""
-    __slots__ = ('w', 'wt', 'group', 'frag')
+    __slots__ = ('w', 'wt', 'group', 'frag', 'fragT')
 
-    def __init__(self, w, wt, group=None, frag=None):
+    def __init__(self, w, wt, group=None, frag=None, fragT=None):
         self.w, self.wt, self.group = w, wt, group
         self.frag = frag          # cat(W) in MFMA fragment order (weight-prep kind 8) for the row-block chain kernels, or None
+        self.fragT = fragT        # W^T in fragment order (kind 9): the data-gradient operand of the backward chain kernel
 
 
 # ---------------------------------------------------------------------------------------------- no-grad helpers
@@ -944,6 +945,7 @@ def gelu_dropout(u, p=0.0, seed=0):
 # the row-block chain kernel wins at every token level of the 128^3 step (micro-benchmark tools/bench_tail.py: 20 / 35 / 58 / 120 us
 # against 27 / 51 / 72 / 130 us for the five launches at 1 024 / 8 640 / 21 504 / 114 816 tokens); LTU_TAIL_MAX_TOKENS caps it
 USE_LAYER_TAIL = _os.environ.get('LTU_NO_LAYER_TAIL', '') == ''
+USE_LAYER_TAIL_BWD = _os.environ.get('LTU_NO_LAYER_TAIL_BWD', '') == ''
 TAIL_MAX_TOKENS = int(_os.environ.get('LTU_TAIL_MAX_TOKENS', '1000000000'))      # the row-block chain kernel serves the small token levels (measured; the 115 k-token level keeps the
                              # streaming ring kernels, which are bandwidth- rather than latency-bound)
 
@@ -1019,6 +1021,32 @@ class _LayerTail(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(gy), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
             return dx
 
+        if USE_LAYER_TAIL_BWD and po.fragT is not None and p1.fragT is not None and p2.fragT is not None:
+            # the whole data-gradient chain as one launch (csrc/tlayer.hip: tail_bwd_kernel)
+            dr2, dr1, dz1, da = (torch.empty_like(a) for _ in range(4))
+            du = torch.empty_like(u)
+            nblk = _lib.load().ltu_layer_tail_blocks(M)
+            lnws = torch.empty((2, nblk, 2 * d), device=dev, dtype=torch.float32)
+            _lib.call('ltu_layer_tail_bwd', _p(g), _p(g2), _p(z2), _p(z1), _p(u), _p(stat2), _p(stat1), _p(gm2), _p(gm1), _p(p2.fragT),
+                      _p(p1.fragT), _p(po.fragT), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), M, d, float(p),
+                      seeds[0], seeds[1], seeds[2], lc.step_ptr(), dt, _s())
+            outs = []
+            for k, (gamma, beta) in enumerate(((gm2, be2), (gm1, be1))):
+                dg, fg = _grad_buf(gamma)
+                db, fb = _grad_buf(beta)
+                job = _defer_job()
+                job.part, job.nsplit, job.n, job.k, job.nseg, job.mode = lnws[k].data_ptr(), nblk, 2 * d, 1, 1, 1
+                job.out[0], job.out[1] = dg.data_ptr(), db.data_ptr()
+                if fg and fb:
+                    lc.defer_push(job, lnws)                  # folded with the other pending second stages, 8 per launch
+                else:
+                    _lib.call('ltu_reduce_batch', ctypes.addressof(job), 1, _s())
+                outs.append((_grad_done(gamma, dg, fg), _grad_done(beta, db, fb)))
+            (dgm2, dbe2), (dgm1, dbe1) = outs
+            (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)
+            (dw1,), (db1,) = _wgrad_now_or_group(lc, du, t1, [w1], [b1], M, 2 * d, d)
+            (dwo,), (dbo,) = _wgrad_now_or_group(lc, dr1, a, [wo], [bo], M, d, d)
+            return da, dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None
         dz2, dr2, dgm2, dbe2 = ln_bwd(g, g2, z2, stat2, gm2, be2, seeds[2])
         dh = dgrad(dr2, p2, w2, d, 2 * d)
         (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)

@@ -363,7 +363,8 @@ def test_linear_gelu_fused(ops, M, K, N, dtype):
 
 
 def test_dropout_masks(ops):
-    """Philox dropout: keep rate, 1/(1-p) scaling, and the backward regenerates exactly the forward mask"""
+    """counter-hash dropout (csrc/common.h: two chained murmur3 finalizers per 4-element group): keep rate, 1/(1-p) scaling, and the
+    backward regenerates exactly the forward mask"""
     n = 1 << 18
     u = torch.ones(n // 64, 64, device=DEV).requires_grad_(True)
     h = ops.gelu_dropout(u, 0.3, 12345)

@@ -23,6 +23,11 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.ltu_version() >= 1
+    # the documents quote the same number of entry points as the header declares
+    for doc in ('DESIGN.md', 'INTEGRATION.md'):
+        text = open(os.path.join(ROOT, doc)).read()
+        quoted = set(int(m) for m in re.findall(r'(\d+) (?:`extern "C"` )?(?:entry points|functions)', text))
+        assert quoted == {len(declared)}, (doc, quoted, len(declared))
     # argument counts of the binding table match the C prototypes
     for name, args in re.findall(r'^(?:int|long long)\s+(ltu_\w+)\s*\(([^;]*)\);', header, flags=re.M | re.S):
         n = 0 if args.strip() == 'void' else len(args.split(','))
