@@ -173,23 +173,30 @@ struct WGroupJob {
   float* part;          // [nsplit][N][K] followed by the bias partials [nsplit][N]
   long long M;
   int ldg, lda, N, K, nk, rows, nsplit;
-  int blk_begin;        // first workgroup of this job; its workgroups are ordered (split, n tile, k tile)
+  int tile_begin;       // first tile of this job in the group's tile list; its tiles are ordered (n tile, k tile)
 };
 struct WGroupArgs {
   WGroupJob j[LTU_WGRAD_GROUP_MAX];
   int njobs;
+  int tiles;            // tiles of all jobs
+  int nsplit;           // row splits (the same for every job)
 };
 template <int R>
 __global__ void __launch_bounds__(256) wgrad_group_ring_bf16_kernel(const WGroupArgs ga) {
   extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
+  // Workgroup -> (split, tile): all tiles of one row split get workgroup ids that are equal modulo 8, i.e. (with the dispatcher's
+  // round-robin over the 8 XCDs) they share one XCD and its L2, and they are adjacent in dispatch order: the three column tiles
+  // of the q,k,v gradient read the same rows of X, the two row tiles of the linear2 gradient the same rows of G.  Placement
+  // affects speed only.  id = ((split / 8) * tiles + tile) * 8 + split % 8.
+  const int s_lo = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+  const int tg = q % ga.tiles, split = (q / ga.tiles) * 8 + s_lo;
+  if (split >= ga.nsplit) return;
   int ji = 0;
 #pragma unroll
   for (int t = 1; t < LTU_WGRAD_GROUP_MAX; ++t)
-    if (t < ga.njobs && (int)blockIdx.x >= ga.j[t].blk_begin) ji = t;
+    if (t < ga.njobs && tg >= ga.j[t].tile_begin) ji = t;
   const WGroupJob& jb = ga.j[ji];
-  const int local = (int)blockIdx.x - jb.blk_begin;
-  const int tiles = (jb.N >> 7) * jb.nk;
-  const int split = local / tiles, t = local - split * tiles;
+  const int t = tg - jb.tile_begin;
   const int nb = t / jb.nk, kb = t - nb * jb.nk;
   const long long m_begin = (long long)split * jb.rows;
   long long m_end = m_begin + jb.rows;
@@ -567,23 +574,29 @@ static void wgroup_geometry(const ltu_wgrad_job* jobs, int njobs, WGroupArgs& ga
   int tiles = 0;
   for (int i = 0; i < njobs; ++i) tiles += (jobs[i].N / 128) * (jobs[i].K / 128);
   const int budget = ltu_knob_pos("LTU_WGROUP_BLOCKS", 256);
-  long long off = 0;
-  int blk = 0;
+  long long off = 0, Mmax = 0;
+  for (int i = 0; i < njobs; ++i) Mmax = jobs[i].M > Mmax ? jobs[i].M : Mmax;
+  // one split count for the whole group (the jobs of a transformer layer have the same M): ~budget workgroups, splits of >= 128 rows
+  long long want = budget / (tiles > 0 ? tiles : 1);
+  if (want < 1) want = 1;
+  long long rows0 = (Mmax + want - 1) / want;
+  if (rows0 < 128) rows0 = 128;
+  rows0 = (rows0 + 31) / 32 * 32;
+  const int nsplit = (int)((Mmax + rows0 - 1) / rows0);
+  int tb = 0;
   ga.njobs = njobs;
+  ga.tiles = tiles;
+  ga.nsplit = nsplit;
   for (int i = 0; i < njobs; ++i) {
     WGroupJob& j = ga.j[i];
     const long long M = jobs[i].M;
-    long long want = budget / (tiles > 0 ? tiles : 1);
-    if (want < 1) want = 1;
-    long long rows = (M + want - 1) / want;
-    if (rows < 128) rows = 128;
-    rows = (rows + 31) / 32 * 32;
+    long long rows = ((M + nsplit - 1) / nsplit + 31) / 32 * 32;
     j.M = M; j.N = jobs[i].N; j.K = jobs[i].K; j.nk = jobs[i].K / 128;
     j.ldg = jobs[i].ldg; j.lda = jobs[i].lda;
     j.rows = (int)rows;
-    j.nsplit = (int)((M + rows - 1) / rows);
-    j.blk_begin = blk;
-    blk += j.nsplit * (j.N / 128) * j.nk;
+    j.nsplit = nsplit;                       // splits past the job's rows store zero tiles
+    j.tile_begin = tb;
+    tb += (j.N / 128) * j.nk;
     part_off[i] = off;
     off += (long long)j.nsplit * j.N * ((long long)j.K + 1);
   }
@@ -621,7 +634,6 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
     j.part = ws + off[i];
     j.grad = reinterpret_cast<const uint16_t*>(jobs[i].grad);
     j.x = reinterpret_cast<const uint16_t*>(jobs[i].a);
-    blocks = j.blk_begin + j.nsplit * (j.N / 128) * j.nk;
     WFoldJob& f = fa.j[i];
     f.part = j.part; f.nsplit = j.nsplit; f.N = j.N; f.K = j.K; f.nseg = jobs[i].nw;
     for (int s = 0; s < 3; ++s) { f.out[s] = s < jobs[i].nw ? jobs[i].dw[s] : nullptr; f.outb[s] = s < jobs[i].nw ? jobs[i].db[s] : nullptr; }
@@ -635,6 +647,7 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_ring_bf16_kernel<TN_RING>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               smem_bytes);
   }
+  blocks = ((ga.nsplit + 7) / 8) * ga.tiles * 8;
   hipLaunchKernelGGL((wgrad_group_ring_bf16_kernel<TN_RING>), dim3(blocks), dim3(256), smem_bytes, st, ga);
   hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fa);
   return ltu_check_launch();

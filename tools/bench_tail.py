@@ -69,5 +69,9 @@ def run(M, d):
     print(f'M={M:7d} d={d}: forward chain {tt:7.1f} us vs five launches {ts:7.1f} us;  backward chain {bt:7.1f} us vs six launches {bs:7.1f} us', flush=True)
 
 
-for M, d in ((1024, 256), (8640, 256), (21504, 256), (28704, 128), (114816, 128)):
+import sys
+SHAPES = ((1024, 256), (8640, 256), (21504, 256), (28704, 128), (114816, 128))
+if len(sys.argv) > 1 and sys.argv[1] == 'scale':
+    SHAPES = tuple((m, d) for d in (128, 256) for m in (64, 32 * 256, 32 * 512, 32 * 1024, 32 * 2048))
+for M, d in SHAPES:
     run(M, d)
