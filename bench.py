@@ -25,9 +25,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Roofline object: the dense projections of the transformer layers (nn.Linear, model/trans_block.py:144-189) are the
-# largest kernel family by time.  They are HBM-bound (AI ~ 98 flop/B < ridge ~ 310); algorithmic bytes
-# of one launch y[M,N] = x[M,K] W^T: (M*K + M*N + N*K) * sizeof(bf16).
+# Roofline object: the chain kernels that carry the post-attention half of every transformer layer (out projection, LayerNorm,
+# FFN, LayerNorm: model/trans_block.py:203-211) are the largest kernel family by time.  Their GEMMs have AI ~ 98 flop/B < ridge
+# ~ 310: HBM-bound.  Algorithmic bytes of a layer with M tokens: forward 10 M d, backward 13 M d
+# elements of activations (each tensor read or written once) + 16 d^2 of weights, bf16.
 HBM_PEAK_GBS = 8000.0
 
 
@@ -253,40 +254,77 @@ def main():
     # multi-class script (train3D_multi_class.py / utils_3D_multi_class.py:85-102): CE + Dice(class 1) + Dice(class 2), weights 10/1/2
     specs = train.level_specs(5, ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'), criterion_weight=[10, 1, 2]) if args.classes == 3 else None
 
-    # live timing of the dominant kernel family (the dense projections of the transformers)
+    # live timing of the dominant kernel family: the transformer layer chain kernels (csrc/tlayer.hip: tail_fwd_kernel and
+    # tail_bwd_kernel carry the post-attention half of every transformer layer, forward and backward; together the largest family by
+    # time).  Their (tokens, d, second-gradient) shapes are recorded over one eager step; the same launches are then re-issued on
+    # buffers of those shapes from a small captured graph and bracketed by ONE HIP event pair on the launching stream.
     timer = KernelTimer()
-    def linear_bytes(ctx, x, prep, *wb):
-        n = sum(w.shape[0] for w in wb[:len(wb) // 2])
-        return float(x.shape[0] * x.shape[1] + x.shape[0] * n + n * x.shape[1]) * x.element_size()
+    import numpy as np
+    from lintransunet_amd import _lib
+    from lintransunet_amd.ops import _p, _s
 
-    def linear_gelu_bytes(ctx, x, prep, w, b, p, seed):       # reads x, W; writes the pre-activation and the activation
-        n = w.shape[0]
-        return float(x.shape[0] * x.shape[1] + 2 * x.shape[0] * n + n * x.shape[1]) * x.element_size()
+    def tail_bytes(ctx, a, x, *rest):
+        # forward: reads a, x; writes z1, t1, z2, y (d wide) and u, h (2d wide); backward: reads dy, dy2, z2, z1, u; writes dr2, dr1,
+        # dz1, da, du; weights (8 d^2 forward + 8 d^2 backward, bf16) are read once per launch from HBM
+        M, d = a.shape
+        return float((10 + 13) * M * d + 16 * d * d) * 2.0
+    ops._LayerTail.forward = staticmethod(timer.wrap(ops._LayerTail.forward, tail_bytes, 'tail'))
+    chain_cache = {}
 
-    ops._Linear.forward = staticmethod(timer.wrap(ops._Linear.forward, linear_bytes, 'linear'))
-    ops._LinearGelu.forward = staticmethod(timer.wrap(ops._LinearGelu.forward, linear_gelu_bytes, 'linear_gelu'))
+    def chain_buffers(M, d):
+        if (M, d) not in chain_cache:
+            bf = lambda *sh: (torch.randn(*sh, device=dev) * 0.5).bfloat16()
+            def fragw(n, k, kind):
+                w = torch.randn(n, k, device=dev) / k ** 0.5
+                out = torch.empty(n * k, device=dev, dtype=torch.bfloat16)
+                rec = np.zeros(1, dtype=ops.WPREP_DTYPE)
+                rec[0] = (w.data_ptr(), out.data_ptr(), kind, n, k, 0, 0, 0)
+                table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+                _lib.call('ltu_weight_prep', table.data_ptr(), 1, 1, _s())
+                torch.cuda.synchronize()
+                return out
+            nblk = _lib.load().ltu_layer_tail_blocks(M)
+            chain_cache[(M, d)] = dict(
+                a=bf(M, d), x=bf(M, d), dy=bf(M, d), dy2=bf(M, d), w=[fragw(d, d, 8), fragw(2 * d, d, 8), fragw(d, 2 * d, 8)],
+                wt=[fragw(d, 2 * d, 9), fragw(2 * d, d, 9), fragw(d, d, 9)], bias=torch.zeros(2 * d, device=dev),
+                gamma=torch.ones(d, device=dev), md=[torch.empty(M, d, device=dev, dtype=torch.bfloat16) for _ in range(8)],
+                m2d=[torch.empty(M, 2 * d, device=dev, dtype=torch.bfloat16) for _ in range(3)],
+                stat=[torch.empty(M, 2, device=dev) for _ in range(2)], lnws=torch.empty(2, nblk, 2 * d, device=dev))
+        return chain_cache[(M, d)]
 
     def replay(c):
-        if c[0] == 'linear':
-            c = c[1:]
-            return ops.linear(c[0], list(c[2:2 + (len(c) - 2) // 2]), list(c[2 + (len(c) - 2) // 2:]), prep=c[1])
-        x, prep, w, b, p, seed = c[1:]
-        return ops.linear_gelu(x, w, b, p, seed, prep=prep)
+        a_ = c[1]
+        M, d = a_.shape
+        q = chain_buffers(M, d)
+        z1, t1, z2, y, dr2, dr1, dz1, da = q['md']
+        u, h, du = q['m2d']
+        _lib.call('ltu_layer_tail_fwd', _p(q['a']), _p(q['x']), _p(q['w'][0]), _p(q['w'][1]), _p(q['w'][2]), _p(q['bias']), _p(q['bias']),
+                  _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y),
+                  _p(q['stat'][0]), _p(q['stat'][1]), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, _s())
+        _lib.call('ltu_layer_tail_bwd', _p(q['dy']), _p(q['dy2']), _p(z2), _p(z1), _p(u), _p(q['stat'][1]), _p(q['stat'][0]), _p(q['gamma']),
+                  _p(q['gamma']), _p(q['wt'][0]), _p(q['wt'][1]), _p(q['wt'][2]), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(q['lnws'][0]),
+                  _p(q['lnws'][1]), M, d, 0.3, 11, 12, 13, 0, 1, _s())
 
     def eager_step(i):
         reducer.zero_grad()
         x, lab = batches[i % 2]
         return train.train_step(model, x, lab, weights, specs=specs, reducer=reducer)
 
-    # The dominant kernel family (forward projections) is recorded over one eager step and re-timed below from a graph of
-    # exactly those launches; the timed region of the headline number replays the whole step from a captured HIP graph.
+    # The dominant kernel family is recorded over one eager step and re-timed below from a graph of exactly those launches (forward
+    # and backward chain of every transformer layer); the timed region of the headline number replays the whole step from a captured
+    # HIP graph.
     eager_step(0)
     torch.cuda.synchronize()
     timer.on = True
     eager_step(1)
     torch.cuda.synchronize()
     timer.on = False
+    reducer.rebucket()                        # buckets in gradient-ready order (recorded by the eager step): each bucket's all-reduce
+                                              # starts while backward still produces the next one
+    for c in timer.calls:
+        chain_buffers(*c[1].shape)            # allocate / prepare outside the timed replay
     ms_lin, n_lin = timer.measure(replay)
+    n_lin *= 2                                # one forward and one backward launch per recorded layer
     timer.calls = []
 
     launch = 'eager'
@@ -331,14 +369,15 @@ def main():
     if rank == 0:
         patches = args.batch * world * args.steps
         achieved = timer.work / (ms_lin * 1e-3) / 1e9 if ms_lin > 0 else 0.0       # GB/s
-        # HBM traffic of the same launches from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): counters need their own
-        # rocprofv3 --pmc passes, so this is the committed offline collection of tools/pmc_collect.sh, not a live number
+        # HBM traffic of the same kernel family from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): counters need their
+        # own rocprofv3 --pmc passes, so this is the committed offline collection of tools/pmc_step.sh, not a live number
         traffic, traffic_src = None, None
-        for name in ('r02_pmc_linear.json', 'r01_pmc_linear.json'):
-            pmc = os.path.join(ROOT, 'profiles', name)
-            if os.path.exists(pmc):
-                traffic, traffic_src = json.load(open(pmc)).get('hbm_bytes_per_launch'), 'profiles/' + name
-                break
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_step.json')
+        if os.path.exists(pmc):
+            fam = json.load(open(pmc))['families'].get('transformer layer chain kernels (forward + backward)')
+            if fam and fam['dispatches_per_step']:
+                traffic = (fam['hbm_read_GB_per_step'] + fam['hbm_write_GB_per_step']) * 1e9 / fam['dispatches_per_step']
+                traffic_src = 'profiles/r02_pmc_step.json (offline rocprofv3 --pmc passes of the same step)'
         ms_step = dt / args.steps * 1e3
         roof_ms = ROOF_MS_PER_PATCH.get(args.size)
         out = {
@@ -348,7 +387,7 @@ def main():
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights' + (', 3 labels (multi-class losses)' if args.classes == 3 else ''), 'global_batch': args.batch * world,
                        'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch, 'allreduce': allreduce},
-            'roofline': {'bound': 'hbm', 'kernel': 'linear_ring_bf16_kernel (transformer projections, forward launches; the FFN front half carries GELU + dropout)',
+            'roofline': {'bound': 'hbm', 'kernel': 'tail_fwd_kernel + tail_bwd_kernel (row-block chain kernels: post-attention half of every transformer layer, forward and backward)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),
                          'algorithmic_bytes_per_launch': timer.work / max(n_lin, 1), 'traffic': traffic,

@@ -45,17 +45,19 @@ struct TailArgs {
   float eps, p;
   uint64_t seed1, seedg, seed2;               // dropout sites: after the out projection, after GELU, after linear2
   const uint64_t* step;
+  int dbg;                // ablation (tools/bench_tail.py): 1 = weight operands are not loaded
 };
 
 __device__ __forceinline__ tl_bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(tl_bf16x8, v); }
 
 // One column tile of a GEMM stage: acc[g][..] = sum_k W[ct*32 + ..][k] X[(rg0+g)*32 + ..][k] (transposed product, see above).
-// X: LDS, bf16, row stride LDX elements; W: fragment order in global memory.  Operand loads run U reduction steps ahead of the
-// matrix instructions.
-template <int NRG>
-__device__ __forceinline__ void tl_tile(const uint16_t* __restrict__ W, int KS, int ct, int rg0, const uint16_t* Xl, int LDX,
-                                        int lane, f32x16 (&acc)[NRG]) {
-  constexpr int U = 4;
+// X: LDS, bf16, row stride LDX elements; W: fragment order in global memory (served by L2: every workgroup streams the same
+// weights).  KS (reduction steps of 16) is a compile-time constant: the loop is fully unrolled around a rotating queue of U weight
+// fragments, so U loads stay in flight per wave all the time (a counted vmcnt per step instead of a drain per group of steps).
+template <int NRG, int KS>
+__device__ __forceinline__ void tl_tile(const uint16_t* __restrict__ W, int ct, int rg0, const uint16_t* Xl, int LDX, int lane,
+                                        f32x16 (&acc)[NRG], int dbg = 0) {
+  constexpr int U = KS < 8 ? KS : 8;
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int g = 0; g < NRG; ++g)
@@ -65,26 +67,29 @@ __device__ __forceinline__ void tl_tile(const uint16_t* __restrict__ W, int KS, 
   const uint16_t* xr[NRG];
 #pragma unroll
   for (int g = 0; g < NRG; ++g) xr[g] = Xl + ((rg0 + g) * 32 + li) * LDX + 8 * lh;
-  uint4 wv[U];
+  uint4 wq[U];
+  if (dbg & 1) {            // ablation: one fragment, re-used for every step
+    const uint4 w0 = wp[0];
 #pragma unroll
-  for (int i = 0; i < U; ++i) wv[i] = wp[(size_t)i * 64];
-  for (int k0 = 0; k0 < KS; k0 += U) {
-    uint4 wc[U], xv[NRG][U];
+    for (int k = 0; k < KS; ++k)
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
-      wc[i] = wv[i];
+      for (int g = 0; g < NRG; ++g) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(xr[g] + k * 16);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w0), as_bf16x8(xv), acc[g], 0, 0, 0);
+      }
+    return;
+  }
 #pragma unroll
-      for (int g = 0; g < NRG; ++g) xv[g][i] = *reinterpret_cast<const uint4*>(xr[g] + (k0 + i) * 16);
+  for (int i = 0; i < U; ++i) wq[i] = wp[(size_t)i * 64];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const uint4 w = wq[k % U];
+    if (k + U < KS) wq[k % U] = wp[(size_t)(k + U) * 64];
+#pragma unroll
+    for (int g = 0; g < NRG; ++g) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(xr[g] + k * 16);
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w), as_bf16x8(xv), acc[g], 0, 0, 0);
     }
-    if (k0 + U < KS) {
-#pragma unroll
-      for (int i = 0; i < U; ++i) wv[i] = wp[(size_t)(k0 + U + i) * 64];
-    }
-#pragma unroll
-    for (int i = 0; i < U; ++i)
-#pragma unroll
-      for (int g = 0; g < NRG; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wc[i]), as_bf16x8(xv[g][i]), acc[g], 0, 0, 0);
   }
 }
 
@@ -148,12 +153,17 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
   const DropCfg dc1 = make_drop(ta.p, ta.seed1, ta.step), dcg = make_drop(ta.p, ta.seedg, ta.step), dc2 = make_drop(ta.p, ta.seed2, ta.step);
 
-  // stage 0: the block's rows of the attention output
+  // stage 0: the block's rows of the attention output -> XA, and of the residual input -> HB (free until stage 3): the residual
+  // is needed only by the LayerNorm of stage 2, but loading it there would expose one more global round trip per workgroup
   for (int i = tid; i < TL_ROWS * (D / 8); i += NTHR) {
     const int r = i / (D / 8), c = (i % (D / 8)) * 8;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row0 + r < ta.M) v = *reinterpret_cast<const uint4*>(ta.a + (row0 + r) * D + c);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u), xv = v;
+    if (row0 + r < ta.M) {
+      v = *reinterpret_cast<const uint4*>(ta.a + (row0 + r) * D + c);
+      xv = *reinterpret_cast<const uint4*>(ta.x + (row0 + r) * D + c);
+    }
     *reinterpret_cast<uint4*>(XA + r * LD + c) = v;
+    *reinterpret_cast<uint4*>(HB + r * LD + c) = xv;
   }
   __syncthreads();
 
@@ -161,7 +171,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
   // stage 1: out projection -> TB (bf16)
   for (int ct = wave; ct < NT1; ct += NW) {
     f32x16 acc[1];
-    tl_tile<1>(ta.wo, D / 16, ct, 0, XA, LD, lane, acc);
+    tl_tile<1, D / 16>(ta.wo, ct, 0, XA, LD, lane, acc, ta.dbg);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
@@ -172,12 +182,12 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
   }
   __syncthreads();
   // stage 2: z1 = x + drop(o), t1 = LN1(z1) -> XA (the attention rows are no longer needed)
-  tl_layernorm<D, false, true>(TB, nullptr, ta.x, XA, LD, ta.g1, ta.be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
+  tl_layernorm<D, true, true>(TB, HB, nullptr, XA, LD, ta.g1, ta.be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
   __syncthreads();
   // stage 3: u = t1 W1^T + b1 (global), h = drop(gelu(u)) (global + HB)
   for (int ct = wave; ct < NT2; ct += NW) {
     f32x16 acc[1];
-    tl_tile<1>(ta.w1, D / 16, ct, 0, XA, LD, lane, acc);
+    tl_tile<1, D / 16>(ta.w1, ct, 0, XA, LD, lane, acc, ta.dbg);
     const long long row = row0 + li;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
   // stage 4: linear2 -> TB
   for (int ct = wave; ct < NT1; ct += NW) {
     f32x16 acc[1];
-    tl_tile<1>(ta.w2, 2 * D / 16, ct, 0, HB, LDH, lane, acc);
+    tl_tile<1, 2 * D / 16>(ta.w2, ct, 0, HB, LDH, lane, acc, ta.dbg);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
@@ -336,7 +346,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const Ta
   // stage 1: dh = dr2 W2, du = dh * dropout mask * gelu'(u) -> UB + global
   for (int ct = wave; ct < NT2; ct += NW) {
     f32x16 acc[1];
-    tl_tile<1>(ta.w2t, D / 16, ct, 0, RB, LD, lane, acc);
+    tl_tile<1, D / 16>(ta.w2t, ct, 0, RB, LD, lane, acc);
     const long long row = row0 + li;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -355,7 +365,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const Ta
   // stage 2: dt1 = du W1 -> RB (dr2 is no longer needed)
   for (int ct = wave; ct < NT1; ct += NW) {
     f32x16 acc[1];
-    tl_tile<1>(ta.w1t, 2 * D / 16, ct, 0, UB, LDH, lane, acc);
+    tl_tile<1, 2 * D / 16>(ta.w1t, ct, 0, UB, LDH, lane, acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
@@ -370,7 +380,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const Ta
   // stage 4: da = dr1 Wo
   for (int ct = wave; ct < NT1; ct += NW) {
     f32x16 acc[1];
-    tl_tile<1>(ta.wot, D / 16, ct, 0, RB, LD, lane, acc);
+    tl_tile<1, D / 16>(ta.wot, ct, 0, RB, LD, lane, acc);
     const long long row = row0 + li;
     if (row < ta.M) {
 #pragma unroll
@@ -429,6 +439,7 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   ta.z1 = (uint16_t*)z1; ta.t1 = (uint16_t*)t1; ta.u = (uint16_t*)u; ta.h = (uint16_t*)h; ta.z2 = (uint16_t*)z2; ta.y = (uint16_t*)y;
   ta.stat1 = stat1; ta.stat2 = stat2;
   ta.M = M; ta.eps = eps; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
+  ta.dbg = ltu_knob("LTU_TAIL_DBG", 0);
   const unsigned blocks = cdiv(M, TL_ROWS);
   const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t);
   if (d == 256) {

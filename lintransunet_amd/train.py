@@ -122,36 +122,57 @@ class GradReducer:
         unused = set(unused or [])
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and n not in unused]
         named.reverse()
-        cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets, cur, cur_n = [], [], 0
+        self.cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.fused = fused
+        self.ready_order = []           # parameters in the order their gradients became ready in the last backward
+        self._seen = set()
         for n, p in named:
-            cur.append(p)
-            cur_n += p.numel()
-            if cur_n >= cap:
-                self.buckets.append(cur)
-                cur, cur_n = [], 0
-        if cur:
-            self.buckets.append(cur)
-        self.flat, self.pending, self.handles = [], [], []
-        self.bucket_of = {}
-        for bi, params in enumerate(self.buckets):
-            flat = torch.zeros(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
-            off = 0
-            for p in params:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
-                self.bucket_of[p] = bi
-                p.register_post_accumulate_grad_hook(self._hook)     # gradients that arrive through autograd
-                if fused and p.is_cuda:
-                    p._ltu_grad = p.grad                            # ... and those written by the wgrad kernels directly
-                    p._ltu_hook = self._hook
-            self.flat.append(flat)
-        self.pending = [0] * len(self.buckets)
+            p.register_post_accumulate_grad_hook(self._hook)     # gradients that arrive through autograd
+        self._assign([p for n, p in named])
         self.active = False
         self.reduce_now = True
         self.ctx = None
         # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) sums and the buckets are divided afterwards
         self.avg = self.world > 1 and dist.get_backend(group) == 'nccl'
+
+    def _assign(self, params):
+        """bucket `params` in the given order: flat fp32 buffers of ~cap elements, every .grad a view into its bucket"""
+        self.buckets, cur, cur_n = [], [], 0
+        for p in params:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= self.cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.handles = [], []
+        self.bucket_of = {}
+        for bi, plist in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in plist), device=plist[0].device, dtype=torch.float32)
+            off = 0
+            for p in plist:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.bucket_of[p] = bi
+                if self.fused and p.is_cuda:
+                    p._ltu_grad = p.grad                            # written by the wgrad kernels directly
+                    p._ltu_hook = self._hook
+            self.flat.append(flat)
+        self.pending = [0] * len(self.buckets)
+
+    def rebucket(self):
+        """Re-assign the buckets in the order in which the gradients became ready during the last backward (as DDP does after its
+        first iteration).  The registration order used at construction is only a guess: in this network the decoder's coarse
+        stages and the bottleneck transformer are registered early in the decoder but finish late in backward, so buckets in
+        registration order all complete near the end of the step and nothing overlaps.  Call between steps, after one backward
+        with hooks armed (`prepare`), before building optimizers / step graphs on top of the buffers (a GraphedStep notices moved
+        gradient storage and captures again).  Every rank records the same order (it depends on the autograd graph only)."""
+        if not self.ready_order:
+            raise RuntimeError('rebucket() needs one backward pass with armed hooks first')
+        seen = set(self.ready_order)
+        rest = [p for b in self.buckets for p in b if p not in seen]
+        self._assign(list(self.ready_order) + rest)
 
     def _all_reduce(self, flat):
         return dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -170,12 +191,16 @@ class GradReducer:
         self.pending = [len(b) for b in self.buckets]
         self.handles = []
         self.active = True
+        self.ready_order, self._seen = [], set()
         self.reduce_now = bool(reduce) and self.world > 1
         self.ctx = ctx or ops.current()          # the hooks run on autograd's thread: they must not look the context up there
 
     def _hook(self, p):
         if not self.active:
             return
+        if p not in self._seen:
+            self._seen.add(p)
+            self.ready_order.append(p)
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.reduce_now:

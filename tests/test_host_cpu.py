@@ -119,6 +119,14 @@ def _reducer_worker(rank, world, port, out):
             assert not red.handles
         red.finish()
     assert all(torch.allclose(a, p.grad, atol=1e-6) for a, p in zip(after_replay, list(net.parameters())[:6]))
+    # buckets re-assigned in gradient-ready order (last layer first): same gradients, first bucket = the head of the network's tail
+    red.rebucket()
+    assert red.buckets[0][0] is net[4].bias or red.buckets[0][0] is net[4].weight
+    red.zero_grad()
+    red.prepare()
+    ((net[:5](x[shard]) - y[shard]) ** 2).mean().backward()
+    red.finish()
+    assert all(torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(after_replay, list(net.parameters())[:6]))
     if rank == 0:
         ref = torch.nn.Sequential(*[m for m in list(net.children())[:5]])
         grads = [p.grad.clone() for p in list(net.parameters())[:6]]

@@ -81,6 +81,16 @@ red.zero_grad()
 train.train_step(m, x, lab, w, reducer=red)
 torch.cuda.synchronize()
 results['eager'] = [f.clone() for f in red.flat]
+# buckets in gradient-ready order, then the captured step again: same gradients (summed over all parameters)
+tot_before = sum(f.double().sum().item() for f in red.flat)
+names = {id(p): n for n, p in m.named_parameters()}
+red.rebucket()
+print('ready-order buckets:', [(names[id(b[0])].split('.')[0:3], len(b), sum(p.numel() for p in b)) for b in red.buckets][:4], '...')
+step = train.GraphedStep(m, x, lab, w, red, overlap='graph')
+step(x, lab)
+torch.cuda.synchronize()
+tot_after = sum(f.double().sum().item() for f in red.flat)
+assert abs(tot_after - tot_before) <= 1e-3 * abs(tot_before) + 1e-6, (tot_before, tot_after)
 for mode in ('after', 'eager'):
     worst = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(results['graph'], results[mode]))
     print(f'gradients graph vs {mode}: worst bucket rel-L2 {worst:.2e}')
