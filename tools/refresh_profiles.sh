@@ -1,13 +1,24 @@
 #!/bin/bash
-# regenerates the files kept under profiles/ (run from the repo root on the GPU box; outputs land in gpurun_out/)
+# regenerates the files kept under profiles/ for the current round (run from the repo root on the GPU box; outputs land in
+# gpurun_out/ and are copied into profiles/ by hand afterwards):  bash tools/refresh_profiles.sh r02
 set -e
+R=${1:-r02}
 ROOT=$(pwd)
-python3 bench.py > gpurun_out/r01_bench.json 2> gpurun_out/r01_bench.err
+python3 bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 bash tools/profile_bench.sh
 {
-  echo "== bench_nt.py (projections: forward kernel | weight gradient incl. second stage)"; python3 tools/bench_nt.py 2>/dev/null
+  echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3   (MI355X; the trace holds 2 eager steps, 2 capture warm-ups, 13 replays of the step graph and 6 replays of the 64-launch chain-kernel timing graph; per-step figures divide by 18, so the chain kernels read a few per cent high; summary of the rocpd database by tools/prof_summary.py)"
+  cat gpurun_out/prof_bench_stats.txt
+} > gpurun_out/${R}_bench_kernel_stats.txt
+cp gpurun_out/prof_bench_stats.csv gpurun_out/${R}_bench_kernel_stats.csv
+bash tools/pmc_step.sh
+cp gpurun_out/r02_pmc_step.json gpurun_out/${R}_pmc_step.json 2>/dev/null || true
+{
+  echo "== bench_tail.py (transformer layer chain kernels vs the op-by-op launches they replace)"; (cd tools && python3 bench_tail.py 2>/dev/null)
+  echo; echo "== bench_nt.py (projections: forward kernel | weight gradient incl. second stage)"; python3 tools/bench_nt.py 2>/dev/null
   echo; echo "== bench_pw.py (LayerNorm, GELU, InstanceNorm)"; python3 tools/bench_pw.py 2>/dev/null
   echo; echo "== bench_conv.py (3x3x3 convs, stride 1)"; python3 tools/bench_conv.py 2>/dev/null
   echo; echo "== bench_class.py (sub-pixel un-embedding forward)"; python3 tools/bench_class.py 2>/dev/null
   echo; echo "== bench_dwconv.py (positional depthwise conv)"; python3 tools/bench_dwconv.py 2>/dev/null
-} > gpurun_out/r01_microbench_body.txt
+  echo; echo "== bucket_timeline.py"; python3 tools/bucket_timeline.py 2>/dev/null
+} > gpurun_out/${R}_microbench.txt
