@@ -339,7 +339,7 @@ def fx_model(tag, cfg, size, batch, wseed, full_arrays):
 
 
 
-def fx_model_multi(tag, cfg, size, batch, wseed):
+def fx_model_multi(tag, cfg, size, batch, wseed, full_arrays=True):
     """multi-class step: reference model with dim_output = 3 + loss/multi_criterions.py, replay of
     utils/utils_3D_multi_class.py:68-102 with the defaults of train3D_multi_class.py:85-90"""
     shapes = O_net.param_shapes(cfg)
@@ -393,12 +393,18 @@ def fx_model_multi(tag, cfg, size, batch, wseed):
     d2 = R_mloss.DiceClassLoss2()(predict, onehot(label))
     print(f'[{tag}] total {total.item():.6f}, grad err {gerr:.2e}, dice1 {d1.item():.6f}, dice2 {d2.item():.6f}')
     keys = sorted(k for k, v in grads.items() if v is not None)
-    out = dict(total=np32(total), dice1=np32(d1), dice2=np32(d2), out=np32(predict),
+    out = dict(total=np32(total), dice1=np32(d1), dice2=np32(d2),
                level_losses=np.array([[v.item() for v in vals] for vals in loss_list], dtype=np.float64),
                weights=np.array(weights, dtype=np.float64),
                grad_keys=np.array(keys), grad_norms=np.array([grads[k].double().norm().item() for k in keys]))
-    for i, m in enumerate(masks):
-        out[f'mask{i}'] = np32(m)
+    if full_arrays:
+        out['out'] = np32(predict)
+        for i, m in enumerate(masks):
+            out[f'mask{i}'] = np32(m)
+    else:          # BASELINE-size case: sampled voxels
+        flat = predict.detach().flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 4096).long()
+        out['out_idx'], out['out_sample'] = idx.numpy(), np32(flat[idx])
     np.savez_compressed(os.path.join(HERE, f'model_{tag}.npz'), **out)
 
 def fx_infer512():
@@ -488,8 +494,12 @@ def main():
         fx_metrics()
         return
     small3 = O_net.NetConfig(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6], dim_output=3)
-    if len(sys.argv) > 1 and sys.argv[1] == 'multi':        # only the multi-class fixture
+    if len(sys.argv) > 1 and sys.argv[1] == 'multi':        # only the multi-class fixtures
         fx_model_multi('multi_small', small3, (32, 32, 32), 2, 400)
+        fx_model_multi('multi128', O_net.NetConfig(dim_output=3), (128, 128, 128), 1, 900, full_arrays=False)      # BASELINE config 4 size
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'multi128':
+        fx_model_multi('multi128', O_net.NetConfig(dim_output=3), (128, 128, 128), 1, 900, full_arrays=False)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':     # only the BASELINE-size fixtures (reference: ~25 s and ~16 GB each)
         fx_model('full128', O_net.NetConfig(), (128, 128, 128), 1, 500, full_arrays=False)
@@ -509,6 +519,7 @@ def main():
         fx_linattn()
         return
     fx_model_multi('multi_small', small3, (32, 32, 32), 2, 400)
+    fx_model_multi('multi128', O_net.NetConfig(dim_output=3), (128, 128, 128), 1, 900, full_arrays=False)
     fx_metrics()
     fx_linattn()
     fx_attn_layer()

@@ -494,6 +494,46 @@ def test_model_multiclass_fp32(golden_dir):
     assert worst <= 1e-2, worst
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_model_multiclass_128(golden_dir, dtype):
+    """BASELINE config 4 at its stated size: 128^3, 3 labels, the reference channel / ROI configuration, the multi-class step of
+    utils/utils_3D_multi_class.py:68-102 (CE + Dice_1 + Dice_2 weighted 10 / 1 / 2) against vectors from the reference's own model +
+    multi_criterions (tests/golden/make_golden.py multi128)"""
+    from lintransunet_amd import train
+    from lintransunet_amd import losses as L
+    G = np.load(os.path.join(golden_dir, 'model_multi128.npz'))
+    cfg = O_net.NetConfig(dim_output=3)
+    model = build(cfg, 900, dtype)
+    x = seedgen.seeded_volume((1, 1, 128, 128, 128), 901).to(DEV)
+    label = seedgen.seeded_label((1, 1, 128, 128, 128), 902, n_classes=3).to(DEV)
+    predict, masks = model(x)
+    specs = train.level_specs(5, ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2'), criterion_weight=[10, 1, 2])
+    totals, named = train.deep_supervision_loss(predict, masks, label, O_step.dynamic_weights(0), specs=specs)
+    torch.autograd.backward(totals, [torch.ones_like(t) for t in totals])
+    torch.cuda.synchronize()
+    total = sum(t.item() for t in totals)
+    d1 = L.DiceClassLoss()(predict.detach(), label).item()
+    d2 = L.DiceClassLoss2()(predict.detach(), label).item()
+    flat = predict.detach().cpu().flatten()[torch.from_numpy(G['out_idx'])]
+    if dtype == torch.float32:
+        assert rel_err(flat, G['out_sample']) <= 1e-3
+        assert abs(total - float(G['total'])) <= 1e-4 * abs(float(G['total']))
+        assert abs(d1 - float(G['dice1'])) <= 1e-4 and abs(d2 - float(G['dice2'])) <= 1e-4
+        lv = G['level_losses']
+        for lvl, vals in enumerate(named):
+            got = [vals[n].item() for n in ('CrossEntroLoss', 'DiceClassLoss', 'DiceClassLoss2')]
+            assert np.allclose(got, lv[lvl], rtol=1e-4, atol=1e-5), (lvl, got, lv[lvl])
+        norms = dict(zip(G['grad_keys'], G['grad_norms']))
+        sd = dict(model.named_parameters())
+        worst = max(abs(sd[k].grad.double().norm().item() - n) / max(n, 1e-3) for k, n in norms.items() if not exact_zero_grad(k))
+        assert worst <= 1e-2, worst
+    else:
+        print(f'[bf16 multi128] dice1 {d1:.6f} vs {float(G["dice1"]):.6f}, dice2 {d2:.6f} vs {float(G["dice2"]):.6f}, total {total:.5f} vs {float(G["total"]):.5f}')
+        assert abs(d1 - float(G['dice1'])) <= BF16_DICE_TOL_MOVED_BOX and abs(d2 - float(G['dice2'])) <= BF16_DICE_TOL_MOVED_BOX
+        assert abs(total - float(G['total'])) <= 1e-2 * abs(float(G['total']))
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
 def test_model_multiclass_bf16(golden_dir):
     """the 3-label configuration in bf16 storage (BASELINE config 4 runs it): 4C = 12 final-conv channels are padded to 16 for the
     bf16 GEMMs; outputs, losses and Dice stay within bf16 distance of the fp32 vectors generated by the reference"""
