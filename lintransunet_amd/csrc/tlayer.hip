@@ -195,11 +195,13 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
       const float4 b = *reinterpret_cast<const float4*>(ta.b1 + n);
       const uint2 uq = pack_quad(acc[0][4 * q] + b.x, acc[0][4 * q + 1] + b.y, acc[0][4 * q + 2] + b.z, acc[0][4 * q + 3] + b.w);
       const float4 uf = unpack_quad(uq);          // GELU of the bf16-rounded pre-activation, as the stand-alone kernel computes it
-      const float4 hv = drop4(dcg, (unsigned long long)((row * (2 * D) + n) >> 2),
-                              make_float4(gelu_erf(uf.x), gelu_erf(uf.y), gelu_erf(uf.z), gelu_erf(uf.w)));
+      float4 hv = uf;
+      if (!(ta.dbg & 2))
+        hv = drop4(dcg, (unsigned long long)((row * (2 * D) + n) >> 2),
+                   make_float4(gelu_erf(uf.x), gelu_erf(uf.y), gelu_erf(uf.z), gelu_erf(uf.w)));
       const uint2 hq = pack_quad(hv.x, hv.y, hv.z, hv.w);
       *reinterpret_cast<uint2*>(HB + li * LDH + n) = hq;
-      if (row < ta.M) {
+      if (row < ta.M && !(ta.dbg & 4)) {
         *reinterpret_cast<uint2*>(ta.u + row * (2 * D) + n) = uq;
         *reinterpret_cast<uint2*>(ta.h + row * (2 * D) + n) = hq;
       }
