@@ -45,51 +45,52 @@ struct TailArgs {
   float eps, p;
   uint64_t seed1, seedg, seed2;               // dropout sites: after the out projection, after GELU, after linear2
   const uint64_t* step;
-  int dbg;                // ablation (tools/bench_tail.py): 1 = weight operands are not loaded
+  int dbg;                // ablation (tools/bench_tail.py): 2 = no GELU / dropout arithmetic, 4 = u and h are not stored
 };
 
 __device__ __forceinline__ tl_bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(tl_bf16x8, v); }
 
-// One column tile of a GEMM stage: acc[g][..] = sum_k W[ct*32 + ..][k] X[(rg0+g)*32 + ..][k] (transposed product, see above).
+// One column tile of a GEMM stage: acc[..] = sum_k W[ct*32 + ..][k] X[..][k] (transposed product, see above).
 // X: LDS, bf16, row stride LDX elements; W: fragment order in global memory (served by L2: every workgroup streams the same
 // weights).  KS (reduction steps of 16) is a compile-time constant: the loop is fully unrolled around a rotating queue of U weight
-// fragments, so U loads stay in flight per wave all the time (a counted vmcnt per step instead of a drain per group of steps).
-template <int NRG, int KS>
-__device__ __forceinline__ void tl_tile(const uint16_t* __restrict__ W, int ct, int rg0, const uint16_t* Xl, int LDX, int lane,
-                                        f32x16 (&acc)[NRG], int dbg = 0) {
-  constexpr int U = KS < 8 ? KS : 8;
+// fragments.  The queue is filled by tl_issue - which the caller places BEFORE the global stores of the previous tile's epilogue:
+// gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued after a store cannot be waited for without also
+// waiting for the store's acknowledgement - and drained by tl_run.  Every step is fenced with sched_barrier: left alone, hipcc
+// sinks each weight load next to its MFMA (one load in flight per wave, an L2 round trip per MFMA).
+template <int KS>
+struct TlQueue {
+  static constexpr int U = KS < 8 ? KS : 8;
+  uint4 q[U];
+};
+
+template <int KS>
+__device__ __forceinline__ void tl_issue(const uint16_t* __restrict__ W, int ct, int lane, TlQueue<KS>& wq) {
+  const uint4* wp = reinterpret_cast<const uint4*>(W) + (size_t)ct * KS * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < TlQueue<KS>::U; ++i) wq.q[i] = wp[(size_t)i * 64];
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KS>
+__device__ __forceinline__ void tl_run(const uint16_t* __restrict__ W, int ct, const uint16_t* Xl, int LDX, int lane, TlQueue<KS>& wq,
+                                       f32x16& acc) {
+  constexpr int U = TlQueue<KS>::U;
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int g = 0; g < NRG; ++g)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const uint4* wp = reinterpret_cast<const uint4*>(W) + (size_t)ct * KS * 64 + lane;
-  const uint16_t* xr[NRG];
-#pragma unroll
-  for (int g = 0; g < NRG; ++g) xr[g] = Xl + ((rg0 + g) * 32 + li) * LDX + 8 * lh;
-  uint4 wq[U];
-  if (dbg & 1) {            // ablation: one fragment, re-used for every step
-    const uint4 w0 = wp[0];
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-#pragma unroll
-      for (int g = 0; g < NRG; ++g) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(xr[g] + k * 16);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w0), as_bf16x8(xv), acc[g], 0, 0, 0);
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < U; ++i) wq[i] = wp[(size_t)i * 64];
+  const uint16_t* xr = Xl + li * LDX + 8 * lh;
+  uint4 xv = *reinterpret_cast<const uint4*>(xr);
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    const uint4 w = wq[k % U];
-    if (k + U < KS) wq[k % U] = wp[(size_t)(k + U) * 64];
-#pragma unroll
-    for (int g = 0; g < NRG; ++g) {
-      const uint4 xv = *reinterpret_cast<const uint4*>(xr[g] + k * 16);
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w), as_bf16x8(xv), acc[g], 0, 0, 0);
-    }
+    const uint4 w = wq.q[k % U];
+    if (k + U < KS) wq.q[k % U] = wp[(size_t)(k + U) * 64];
+    uint4 xn = xv;
+    if (k + 1 < KS) xn = *reinterpret_cast<const uint4*>(xr + (k + 1) * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w), as_bf16x8(xv), acc, 0, 0, 0);
+    asm volatile("" : "+v"(acc));          // the MFMA has no side effect of its own: without this it floats past the fences
+    xv = xn;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -141,20 +142,35 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
 }
 
 template <int D>
-__global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const TailArgs ta) {
+__global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const TailArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;          // padded rows: +16 bytes rotates the banks from row to row
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
+  constexpr int NT1 = D / 32, NT2 = 2 * D / 32;       // column tiles of the d-wide and the 2d-wide stages
+  static_assert(NT1 == NW && NT2 == 2 * NW, "one d-wide tile and two 2d-wide tiles per wave");
+  constexpr int KS1 = D / 16, KS2 = 2 * D / 16;       // reduction steps over d and over 2d
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* XA = smem;                                // [32][LD]   a, later t1
   uint16_t* TB = XA + TL_ROWS * LD;                   // [32][LD]   out-projection result, later linear2 result
-  uint16_t* HB = TB + TL_ROWS * LD;                   // [32][LDH]  h
+  uint16_t* HB = TB + TL_ROWS * LD;                   // [32][LDH]  x (stage 0-2), then h
+  float* PB = reinterpret_cast<float*>(HB + TL_ROWS * LDH);   // bo[D] b1[2D] b2[D] g1[D] be1[D] g2[D] be2[D]: no parameter is loaded
+                                                              // from global memory behind a store (see tl_issue)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
   const DropCfg dc1 = make_drop(ta.p, ta.seed1, ta.step), dcg = make_drop(ta.p, ta.seedg, ta.step), dc2 = make_drop(ta.p, ta.seed2, ta.step);
 
-  // stage 0: the block's rows of the attention output -> XA, and of the residual input -> HB (free until stage 3): the residual
-  // is needed only by the LayerNorm of stage 2, but loading it there would expose one more global round trip per workgroup
+  // stage 0: the wave's out-projection weights first (they do not depend on the rows), then the block's rows of the attention
+  // output -> XA and of the residual input -> HB (free until stage 3: loading it in stage 2 would expose one more global round
+  // trip per workgroup), and the parameters -> PB
+  TlQueue<KS1> q1;
+  tl_issue<KS1>(ta.wo, wave, lane, q1);
+  {
+    static_assert(8 * D == 4 * NTHR, "one float4 of parameters per thread");
+    const int e = tid * 4;
+    const float* src = e < D ? ta.bo + e : e < 3 * D ? ta.b1 + (e - D) : e < 4 * D ? ta.b2 + (e - 3 * D) : e < 5 * D ? ta.g1 + (e - 4 * D)
+                       : e < 6 * D ? ta.be1 + (e - 5 * D) : e < 7 * D ? ta.g2 + (e - 6 * D) : ta.be2 + (e - 7 * D);
+    *reinterpret_cast<float4*>(PB + e) = *reinterpret_cast<const float4*>(src);
+  }
   for (int i = tid; i < TL_ROWS * (D / 8); i += NTHR) {
     const int r = i / (D / 8), c = (i % (D / 8)) * 8;
     uint4 v = make_uint4(0u, 0u, 0u, 0u), xv = v;
@@ -166,34 +182,36 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
     *reinterpret_cast<uint4*>(HB + r * LD + c) = xv;
   }
   __syncthreads();
+  const float* bo = PB, *b1 = PB + D, *b2 = PB + 3 * D, *g1 = PB + 4 * D, *be1 = PB + 5 * D, *g2 = PB + 6 * D, *be2 = PB + 7 * D;
 
-  constexpr int NT1 = D / 32, NT2 = 2 * D / 32;       // column tiles; wave w takes tiles w, w + NW, ..
   // stage 1: out projection -> TB (bf16)
-  for (int ct = wave; ct < NT1; ct += NW) {
-    f32x16 acc[1];
-    tl_tile<1, D / 16>(ta.wo, ct, 0, XA, LD, lane, acc, ta.dbg);
+  f32x16 acc;
+  tl_run<KS1>(ta.wo, wave, XA, LD, lane, q1, acc);
+  tl_issue<KS1>(ta.w1, wave, lane, q1);               // first linear1 tile: in flight across the LayerNorm stage
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = ct * 32 + 8 * q + 4 * lh;
-      const float4 b = *reinterpret_cast<const float4*>(ta.bo + n);
-      *reinterpret_cast<uint2*>(TB + li * LD + n) =
-          pack_quad(acc[0][4 * q] + b.x, acc[0][4 * q + 1] + b.y, acc[0][4 * q + 2] + b.z, acc[0][4 * q + 3] + b.w);
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int n = wave * 32 + 8 * q + 4 * lh;
+    const float4 b = *reinterpret_cast<const float4*>(bo + n);
+    *reinterpret_cast<uint2*>(TB + li * LD + n) = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
   }
   __syncthreads();
   // stage 2: z1 = x + drop(o), t1 = LN1(z1) -> XA (the attention rows are no longer needed)
-  tl_layernorm<D, true, true>(TB, HB, nullptr, XA, LD, ta.g1, ta.be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
+  tl_layernorm<D, true, true>(TB, HB, nullptr, XA, LD, g1, be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
   __syncthreads();
-  // stage 3: u = t1 W1^T + b1 (global), h = drop(gelu(u)) (global + HB)
-  for (int ct = wave; ct < NT2; ct += NW) {
-    f32x16 acc[1];
-    tl_tile<1, D / 16>(ta.w1, ct, 0, XA, LD, lane, acc, ta.dbg);
+  // stage 3: u = t1 W1^T + b1 (global), h = drop(gelu(u)) (global + HB); the wave's tiles are wave and wave + NW
+  TlQueue<KS2> q2;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ct = wave + t * NW;
+    tl_run<KS1>(ta.w1, ct, XA, LD, lane, q1, acc);
+    if (t == 0) tl_issue<KS1>(ta.w1, wave + NW, lane, q1);      // next operands before this tile's stores
+    else tl_issue<KS2>(ta.w2, wave, lane, q2);
     const long long row = row0 + li;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
-      const float4 b = *reinterpret_cast<const float4*>(ta.b1 + n);
-      const uint2 uq = pack_quad(acc[0][4 * q] + b.x, acc[0][4 * q + 1] + b.y, acc[0][4 * q + 2] + b.z, acc[0][4 * q + 3] + b.w);
+      const float4 b = *reinterpret_cast<const float4*>(b1 + n);
+      const uint2 uq = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
       const float4 uf = unpack_quad(uq);          // GELU of the bf16-rounded pre-activation, as the stand-alone kernel computes it
       float4 hv = uf;
       if (!(ta.dbg & 2))
@@ -209,20 +227,16 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_fwd_kernel(const Ta
   }
   __syncthreads();
   // stage 4: linear2 -> TB
-  for (int ct = wave; ct < NT1; ct += NW) {
-    f32x16 acc[1];
-    tl_tile<1, 2 * D / 16>(ta.w2, ct, 0, HB, LDH, lane, acc, ta.dbg);
+  tl_run<KS2>(ta.w2, wave, HB, LDH, lane, q2, acc);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = ct * 32 + 8 * q + 4 * lh;
-      const float4 b = *reinterpret_cast<const float4*>(ta.b2 + n);
-      *reinterpret_cast<uint2*>(TB + li * LD + n) =
-          pack_quad(acc[0][4 * q] + b.x, acc[0][4 * q + 1] + b.y, acc[0][4 * q + 2] + b.z, acc[0][4 * q + 3] + b.w);
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int n = wave * 32 + 8 * q + 4 * lh;
+    const float4 b = *reinterpret_cast<const float4*>(b2 + n);
+    *reinterpret_cast<uint2*>(TB + li * LD + n) = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
   }
   __syncthreads();
   // stage 5: z2 = t1 + drop(f), y = LN2(z2)
-  tl_layernorm<D, true, false>(TB, XA, nullptr, nullptr, LD, ta.g2, ta.be2, ta.z2, ta.y, ta.stat2, row0, ta.M, ta.eps, dc2, tid);
+  tl_layernorm<D, true, false>(TB, XA, nullptr, nullptr, LD, g2, be2, ta.z2, ta.y, ta.stat2, row0, ta.M, ta.eps, dc2, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ backward chain
@@ -264,11 +278,29 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
                                                  const float* __restrict__ gamma, uint16_t* dzl, uint16_t* dzg, uint16_t* drl,
                                                  uint16_t* drg, float* __restrict__ lnws, float* red, int LD, long long row0,
                                                  long long M, const DropCfg& dc, int tid) {
-  constexpr int G = D / 4, RPP = NTHR / G;
+  constexpr int G = D / 4, RPP = NTHR / G, NR = TL_ROWS / RPP;
   const int gl = tid % G, rgp = tid / G;
   const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
   float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int r = rgp; r < TL_ROWS; r += RPP) {
+  // all global operands of the thread's NR rows first (one round trip, not one per row), then the arithmetic
+  uint2 zq[NR], q1[NR], q2[NR];
+  float2 st[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const long long row = row0 + rgp + i * RPP;
+    zq[i] = q1[i] = q2[i] = make_uint2(0u, 0u);
+    st[i] = make_float2(0.f, 0.f);
+    if (row < M) {
+      zq[i] = *reinterpret_cast<const uint2*>(zg + row * D + gl * 4);
+      st[i] = *reinterpret_cast<const float2*>(stat + row * 2);
+      if (gg1 != nullptr) q1[i] = *reinterpret_cast<const uint2*>(gg1 + row * D + gl * 4);
+      if (gg2 != nullptr) q2[i] = *reinterpret_cast<const uint2*>(gg2 + row * D + gl * 4);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = rgp + i * RPP;
     const long long row = row0 + r;
     const bool ok = row < M;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -277,20 +309,16 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
       const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gl2_ + r * LD + gl * 4));
       g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
     }
-    if (gg1 != nullptr && ok) {
-      const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gg1 + row * D + gl * 4));
+    if (gg1 != nullptr) {
+      const float4 t = unpack_quad(q1[i]);
       g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
     }
-    if (gg2 != nullptr && ok) {
-      const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gg2 + row * D + gl * 4));
+    if (gg2 != nullptr) {
+      const float4 t = unpack_quad(q2[i]);
       g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
     }
-    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
-    float mean = 0.f, rstd = 0.f;
-    if (ok) {
-      zv = unpack_quad(*reinterpret_cast<const uint2*>(zg + row * D + gl * 4));
-      mean = stat[row * 2]; rstd = stat[row * 2 + 1];
-    }
+    const float4 zv = unpack_quad(zq[i]);
+    const float mean = st[i].x, rstd = st[i].y;
     const float gv[4] = {g.x, g.y, g.z, g.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w};
     float h[4] = {(zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd};
     float gg[4], s1 = 0.f, s2 = 0.f;
@@ -327,35 +355,59 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
 }
 
 template <int D>
-__global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const TailBwdArgs ta) {
+__global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const TailBwdArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
+  constexpr int NT1 = D / 32, NT2 = 2 * D / 32;
+  static_assert(NT1 == NW && NT2 == 2 * NW, "one d-wide tile and two 2d-wide tiles per wave");
+  constexpr int KS1 = D / 16, KS2 = 2 * D / 16;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* RB = smem;                                // [32][LD]   dr2, later dt1 and (in place) dr1
   uint16_t* ZB = RB + TL_ROWS * LD;                   // [32][LD]   dz2
   uint16_t* UB = ZB + TL_ROWS * LD;                   // [32][LDH]  du
-  float* red = reinterpret_cast<float*>(UB + TL_ROWS * LDH);      // [NTHR / (D/4)][2 D] column-sum scratch
+  float* red = reinterpret_cast<float*>(UB);          // [NTHR / (D/4)][2 D] column-sum scratch of the two LayerNorm stages: du is
+                                                      // not yet written in stage 0 and no longer needed in stage 3
+  static_assert((NTHR / (D / 4)) * 2 * D * sizeof(float) <= TL_ROWS * LDH * sizeof(uint16_t), "column-sum scratch fits in UB");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
+  const long long row = row0 + li;                    // the token whose outputs this lane owns in the GEMM stages
   const DropCfg dc1 = make_drop(ta.p, ta.seed1, ta.step), dcg = make_drop(ta.p, ta.seedg, ta.step), dc2 = make_drop(ta.p, ta.seed2, ta.step);
-  constexpr int NT1 = D / 32, NT2 = 2 * D / 32;
 
+  // the wave's first linear2^T operands and the pre-activations of its first tile: in flight across the LayerNorm stage
+  TlQueue<KS1> q1;
+  TlQueue<KS2> q2;
+  uint2 uq[4];
+  auto load_u = [&](int ct) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uq[q] = make_uint2(0u, 0u);
+      if (row < ta.M) uq[q] = *reinterpret_cast<const uint2*>(ta.u + row * (2 * D) + ct * 32 + 8 * q + 4 * lh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  tl_issue<KS1>(ta.w2t, wave, lane, q1);
   // stage 0: LayerNorm 2 backward: dz2 -> ZB, dr2 -> RB + global
   tl_layernorm_bwd<D, NTHR, false, false, true, false>(nullptr, nullptr, ta.dy, ta.dy2, ta.z2, ta.stat2, ta.g2, ZB, nullptr, RB, ta.dr2,
                                                       ta.lnws2, red, LD, row0, ta.M, dc2, tid);
+  load_u(wave);               // (not before the LayerNorm: its row operands need the registers)
   __syncthreads();
-  // stage 1: dh = dr2 W2, du = dh * dropout mask * gelu'(u) -> UB + global
-  for (int ct = wave; ct < NT2; ct += NW) {
-    f32x16 acc[1];
-    tl_tile<1, D / 16>(ta.w2t, ct, 0, RB, LD, lane, acc);
-    const long long row = row0 + li;
+  // stage 1: dh = dr2 W2, du = dh * dropout mask * gelu'(u) -> UB + global; the wave's tiles are wave and wave + NW
+  f32x16 acc;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ct = wave + t * NW;
+    tl_run<KS1>(ta.w2t, ct, RB, LD, lane, q1, acc);
+    uint2 uc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) uc[q] = uq[q];
+    if (t == 0) { tl_issue<KS1>(ta.w2t, wave + NW, lane, q1); load_u(wave + NW); }     // next operands before this tile's stores
+    else tl_issue<KS2>(ta.w1t, wave, lane, q2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
-      const float4 dh = unpack_quad(pack_quad(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]));   // bf16-rounded, as stored by the op-by-op path
-      float4 uf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < ta.M) uf = unpack_quad(*reinterpret_cast<const uint2*>(ta.u + row * (2 * D) + n));
+      const float4 dh = unpack_quad(pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));   // bf16-rounded, as stored by the op-by-op path
+      const float4 uf = unpack_quad(uc[q]);
       const float4 mk = dropmask4(dcg, (unsigned long long)((row * (2 * D) + n) >> 2));
       const uint2 dq = pack_quad(dh.x * mk.x * gelu_erf_grad(uf.x), dh.y * mk.y * gelu_erf_grad(uf.y), dh.z * mk.z * gelu_erf_grad(uf.z),
                                  dh.w * mk.w * gelu_erf_grad(uf.w));
@@ -365,14 +417,12 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const Ta
   }
   __syncthreads();
   // stage 2: dt1 = du W1 -> RB (dr2 is no longer needed)
-  for (int ct = wave; ct < NT1; ct += NW) {
-    f32x16 acc[1];
-    tl_tile<1, 2 * D / 16>(ta.w1t, ct, 0, UB, LDH, lane, acc);
+  tl_run<KS2>(ta.w1t, wave, UB, LDH, lane, q2, acc);
+  tl_issue<KS1>(ta.wot, wave, lane, q1);              // the out-projection^T operands: in flight across the LayerNorm stage
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = ct * 32 + 8 * q + 4 * lh;
-      *reinterpret_cast<uint2*>(RB + li * LD + n) = pack_quad(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]);
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int n = wave * 32 + 8 * q + 4 * lh;
+    *reinterpret_cast<uint2*>(RB + li * LD + n) = pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
   __syncthreads();
   // stage 3: LayerNorm 1 backward on dt1 + dz2: dz1 -> global, dr1 -> RB (in place) + global
@@ -380,16 +430,12 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256) tail_bwd_kernel(const Ta
                                                     red, LD, row0, ta.M, dc1, tid);
   __syncthreads();
   // stage 4: da = dr1 Wo
-  for (int ct = wave; ct < NT1; ct += NW) {
-    f32x16 acc[1];
-    tl_tile<1, D / 16>(ta.wot, ct, 0, RB, LD, lane, acc);
-    const long long row = row0 + li;
-    if (row < ta.M) {
+  tl_run<KS1>(ta.wot, wave, RB, LD, lane, q1, acc);
+  if (row < ta.M) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = ct * 32 + 8 * q + 4 * lh;
-        *reinterpret_cast<uint2*>(ta.da + row * D + n) = pack_quad(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]);
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int n = wave * 32 + 8 * q + 4 * lh;
+      *reinterpret_cast<uint2*>(ta.da + row * D + n) = pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
   }
 }
@@ -412,8 +458,7 @@ extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z
   ta.lnws2 = lnws2; ta.lnws1 = lnws1;
   ta.M = M; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
   const unsigned blocks = cdiv(M, TL_ROWS);
-  const int rpp = (d >= 256 ? 512 : 256) / (d / 4);
-  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)rpp * 2 * d * sizeof(float);
+  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t);
   if (d == 256) {
     static LtuDevOnce once;
     if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -443,7 +488,7 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   ta.M = M; ta.eps = eps; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
   ta.dbg = ltu_knob("LTU_TAIL_DBG", 0);
   const unsigned blocks = cdiv(M, TL_ROWS);
-  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t);
+  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)8 * d * sizeof(float);
   if (d == 256) {
     static LtuDevOnce once;
     if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

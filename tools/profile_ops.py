@@ -33,7 +33,8 @@ def main():
                                             dropout=0.3, act_dtype=act).to(dev).train()
     x, lab = bench.synthetic_batch(args.batch, (args.size,) * 3, 5, dev)
     weights = train.get_dynamic_weight(1)[0]
-    train.train_step(model, x, lab, weights)          # warm-up
+    reducer = train.GradReducer(model, unused=train.UNUSED_PARAMETERS)      # fused gradient buffers: the grouped weight-gradient path
+    train.train_step(model, x, lab, weights, reducer=reducer)          # warm-up
     torch.cuda.synchronize()
 
     stats = collections.defaultdict(lambda: [0, 0.0])
@@ -53,11 +54,10 @@ def main():
     _lib.call = timed
     import lintransunet_amd.ops as ops
     ops._lib.call = timed
-    for p in model.parameters():
-        p.grad = None
+    reducer.zero_grad()
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
-    train.train_step(model, x, lab, weights)
+    train.train_step(model, x, lab, weights, reducer=reducer)
     t1.record(); t1.synchronize()
     total = sum(v[1] for v in stats.values())
     print(f'step wall (serialised) {t0.elapsed_time(t1):.1f} ms; sum of timed C calls {total:.1f} ms; {sum(v[0] for v in stats.values())} calls')
@@ -66,6 +66,12 @@ def main():
         by_name[name] += v[1]
     for name, ms in sorted(by_name.items(), key=lambda kv: -kv[1]):
         print(f'  {ms:8.2f} ms  {name}')
+    # the four token transformers: calls whose integer arguments contain the level's token count (B * N) or per-sample count N
+    print('--- transformer levels (event-timed eager calls: each includes ~5 us of launch overhead)')
+    for M, N, d in ((114816, 57408, 128), (21504, 10752, 256), (8640, 4320, 256), (1024, 512, 256)):
+        ms = sum(v[1] for (name, ints), v in stats.items() if (M in ints or N in ints) and name.startswith(('ltu_linear', 'ltu_layer_tail', 'ltu_linattn', 'ltu_layernorm', 'ltu_gelu')))
+        n = sum(v[0] for (name, ints), v in stats.items() if (M in ints or N in ints) and name.startswith(('ltu_linear', 'ltu_layer_tail', 'ltu_linattn', 'ltu_layernorm', 'ltu_gelu')))
+        print(f'  {M:7d} tokens x {d}: {ms:6.2f} ms in {n} calls')
     print('--- by call signature')
     for (name, ints), (n, ms) in sorted(stats.items(), key=lambda kv: -kv[1][1])[:args.top]:
         print(f'{ms:8.3f} ms  x{n:<3d} {ms / n * 1e3:8.1f} us  {name} {ints}')
