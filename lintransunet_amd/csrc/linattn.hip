@@ -323,6 +323,95 @@ __global__ void __launch_bounds__(2 * D) linattn_apply(const T* __restrict__ qkv
   }
 }
 
+// bf16 storage, register-direct form of phase B.  Everything phase B does is per token with one constant 32x32 matrix per
+// (sample, head), so nothing has to meet in LDS: the product is formed transposed, outT[j][t] = sum_i ctx[i][j] qs[t][i]
+// (v_mfma_f32_32x32x16_bf16, A = ctx^T, B = qs^T), lane (t = li, lh) supplies and receives the SAME 16 channels of its token -
+// the four quads 8 q + 4 lh (q = 0..3) - because the k index of the MFMA may be any bijection of the channels as long as both
+// operands use it (k-step u, element e  <->  channel 8 (2u + e/4) + 4 lh + e%4) and that bijection is chosen to be the
+// accumulator's row pattern.  A wave therefore reads its token quads straight from global memory (8-byte loads, the four
+// quads of a token fill its 64-byte head segment; the heads of a row are the waves of the workgroup), applies the row softmax
+// with one cross-half exchange, issues two MFMAs and stores four quads: no LDS, no barrier, the next tile's loads in flight
+// during the arithmetic.  The fp32-LDS kernel above (4 barriers per 32-token tile, 240 workgroups) ran at 2 TB/s.
+__device__ __forceinline__ int la_chan(int u, int lh, int e) { return 8 * (2 * u + (e >> 2)) + 4 * lh + (e & 3); }
+
+template <int D>
+__global__ void __launch_bounds__(2 * D) linattn_apply_direct(const uint16_t* __restrict__ qkv, const float* __restrict__ ctx,
+                                                             uint16_t* __restrict__ out, float* __restrict__ qstat, int N, int tokb) {
+  constexpr int H = D / DK;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // wave = head
+  const int li = lane & 31, lh = lane >> 5;
+  // A operand: ctx^T[j = li][i = la_chan(u, lh, e)]
+  const float* cx = ctx + ((long long)b * H + wave) * 1024;
+  bf16x8 ca[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = cx[la_chan(u, lh, e) * 32 + li];
+    ca[u] = pack8(t);
+  }
+  const float rs = 0.17677669529663688110f;      // 1/sqrt(32)
+  const int n_begin = blockIdx.x * tokb, n_end = min(N, n_begin + tokb);
+  const uint16_t* qb = qkv + (long long)b * N * 3 * D + wave * DK + 4 * lh;
+  uint16_t* ob = out + (long long)b * N * D + wave * DK + 4 * lh;
+  uint2 nx[4];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nx[q] = make_uint2(0u, 0u);
+      if (n0 + li < n_end) nx[q] = *reinterpret_cast<const uint2*>(qb + (long long)(n0 + li) * 3 * D + 8 * q);
+    }
+  };
+  fetch(n_begin);
+  for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
+    uint2 cur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nx[q];
+    if (n0 + TOK < n_end) fetch(n0 + TOK);
+    float a[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[4 * q] = __uint_as_float(cur[q].x << 16); a[4 * q + 1] = __uint_as_float(cur[q].x & 0xffff0000u);
+      a[4 * q + 2] = __uint_as_float(cur[q].y << 16); a[4 * q + 3] = __uint_as_float(cur[q].y & 0xffff0000u);
+    }
+    float mx = a[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) mx = fmaxf(mx, a[s]);
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      a[s] = __expf(a[s] - mx);
+      sum += a[s];
+    }
+    sum += xhalf(sum);
+    const float inv = rs / sum;
+    const bool ok = n0 + li < n_end;
+    if (lh == 0 && ok) {
+      float* qs = qstat + (((long long)b * N + n0 + li) * H + wave) * 2;
+      *reinterpret_cast<float2*>(qs) = make_float2(mx, inv);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] *= inv;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], pack8(a), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], pack8(a + 8), acc, 0, 0, 0);
+    if (ok) {
+      uint16_t* o = ob + (long long)(n0 + li) * D;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 v;
+        v.x = pack_bf16x2(acc[4 * q], acc[4 * q + 1]);
+        v.y = pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3]);
+        *reinterpret_cast<uint2*>(o + 8 * q) = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward pass 1
 // dctxT[j][i] = sum_n dO[n][j] * qs[n][i];  same split structure as phase A.
 // part layout: [B][nsplit][H][1024 (accT[j][i])]
@@ -642,7 +731,15 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
       } else {
         hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part_ws, nsplit, nsplit, nullptr, colstats, ctx, H, 1);
       }
-      hipLaunchKernelGGL((linattn_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), 0, st, (const T*)qkv, ctx, (T*)out, qstat, N, tokb);
+      if constexpr (IsBf16<T>::value && D >= 64) {
+        // register-direct form: a wave per (head, token chunk); ~LTU_LA_APPLY_WAVES waves in flight
+        const long long tiles = (long long)B * cdiv(N, TOK);
+        const long long tpw = cdiv(tiles * (D / DK), (long long)ltu_knob_pos("LTU_LA_APPLY_WAVES", 8192));
+        const int tokd = (int)(tpw < 1 ? 1 : tpw) * TOK;
+        hipLaunchKernelGGL((linattn_apply_direct<D>), dim3(cdiv(N, tokd), B), dim3(2 * D), 0, st, (const uint16_t*)qkv, ctx, (uint16_t*)out, qstat, N, tokd);
+      } else {
+        hipLaunchKernelGGL((linattn_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), 0, st, (const T*)qkv, ctx, (T*)out, qstat, N, tokb);
+      }
     });
   });
   return ltu_check_launch();

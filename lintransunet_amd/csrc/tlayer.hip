@@ -198,30 +198,44 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   // stage 2: z1 = x + drop(o), t1 = LN1(z1) -> XA (the attention rows are no longer needed)
   tl_layernorm<D, true, true>(TB, HB, nullptr, XA, LD, g1, be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
   __syncthreads();
-  // stage 3: u = t1 W1^T + b1 (global), h = drop(gelu(u)) (global + HB); the wave's tiles are wave and wave + NW
+  // stage 3a: u = t1 W1^T + b1 -> HB (bf16); the wave's tiles are wave and wave + NW
   TlQueue<KS2> q2;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wave + t * NW;
     tl_run<KS1>(ta.w1, ct, XA, LD, lane, q1, acc);
-    if (t == 0) tl_issue<KS1>(ta.w1, wave + NW, lane, q1);      // next operands before this tile's stores
-    else tl_issue<KS2>(ta.w2, wave, lane, q2);
-    const long long row = row0 + li;
+    if (t == 0) tl_issue<KS1>(ta.w1, wave + NW, lane, q1);
+    else tl_issue<KS2>(ta.w2, wave, lane, q2);        // linear2 operands: requested before any store of stage 3b
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
       const float4 b = *reinterpret_cast<const float4*>(b1 + n);
-      const uint2 uq = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
-      const float4 uf = unpack_quad(uq);          // GELU of the bf16-rounded pre-activation, as the stand-alone kernel computes it
-      float4 hv = uf;
-      if (!(ta.dbg & 2))
-        hv = drop4(dcg, (unsigned long long)((row * (2 * D) + n) >> 2),
-                   make_float4(gelu_erf(uf.x), gelu_erf(uf.y), gelu_erf(uf.z), gelu_erf(uf.w)));
-      const uint2 hq = pack_quad(hv.x, hv.y, hv.z, hv.w);
-      *reinterpret_cast<uint2*>(HB + li * LDH + n) = hq;
+      *reinterpret_cast<uint2*>(HB + li * LDH + n) = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
+    }
+  }
+  __syncthreads();
+  // stage 3b: row-contiguous pass over the block: u -> global, h = drop(gelu(u)) -> global and (in place) HB.  The accumulator
+  // layout gives a lane one token, i.e. a wave store would touch 32 rows with 16 bytes each; here a wave writes whole 512-byte
+  // or 1 KiB row segments (the vector L1 works per line: bytes per line, not bytes, set the store rate).
+  {
+    constexpr int CPR = 2 * D / 8;                    // 16-byte chunks per row
+    for (int i = tid; i < TL_ROWS * CPR; i += NTHR) {
+      const int r = i / CPR, c = (i % CPR) * 8;
+      const long long row = row0 + r;
+      const uint4 uv = *reinterpret_cast<const uint4*>(HB + r * LDH + c);
+      const float4 u0 = unpack_quad(make_uint2(uv.x, uv.y)), u1 = unpack_quad(make_uint2(uv.z, uv.w));
+      float4 h0 = u0, h1 = u1;
+      if (!(ta.dbg & 2)) {
+        const unsigned long long g4 = (unsigned long long)((row * (2 * D) + c) >> 2);
+        h0 = drop4(dcg, g4, make_float4(gelu_erf(u0.x), gelu_erf(u0.y), gelu_erf(u0.z), gelu_erf(u0.w)));
+        h1 = drop4(dcg, g4 + 1, make_float4(gelu_erf(u1.x), gelu_erf(u1.y), gelu_erf(u1.z), gelu_erf(u1.w)));
+      }
+      const uint2 a0 = pack_quad(h0.x, h0.y, h0.z, h0.w), a1 = pack_quad(h1.x, h1.y, h1.z, h1.w);
+      const uint4 hv = make_uint4(a0.x, a0.y, a1.x, a1.y);
+      *reinterpret_cast<uint4*>(HB + r * LDH + c) = hv;
       if (row < ta.M && !(ta.dbg & 4)) {
-        *reinterpret_cast<uint2*>(ta.u + row * (2 * D) + n) = uq;
-        *reinterpret_cast<uint2*>(ta.h + row * (2 * D) + n) = hq;
+        *reinterpret_cast<uint4*>(ta.u + row * (2 * D) + c) = uv;
+        *reinterpret_cast<uint4*>(ta.h + row * (2 * D) + c) = hv;
       }
     }
   }
@@ -371,49 +385,58 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
-  const long long row = row0 + li;                    // the token whose outputs this lane owns in the GEMM stages
   const DropCfg dc1 = make_drop(ta.p, ta.seed1, ta.step), dcg = make_drop(ta.p, ta.seedg, ta.step), dc2 = make_drop(ta.p, ta.seed2, ta.step);
 
-  // the wave's first linear2^T operands and the pre-activations of its first tile: in flight across the LayerNorm stage
+  // the wave's first linear2^T operands: in flight across the LayerNorm stage
   TlQueue<KS1> q1;
   TlQueue<KS2> q2;
-  uint2 uq[4];
-  auto load_u = [&](int ct) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uq[q] = make_uint2(0u, 0u);
-      if (row < ta.M) uq[q] = *reinterpret_cast<const uint2*>(ta.u + row * (2 * D) + ct * 32 + 8 * q + 4 * lh);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
   tl_issue<KS1>(ta.w2t, wave, lane, q1);
   // stage 0: LayerNorm 2 backward: dz2 -> ZB, dr2 -> RB + global
   tl_layernorm_bwd<D, NTHR, false, false, true, false>(nullptr, nullptr, ta.dy, ta.dy2, ta.z2, ta.stat2, ta.g2, ZB, nullptr, RB, ta.dr2,
                                                       ta.lnws2, red, LD, row0, ta.M, dc2, tid);
-  load_u(wave);               // (not before the LayerNorm: its row operands need the registers)
+  // the thread's 16-byte chunks of the pre-activations u for stage 1b (row-contiguous): in flight across stage 1a
+  constexpr int CPR2 = 2 * D / 8, NCH2 = TL_ROWS * CPR2 / NTHR;
+  uint4 uch[NCH2];
+#pragma unroll
+  for (int j = 0; j < NCH2; ++j) {
+    const int i = tid + j * NTHR, r = i / CPR2, c = (i % CPR2) * 8;
+    uch[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (row0 + r < ta.M) uch[j] = *reinterpret_cast<const uint4*>(ta.u + (row0 + r) * (2 * D) + c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  // stage 1: dh = dr2 W2, du = dh * dropout mask * gelu'(u) -> UB + global; the wave's tiles are wave and wave + NW
+  // stage 1a: dh = dr2 W2 -> UB (bf16, as stored by the op-by-op path); the wave's tiles are wave and wave + NW
   f32x16 acc;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wave + t * NW;
     tl_run<KS1>(ta.w2t, ct, RB, LD, lane, q1, acc);
-    uint2 uc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) uc[q] = uq[q];
-    if (t == 0) { tl_issue<KS1>(ta.w2t, wave + NW, lane, q1); load_u(wave + NW); }     // next operands before this tile's stores
-    else tl_issue<KS2>(ta.w1t, wave, lane, q2);
+    if (t == 0) tl_issue<KS1>(ta.w2t, wave + NW, lane, q1);
+    else tl_issue<KS2>(ta.w1t, wave, lane, q2);       // linear1^T operands: requested before any store of stage 1b
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
-      const float4 dh = unpack_quad(pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));   // bf16-rounded, as stored by the op-by-op path
-      const float4 uf = unpack_quad(uc[q]);
-      const float4 mk = dropmask4(dcg, (unsigned long long)((row * (2 * D) + n) >> 2));
-      const uint2 dq = pack_quad(dh.x * mk.x * gelu_erf_grad(uf.x), dh.y * mk.y * gelu_erf_grad(uf.y), dh.z * mk.z * gelu_erf_grad(uf.z),
-                                 dh.w * mk.w * gelu_erf_grad(uf.w));
-      *reinterpret_cast<uint2*>(UB + li * LDH + n) = dq;
-      if (row < ta.M) *reinterpret_cast<uint2*>(ta.du + row * (2 * D) + n) = dq;
+      *reinterpret_cast<uint2*>(UB + li * LDH + n) = pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
+  }
+  __syncthreads();
+  // stage 1b: row-contiguous pass: du = dh * dropout mask * gelu'(u) -> global and (in place) UB (see stage 3b of the forward kernel)
+#pragma unroll
+  for (int j = 0; j < NCH2; ++j) {
+    const int i = tid + j * NTHR, r = i / CPR2, c = (i % CPR2) * 8;
+    const long long rw = row0 + r;
+    const uint4 dv = *reinterpret_cast<const uint4*>(UB + r * LDH + c);
+    const float4 d0 = unpack_quad(make_uint2(dv.x, dv.y)), d1 = unpack_quad(make_uint2(dv.z, dv.w));
+    const float4 u0 = unpack_quad(make_uint2(uch[j].x, uch[j].y)), u1 = unpack_quad(make_uint2(uch[j].z, uch[j].w));
+    const unsigned long long g4 = (unsigned long long)((rw * (2 * D) + c) >> 2);
+    const float4 m0 = dropmask4(dcg, g4), m1 = dropmask4(dcg, g4 + 1);
+    const uint2 a0 = pack_quad(d0.x * m0.x * gelu_erf_grad(u0.x), d0.y * m0.y * gelu_erf_grad(u0.y), d0.z * m0.z * gelu_erf_grad(u0.z),
+                               d0.w * m0.w * gelu_erf_grad(u0.w));
+    const uint2 a1 = pack_quad(d1.x * m1.x * gelu_erf_grad(u1.x), d1.y * m1.y * gelu_erf_grad(u1.y), d1.z * m1.z * gelu_erf_grad(u1.z),
+                               d1.w * m1.w * gelu_erf_grad(u1.w));
+    const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
+    *reinterpret_cast<uint4*>(UB + r * LDH + c) = dq;
+    if (rw < ta.M) *reinterpret_cast<uint4*>(ta.du + rw * (2 * D) + c) = dq;
   }
   __syncthreads();
   // stage 2: dt1 = du W1 -> RB (dr2 is no longer needed)
@@ -429,13 +452,19 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const
   tl_layernorm_bwd<D, NTHR, true, true, false, true>(RB, ZB, nullptr, nullptr, ta.z1, ta.stat1, ta.g1, nullptr, ta.dz1, RB, ta.dr1, ta.lnws1,
                                                     red, LD, row0, ta.M, dc1, tid);
   __syncthreads();
-  // stage 4: da = dr1 Wo
+  // stage 4: da = dr1 Wo -> ZB (dz2 is no longer needed), then row-contiguous stores
   tl_run<KS1>(ta.wot, wave, RB, LD, lane, q1, acc);
-  if (row < ta.M) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = wave * 32 + 8 * q + 4 * lh;
-      *reinterpret_cast<uint2*>(ta.da + row * D + n) = pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  for (int q = 0; q < 4; ++q) {
+    const int n = wave * 32 + 8 * q + 4 * lh;
+    *reinterpret_cast<uint2*>(ZB + li * LD + n) = pack_quad(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = D / 8;
+    for (int i = tid; i < TL_ROWS * CPR; i += NTHR) {
+      const int r = i / CPR, c = (i % CPR) * 8;
+      if (row0 + r < ta.M) *reinterpret_cast<uint4*>(ta.da + (row0 + r) * D + c) = *reinterpret_cast<const uint4*>(ZB + r * LD + c);
     }
   }
 }
