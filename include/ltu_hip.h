@@ -212,7 +212,8 @@ int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int 
 int ltu_linattn_splits(int B, int N);
 int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws, int B, int N,
                     int d, int dtype, ltu_stream_t s);
-/* dqkv [B*N][3d] from dout [B*N][d]; dctx [B*H][32][32] and tvec [B*H][32] are scratch outputs */
+/* dqkv [B*N][3d] from dout [B*N][d]; dctx [B*H][32][32] is a scratch output; tvec [B*H][32] is reserved (may be NULL: the term it
+ * held is formed inside the per-token kernel since round 2) */
 int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const float* colstats, const float* qstat,
                     void* dqkv, float* dctx, float* tvec, float* part_ws, int B, int N, int d, int dtype, ltu_stream_t s);
 

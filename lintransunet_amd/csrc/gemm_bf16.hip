@@ -600,22 +600,26 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
 // Workgroups [0, wblocks) fold weights: each owns 64 groups of 4 consecutive k (16-byte loads; K and kpad are multiples of 4), its
 // 4 thread groups sum every 4th split with independent loads in flight and combine through LDS; the remaining workgroups fold the
 // bias rows.  The scatter into the PyTorch conv layout ([Co][Ci][27]: stride-27 writes) is per element.
-__device__ __forceinline__ void wgrad_reduce_put(const WGradArgs& wa, int n, int k, float v) {
+// destination of element (n, k) in the PyTorch layouts (nullptr: padding).  The fold reads the old values of its four
+// destinations FIRST, together with the partials: a `+=` at the end is a read round trip behind the previous element's store (and
+// no-return float atomics, tried instead, were 1.4x slower here: four dword atomics per lane against one round of loads).
+__device__ __forceinline__ float* wgrad_reduce_dst(const WGradArgs& wa, int n, int k) {
   const IGemmArgs& g = wa.g;
   if (wa.t_co) {
     const int slot = k / g.C, c = k - slot * g.C;
-    if (n < wa.t_co && c < wa.t_ci) wa.dw[((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
-    else if (wa.dw2 != nullptr && n >= wa.n0_2 && n - wa.n0_2 < wa.t_co2 && c < wa.t_ci)
-      wa.dw2[((long long)(n - wa.n0_2) * wa.t_ci + c) * 27 + g.tap[slot].wt] += v;
-  } else if (wa.nseg_w > 1) {
-    const int nper = g.N / wa.nseg_w, seg = n / nper;
-    wa.dwseg[seg][(long long)(n - seg * nper) * g.K + k] += v;
-  } else {
-    const int slot = k / g.C, c = k - slot * g.C;
-    wa.dw[(long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c] += v;
+    if (n < wa.t_co && c < wa.t_ci) return wa.dw + ((long long)n * wa.t_ci + c) * 27 + g.tap[slot].wt;
+    if (wa.dw2 != nullptr && n >= wa.n0_2 && n - wa.n0_2 < wa.t_co2 && c < wa.t_ci)
+      return wa.dw2 + ((long long)(n - wa.n0_2) * wa.t_ci + c) * 27 + g.tap[slot].wt;
+    return nullptr;
   }
+  if (wa.nseg_w > 1) {
+    const int nper = g.N / wa.nseg_w, seg = n / nper;
+    return wa.dwseg[seg] + (long long)(n - seg * nper) * g.K + k;
+  }
+  const int slot = k / g.C, c = k - slot * g.C;
+  return wa.dw + (long long)n * g.wrow + (long long)g.tap[slot].wt * g.C + c;
 }
-// SG = thread groups that share the splits of one output quad (256 / SG quads per workgroup): 4 for large gradients, 16 for the
+// SG = thread groups that share the splits of one output quad (256 / SG quads per workgroup): 4 for large gradients, 16 / 64 for the
 // small ones with hundreds of splits (conv weights of the first levels: a few thousand elements), which would otherwise be a
 // grid of a few dozen workgroups walking long serial loops.
 template <int SG>
@@ -630,9 +634,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
     const long long q = (long long)blockIdx.x * NQ + l64;
     const int n = (int)(q / kq), k = (int)(q - (long long)n * kq) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    float old[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < g.N) {
+      if (grp == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dst[e] = wgrad_reduce_dst(wa, n, k + e);
+          if (dst[e] != nullptr) old[e] = *dst[e];
+        }
+      }
       const float* p = wa.part + (long long)n * wa.kpad + k;
-#pragma unroll 4
+#pragma unroll 8
       for (int z = grp; z < nsplit; z += SG) {
         const float4 v = *reinterpret_cast<const float4*>(p + z * zs);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -646,17 +659,27 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
       const float4 v = red[r][l64];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    wgrad_reduce_put(wa, n, k, acc.x);
-    wgrad_reduce_put(wa, n, k + 1, acc.y);
-    wgrad_reduce_put(wa, n, k + 2, acc.z);
-    wgrad_reduce_put(wa, n, k + 3, acc.w);
+    const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (dst[e] != nullptr) *dst[e] = old[e] + av[e];
     return;
   }
-  const int n = ((int)blockIdx.x - wblocks) * 256 + (int)threadIdx.x;
-  if (n >= g.N) return;
+  // bias rows: 16 outputs per workgroup, 16 thread groups share the splits (one thread per output would walk hundreds of splits
+  // as a serial chain of dependent round trips: that chain, not the weight fold, set this kernel's duration)
+  __shared__ float bred[16][16];
+  const int bl = threadIdx.x & 15, bg = threadIdx.x >> 4;
+  const int n = ((int)blockIdx.x - wblocks) * 16 + bl;
   float v = 0.f;
-#pragma unroll 4
-  for (int z = 0; z < nsplit; ++z) v += wa.bpart[(long long)z * wa.npad + n];
+  if (n < g.N) {
+#pragma unroll 8
+    for (int z = bg; z < nsplit; z += 16) v += wa.bpart[(long long)z * wa.npad + n];
+  }
+  bred[bg][bl] = v;
+  __syncthreads();
+  if (bg != 0 || n >= g.N) return;
+#pragma unroll
+  for (int r = 1; r < 16; ++r) v += bred[r][bl];
   if (wa.nseg_w > 1) {
     const int nper = g.N / wa.nseg_w, seg = n / nper;
     if (wa.dbseg[seg]) wa.dbseg[seg][n - seg * nper] += v;
@@ -670,12 +693,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WGradArgs wa, i
 int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st) {
   if (wa.g.K % 4 || wa.kpad % 4) return LTU_E_SHAPE;
   const long long quads = (long long)wa.g.N * (wa.g.K / 4);
-  if (quads < 256 * 64 && nsplit >= 32) {
+  if (quads < 256 * 16 && nsplit >= 128) {          // a few thousand elements under hundreds of splits (first-level conv weights)
+    const int wblocks = (int)((quads + 3) / 4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)(wblocks + (wa.g.N + 15) / 16)), dim3(256), 0, st, wa, nsplit, wblocks);
+  } else if (quads < 256 * 64 && nsplit >= 32) {
     const int wblocks = (int)((quads + 15) / 16);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)(wblocks + (wa.g.N + 255) / 256)), dim3(256), 0, st, wa, nsplit, wblocks);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)(wblocks + (wa.g.N + 15) / 16)), dim3(256), 0, st, wa, nsplit, wblocks);
   } else {
     const int wblocks = (int)((quads + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(wblocks + (wa.g.N + 255) / 256)), dim3(256), 0, st, wa, nsplit, wblocks);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(wblocks + (wa.g.N + 15) / 16)), dim3(256), 0, st, wa, nsplit, wblocks);
   }
   return ltu_check_launch();
 }

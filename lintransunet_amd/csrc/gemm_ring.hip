@@ -532,8 +532,15 @@ __global__ void __launch_bounds__(256) wgroup_fold_kernel(const WFoldArgs fa) {
   if (local < jb.wblocks) {
     const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long e = ((long long)local * 64 + lane64) * 4;          // first of 4 consecutive k of one row n (K % 128 == 0)
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), cur = acc;
+    float* o = nullptr;
     if (e < nk) {
+      if (grp == 0) {                    // the old gradient values: requested with the partials, not behind them
+        const int n = (int)(e / jb.K), k = (int)(e - (long long)n * jb.K);
+        const int seg = n / nper;
+        o = (seg == 0 ? jb.out[0] : (seg == 1 ? jb.out[1] : jb.out[2])) + (long long)(n - seg * nper) * jb.K + k;
+        cur = *reinterpret_cast<const float4*>(o);
+      }
       const float* p = jb.part + e;
 #pragma unroll 4
       for (int sp = grp; sp < jb.nsplit; sp += 4) {
@@ -549,20 +556,24 @@ __global__ void __launch_bounds__(256) wgroup_fold_kernel(const WFoldArgs fa) {
         const float4 v = red[q][lane64];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-      const int n = (int)(e / jb.K), k = (int)(e - (long long)n * jb.K);
-      const int seg = n / nper;
-      float* o = (seg == 0 ? jb.out[0] : (seg == 1 ? jb.out[1] : jb.out[2])) + (long long)(n - seg * nper) * jb.K + k;
-      float4 cur = *reinterpret_cast<float4*>(o);
       cur.x += acc.x; cur.y += acc.y; cur.z += acc.z; cur.w += acc.w;
       *reinterpret_cast<float4*>(o) = cur;
     }
   } else {
-    const int n = (local - jb.wblocks) * 256 + (int)threadIdx.x;
+    // bias rows: 64 outputs per workgroup, the 4 thread groups share the splits (no serial walk over all of them)
+    const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = (local - jb.wblocks) * 64 + lane64;
+    float a = 0.f;
     if (n < jb.N) {
       const float* bp = jb.part + (long long)jb.nsplit * nk + n;
-      float a = 0.f;
-#pragma unroll 4
-      for (int sp = 0; sp < jb.nsplit; ++sp) a += bp[(long long)sp * jb.N];
+#pragma unroll 8
+      for (int sp = grp; sp < jb.nsplit; sp += 4) a += bp[(long long)sp * jb.N];
+    }
+    float* redf = reinterpret_cast<float*>(red);
+    if (grp > 0) redf[(grp - 1) * 64 + lane64] = a;
+    __syncthreads();
+    if (grp == 0 && n < jb.N) {
+      a += redf[lane64] + redf[64 + lane64] + redf[128 + lane64];
       const int seg = n / nper;
       float* o = seg == 0 ? jb.outb[0] : (seg == 1 ? jb.outb[1] : jb.outb[2]);
       if (o != nullptr) o[n - seg * nper] += a;
@@ -639,7 +650,7 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
     for (int s = 0; s < 3; ++s) { f.out[s] = s < jobs[i].nw ? jobs[i].dw[s] : nullptr; f.outb[s] = s < jobs[i].nw ? jobs[i].db[s] : nullptr; }
     f.blk_begin = fblocks;
     f.wblocks = (int)(((long long)j.N * j.K / 4 + 63) / 64);
-    fblocks += f.wblocks + (j.N + 255) / 256;
+    fblocks += f.wblocks + (j.N + 63) / 64;
   }
   constexpr int smem_bytes = TN_RING * 2 * 32 * 128 * 2;
   static LtuDevOnce attr_once;

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
 //   level 1: grid (ngroups, B*H): partials [g*group, (g+1)*group) of `part` -> one partial in `part2`
 //   level 2: grid (1, B*H) with final != 0: the ngroups partials -> colmax, colsum, ctx (normalised)
 // block 1024: thread (i = tid&31, j = tid>>5) (coalesced over accT[j][i]).
+#define KVC_GROUP 16
 __global__ void __launch_bounds__(1024) linattn_kv_combine(const float* __restrict__ part, int nsplit, int group,
                                                            float* __restrict__ part2, float* __restrict__ stats,
                                                            float* __restrict__ ctx, int H, int final) {
@@ -210,16 +211,27 @@ __global__ void __launch_bounds__(1024) linattn_kv_combine(const float* __restri
   const float* p0 = part + ((long long)b * nsplit * H + h) * PART_STRIDE;
   const long long sstride = (long long)H * PART_STRIDE;
   const int s0 = g * group, s1 = min(nsplit, s0 + group);
-  float m = -INFINITY;
-#pragma unroll 4
-  for (int s = s0; s < s1; ++s) m = fmaxf(m, p0[s * sstride + i]);
+  // at most KVC_GROUP splits per workgroup: every load of a pass is issued before the first use (two round trips in all, not one
+  // per four splits)
+  float mv[KVC_GROUP];
+#pragma unroll
+  for (int q = 0; q < KVC_GROUP; ++q) mv[q] = s0 + q < s1 ? p0[(s0 + q) * sstride + i] : -INFINITY;
+  float m = mv[0];
+#pragma unroll
+  for (int q = 1; q < KVC_GROUP; ++q) m = fmaxf(m, mv[q]);
+  float sv[KVC_GROUP], av[KVC_GROUP];
+#pragma unroll
+  for (int q = 0; q < KVC_GROUP; ++q) {
+    const float* p = p0 + (s0 + q) * sstride;
+    sv[q] = s0 + q < s1 ? p[32 + i] : 0.f;
+    av[q] = s0 + q < s1 ? p[64 + j * 32 + i] : 0.f;
+  }
   float ssum = 0.f, a = 0.f;
-#pragma unroll 4
-  for (int s = s0; s < s1; ++s) {
-    const float* p = p0 + s * sstride;
-    const float f = __expf(p[i] - m);
-    ssum += p[32 + i] * f;
-    a += p[64 + j * 32 + i] * f;
+#pragma unroll
+  for (int q = 0; q < KVC_GROUP; ++q) {
+    const float f = __expf(mv[q] - m);          // exp(-inf) = 0 for the absent splits
+    ssum += sv[q] * f;
+    a += av[q] * f;
   }
   if (final) {
     ctx[(long long)bh * 1024 + i * 32 + j] = a / ssum;
@@ -323,91 +335,116 @@ __global__ void __launch_bounds__(2 * D) linattn_apply(const T* __restrict__ qkv
   }
 }
 
-// bf16 storage, register-direct form of phase B.  Everything phase B does is per token with one constant 32x32 matrix per
-// (sample, head), so nothing has to meet in LDS: the product is formed transposed, outT[j][t] = sum_i ctx[i][j] qs[t][i]
-// (v_mfma_f32_32x32x16_bf16, A = ctx^T, B = qs^T), lane (t = li, lh) supplies and receives the SAME 16 channels of its token -
-// the four quads 8 q + 4 lh (q = 0..3) - because the k index of the MFMA may be any bijection of the channels as long as both
-// operands use it (k-step u, element e  <->  channel 8 (2u + e/4) + 4 lh + e%4) and that bijection is chosen to be the
-// accumulator's row pattern.  A wave therefore reads its token quads straight from global memory (8-byte loads, the four
-// quads of a token fill its 64-byte head segment; the heads of a row are the waves of the workgroup), applies the row softmax
-// with one cross-half exchange, issues two MFMAs and stores four quads: no LDS, no barrier, the next tile's loads in flight
-// during the arithmetic.  The fp32-LDS kernel above (4 barriers per 32-token tile, 240 workgroups) ran at 2 TB/s.
-__device__ __forceinline__ int la_chan(int u, int lh, int e) { return 8 * (2 * u + (e >> 2)) + 4 * lh + (e & 3); }
+// bf16 storage, wave-private form of phase B.  Everything phase B does is per token with one constant 32x32 matrix per
+// (sample, head), so no two waves have to meet: a wave owns 32 tokens x 4 heads (256 bytes of every token row), stages them in
+// its own 8.5 KB of LDS with row-contiguous 16-byte loads (a wave instruction covers 4 whole row segments: the vector L1 works
+// per line, and a lane-per-token access would touch 32 lines for 512 bytes), and walks the 4 heads: lane (t = li, lh) reads 16
+// channels of its token, row softmax with one cross-half exchange, the product transposed - outT[j][t] = sum_i ctx[i][j] qs[t][i],
+// A = ctx^T held in registers for all 4 heads - so that the lane receives quads of its own token, which go back into the tile in
+// place; the tile leaves as it came, in whole row segments.  No barrier (LDS operations of one wave execute in order), the next
+// tile's loads in flight during the arithmetic.  The fp32-LDS kernel above (4 barriers per tile, 240 workgroups) ran at 2 TB/s.
+#define LAW_HEADS 4                              // heads per wave tile
+#define LAW_LD (LAW_HEADS * DK + 8)              // LDS row stride in bf16 elements (272 bytes: 16-byte aligned, banks rotate by 4 per row)
 
 template <int D>
-__global__ void __launch_bounds__(2 * D) linattn_apply_direct(const uint16_t* __restrict__ qkv, const float* __restrict__ ctx,
-                                                             uint16_t* __restrict__ out, float* __restrict__ qstat, int N, int tokb) {
-  constexpr int H = D / DK;
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // wave = head
+__global__ void __launch_bounds__(256) linattn_apply_rows(const uint16_t* __restrict__ qkv, const float* __restrict__ ctx,
+                                                         uint16_t* __restrict__ out, float* __restrict__ qstat, int N, int tiles_per_wave) {
+  constexpr int H = D / DK, CG = H / LAW_HEADS;          // column groups of 4 heads per token row
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * TOK * LAW_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  // A operand: ctx^T[j = li][i = la_chan(u, lh, e)]
-  const float* cx = ctx + ((long long)b * H + wave) * 1024;
-  bf16x8 ca[2];
+  uint16_t* tile = smem + wave * TOK * LAW_LD;
+  // work item of the wave: (sample b, column group cg, first tile)
+  const int b = blockIdx.y;
+  const int gw = blockIdx.x * 4 + wave;                  // global wave index within the sample
+  const int cg = gw % CG;
+  const int n_begin = (gw / CG) * tiles_per_wave * TOK;
+  const int n_end = min(N, n_begin + tiles_per_wave * TOK);
+  if (n_begin >= N) return;
+  // A operands: ctx^T[j = li][i = 16 lh + 8 u + e] of the 4 heads
+  bf16x8 ca[LAW_HEADS][2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    float t[8];
+  for (int hh = 0; hh < LAW_HEADS; ++hh) {
+    const float* cx = ctx + ((long long)b * H + cg * LAW_HEADS + hh) * 1024;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = cx[la_chan(u, lh, e) * 32 + li];
-    ca[u] = pack8(t);
+    for (int u = 0; u < 2; ++u) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = cx[(16 * lh + 8 * u + e) * 32 + li];
+      ca[hh][u] = pack8(t);
+    }
   }
   const float rs = 0.17677669529663688110f;      // 1/sqrt(32)
-  const int n_begin = blockIdx.x * tokb, n_end = min(N, n_begin + tokb);
-  const uint16_t* qb = qkv + (long long)b * N * 3 * D + wave * DK + 4 * lh;
-  uint16_t* ob = out + (long long)b * N * D + wave * DK + 4 * lh;
-  uint2 nx[4];
+  // row-contiguous chunk map: instruction p covers rows 4p .. 4p+3, 16 lanes x 16 bytes each
+  const int cr = lane >> 4, cc = (lane & 15) * 8;
+  const uint16_t* qb = qkv + (long long)b * N * 3 * D + cg * (LAW_HEADS * DK) + cc;
+  uint16_t* ob = out + (long long)b * N * D + cg * (LAW_HEADS * DK) + cc;
+  uint4 nx[8];
   auto fetch = [&](int n0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      nx[q] = make_uint2(0u, 0u);
-      if (n0 + li < n_end) nx[q] = *reinterpret_cast<const uint2*>(qb + (long long)(n0 + li) * 3 * D + 8 * q);
+    for (int p = 0; p < 8; ++p) {
+      const int n = n0 + 4 * p + cr;
+      nx[p] = make_uint4(0u, 0u, 0u, 0u);
+      if (n < n_end) nx[p] = *reinterpret_cast<const uint4*>(qb + (long long)n * 3 * D);
     }
   };
   fetch(n_begin);
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
-    uint2 cur[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = nx[q];
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<uint4*>(tile + (4 * p + cr) * LAW_LD + cc) = nx[p];
     if (n0 + TOK < n_end) fetch(n0 + TOK);
-    float a[16];
+    float2 st[LAW_HEADS];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      a[4 * q] = __uint_as_float(cur[q].x << 16); a[4 * q + 1] = __uint_as_float(cur[q].x & 0xffff0000u);
-      a[4 * q + 2] = __uint_as_float(cur[q].y << 16); a[4 * q + 3] = __uint_as_float(cur[q].y & 0xffff0000u);
-    }
-    float mx = a[0];
+    for (int hh = 0; hh < LAW_HEADS; ++hh) {
+      const uint16_t* qr = tile + li * LAW_LD + hh * DK + 16 * lh;
+      const uint4 v0 = *reinterpret_cast<const uint4*>(qr), v1 = *reinterpret_cast<const uint4*>(qr + 8);
+      const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      float a[16];
 #pragma unroll
-    for (int s = 1; s < 16; ++s) mx = fmaxf(mx, a[s]);
-    mx = fmaxf(mx, xhalf(mx));
-    float sum = 0.f;
+      for (int k = 0; k < 8; ++k) {
+        a[2 * k] = __uint_as_float(w[k] << 16);
+        a[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+      }
+      float mx = a[0];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      a[s] = __expf(a[s] - mx);
-      sum += a[s];
-    }
-    sum += xhalf(sum);
-    const float inv = rs / sum;
-    const bool ok = n0 + li < n_end;
-    if (lh == 0 && ok) {
-      float* qs = qstat + (((long long)b * N + n0 + li) * H + wave) * 2;
-      *reinterpret_cast<float2*>(qs) = make_float2(mx, inv);
-    }
+      for (int s = 1; s < 16; ++s) mx = fmaxf(mx, a[s]);
+      mx = fmaxf(mx, xhalf(mx));
+      float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) a[s] *= inv;
-    f32x16 acc;
+      for (int s = 0; s < 16; ++s) {
+        a[s] = __expf(a[s] - mx);
+        sum += a[s];
+      }
+      sum += xhalf(sum);
+      const float inv = rs / sum;
+      st[hh] = make_float2(mx, inv);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], pack8(a), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], pack8(a + 8), acc, 0, 0, 0);
-    if (ok) {
-      uint16_t* o = ob + (long long)(n0 + li) * D;
+      for (int s = 0; s < 16; ++s) a[s] *= inv;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[hh][0], pack8(a), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[hh][1], pack8(a + 8), acc, 0, 0, 0);
+      // the lane's quads of token li, head hh: channels 8 q + 4 lh (in place: this head's q values have been read by every lane)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         uint2 v;
         v.x = pack_bf16x2(acc[4 * q], acc[4 * q + 1]);
         v.y = pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3]);
-        *reinterpret_cast<uint2*>(o + 8 * q) = v;
+        *reinterpret_cast<uint2*>(tile + li * LAW_LD + hh * DK + 8 * q + 4 * lh) = v;
       }
+    }
+    // per-token softmax statistics of the 4 heads: 32 contiguous bytes per token
+    if (lh == 0 && n0 + li < n_end) {
+      float4* qs = reinterpret_cast<float4*>(qstat + (((long long)b * N + n0 + li) * H + cg * LAW_HEADS) * 2);
+      qs[0] = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
+      qs[1] = make_float4(st[2].x, st[2].y, st[3].x, st[3].y);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int n = n0 + 4 * p + cr;
+      const uint4 v = *reinterpret_cast<const uint4*>(tile + (4 * p + cr) * LAW_LD + cc);
+      if (n < n_end) *reinterpret_cast<uint4*>(ob + (long long)n * D) = v;
     }
   }
 }
@@ -492,26 +529,31 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
   }
 }
 
-// grid (B*H), block 1024: dctx[bh][i][j] = sum_s partT[s][j][i];  tvec[bh][i] = sum_j dctx[i][j]*ctx[i][j]
-__global__ void __launch_bounds__(1024) linattn_dctx_combine(const float* __restrict__ part, const float* __restrict__ ctx,
-                                                             float* __restrict__ dctx, float* __restrict__ tvec, int nsplit, int H) {
-  __shared__ float sm[32][33];
-  const int bh = blockIdx.x, b = bh / H, h = bh % H;
-  const float* p0 = part + ((long long)b * nsplit * H + h) * 1024;
-  {
-    const int ii = threadIdx.x & 31, jj = threadIdx.x >> 5;   // coalesced over the split partials partT[jj][ii]
-    float a = 0.f;
+// grid (8, B*H), block 256: dctx[bh][i][j] = sum_s partT[s][j][i].  Workgroup w folds partT rows j = 4w .. 4w+3 (32 float4 outputs
+// x 8 thread groups that share the splits).  One workgroup per (sample, head) pulled 0.9 MB through a single CU (8.5 us); the
+// Jacobian term tvec[i] = sum_j dctx[i][j] ctx[i][j] moved into linattn_bwd_apply's prologue (its lanes hold both rows).
+__global__ void __launch_bounds__(256) linattn_dctx_combine(const float* __restrict__ part, float* __restrict__ dctx, int nsplit, int H) {
+  __shared__ float4 red4[7][32];
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const float* p0 = part + ((long long)b * nsplit * H + h) * 1024 + blockIdx.x * 128;
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-    for (int s = 0; s < nsplit; ++s) a += p0[(long long)s * H * 1024 + jj * 32 + ii];
-    sm[jj][ii] = a;
+  for (int s = grp; s < nsplit; s += 8) {
+    const float4 v = *reinterpret_cast<const float4*>(p0 + (long long)s * H * 1024 + l * 4);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
+  if (grp > 0) red4[grp - 1][l] = a;
   __syncthreads();
-  const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
-  const float a = sm[j][i];
-  dctx[(long long)bh * 1024 + i * 32 + j] = a;
-  float t = a * ctx[(long long)bh * 1024 + i * 32 + j];
-  t = group_sum<32>(t);
-  if (j == 0) tvec[bh * 32 + i] = t;
+  if (grp != 0) return;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float4 v = red4[q][l];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int e = blockIdx.x * 128 + l * 4, jj = e >> 5, ii = e & 31;      // partT[jj][ii .. ii+3] -> dctx[ii ..][jj]
+  float* o = dctx + (long long)bh * 1024 + jj;
+  o[ii * 32] = a.x; o[(ii + 1) * 32] = a.y; o[(ii + 2) * 32] = a.z; o[(ii + 3) * 32] = a.w;
 }
 
 // ------------------------------------------------------------------------------------------------ backward pass 2
@@ -536,7 +578,6 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
   if (lane < 32) {
     cs[lane] = stats[bh * 64 + lane];
     cs[32 + lane] = 1.f / stats[bh * 64 + 32 + lane];
-    cs[64 + lane] = tvec[bh * 32 + lane];
   }
   // A operands (rows on lanes), k-index ch(s,lh) = 16*lh + s:
   //   ctxA[s] = ctx[i=li][j=ch];  dcA[s] = dctx[i=li][j=ch];  dcT[s] = dctx[i=ch][j=li]
@@ -546,6 +587,14 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
     ctxA[s] = ctx[bh * 1024 + li * 32 + 16 * lh + s];
     dcA[s] = dctx[bh * 1024 + li * 32 + 16 * lh + s];
     dcT[s] = dctx[bh * 1024 + (16 * lh + s) * 32 + li];
+  }
+  {
+    // tvec[i] = sum_j dctx[i][j] ctx[i][j] (the column-softmax Jacobian term), from the fp32 values: lane (i = li, lh) holds 16 j
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) t += ctxA[s] * dcA[s];
+    t += xhalf(t);
+    if (lane < 32) cs[64 + lane] = t;
   }
   const bf16x8 ctxB[2] = {pack8(ctxA), pack8(ctxA + 8)}, dcTB[2] = {pack8(dcT), pack8(dcT + 8)};
   // dk = P (dP - tvec) cancels almost completely (the key gradients are ~1e-3 of the others), and tvec comes from the fp32
@@ -681,6 +730,7 @@ static int pick_splits(int B, int N, int* tokens_per_split) {
   total = ltu_knob_pos("LTU_LA_SPLITS", 512);
   int want = total / (B > 0 ? B : 1);
   if (want < 1) want = 1;
+  if (want > KVC_GROUP * KVC_GROUP) want = KVC_GROUP * KVC_GROUP;      // the merge is two levels of at most KVC_GROUP partials
   int tps = (N + want - 1) / want;
   tps = (tps + 31) / 32 * 32;
   if (tps < 32) tps = 32;
@@ -723,7 +773,7 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
     LA_DISPATCH_D(d, {
       hipLaunchKernelGGL((linattn_kv_partial<T, D>), dim3(nsplit, B), dim3(2 * D), 0, st, (const T*)qkv, part_ws, N, tps);
       // two-level merge of the split partials (level-1 results live behind the level-0 partials in part_ws)
-      const int group = 16, ngroups = (nsplit + group - 1) / group;
+      const int group = KVC_GROUP, ngroups = (nsplit + group - 1) / group;
       float* part2 = part_ws + (size_t)B * nsplit * H * PART_STRIDE;
       if (ngroups > 1) {
         hipLaunchKernelGGL(linattn_kv_combine, dim3(ngroups, B * H), dim3(1024), 0, st, part_ws, nsplit, group, part2, colstats, ctx, H, 0);
@@ -731,12 +781,14 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
       } else {
         hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part_ws, nsplit, nsplit, nullptr, colstats, ctx, H, 1);
       }
-      if constexpr (IsBf16<T>::value && D >= 64) {
-        // register-direct form: a wave per (head, token chunk); ~LTU_LA_APPLY_WAVES waves in flight
-        const long long tiles = (long long)B * cdiv(N, TOK);
-        const long long tpw = cdiv(tiles * (D / DK), (long long)ltu_knob_pos("LTU_LA_APPLY_WAVES", 8192));
-        const int tokd = (int)(tpw < 1 ? 1 : tpw) * TOK;
-        hipLaunchKernelGGL((linattn_apply_direct<D>), dim3(cdiv(N, tokd), B), dim3(2 * D), 0, st, (const uint16_t*)qkv, ctx, (uint16_t*)out, qstat, N, tokd);
+      if constexpr (IsBf16<T>::value && D >= 128) {
+        // wave-private form: a wave per (4 heads, token chunk); ~LTU_LA_APPLY_WAVES waves in flight
+        constexpr int CG = D / DK / LAW_HEADS;
+        const long long tiles = cdiv(N, TOK);
+        long long tpw = cdiv((long long)B * tiles * CG, (long long)ltu_knob_pos("LTU_LA_APPLY_WAVES", 4096));
+        if (tpw < 1) tpw = 1;
+        const long long waves = cdiv(tiles, tpw) * CG;              // per sample
+        hipLaunchKernelGGL((linattn_apply_rows<D>), dim3((unsigned)cdiv(waves, 4), B), dim3(256), 0, st, (const uint16_t*)qkv, ctx, (uint16_t*)out, qstat, N, (int)tpw);
       } else {
         hipLaunchKernelGGL((linattn_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), 0, st, (const T*)qkv, ctx, (T*)out, qstat, N, tokb);
       }
@@ -757,7 +809,7 @@ extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* c
   LTU_DISPATCH_T(dtype, {
     LA_DISPATCH_D(d, {
       hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float), st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);
-      hipLaunchKernelGGL(linattn_dctx_combine, dim3(B * H), dim3(1024), 0, st, part_ws, ctx, dctx, tvec, nsplit, H);
+      hipLaunchKernelGGL(linattn_dctx_combine, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
       hipLaunchKernelGGL((linattn_bwd_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), lds_b, st, (const T*)qkv, (const T*)dout, ctx, dctx, colstats, tvec, qstat, (T*)dqkv, N, tokb);
     });
   });
