@@ -223,18 +223,30 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   const int li = lane & 31, lh = lane >> 5;
   const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
 
-  // weights once: row (tap, n) <- w[n][tap (mirrored for the data gradient)][0..C)
+  // weights once: row (tap, n) <- w[n][tap (mirrored for the data gradient)][0..C).  All loads first (unconditional, from a clamped
+  // address; padding is selected to zero afterwards), then the LDS stores: with a test around each load hipcc waits for every
+  // one where it stands - 14 dependent L2 round trips at the head of every workgroup.
+  {
+    uint4 wv[NWV];
 #pragma unroll
-  for (int p = 0; p < NWV; ++p) {
-    const int idx = tid + p * 256;
-    if (idx >= 27 * 32 * VPV) break;
-    const int part = idx % VPV, row = idx / VPV;
-    const int n = row & 31, tap = row >> 5;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (n < a.N && part * 8 < a.C)
-      v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + ((long long)n * 27 + tap) * a.C + part * 8);
-    const int slot = CC == 32 ? (part ^ ((row >> 2) & 1)) : part;
-    *reinterpret_cast<uint4*>(&Wl[row * CC + slot * 8]) = v;
+    for (int p = 0; p < NWV; ++p) {
+      const int idx = min(tid + p * 256, 27 * 32 * VPV - 1);
+      const int part = idx % VPV, row = idx / VPV;
+      const int n = min(row & 31, a.N - 1), tap = row >> 5;
+      const int c = min(part * 8, a.C - 8);
+      wv[p] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + ((long long)n * 27 + tap) * a.C + c);
+    }
+#pragma unroll
+    for (int p = 0; p < NWV; ++p) {
+      const int idx = tid + p * 256;
+      if (idx < 27 * 32 * VPV) {
+        const int part = idx % VPV, row = idx / VPV;
+        const int n = row & 31;
+        const uint4 v = (n < a.N && part * 8 < a.C) ? wv[p] : make_uint4(0u, 0u, 0u, 0u);
+        const int slot = CC == 32 ? (part ^ ((row >> 2) & 1)) : part;
+        *reinterpret_cast<uint4*>(&Wl[row * CC + slot * 8]) = v;
+      }
+    }
   }
 
   // Index arithmetic is hoisted out of the brick loop: a thread always stages the same halo pieces and stores the same output
@@ -304,11 +316,10 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   for (int rr = 0; rr < 4; ++rr) {
     const int n = 8 * rr + 4 * lh;
     bv4[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias != nullptr) {
-      if (n + 0 < a.N) bv4[rr].x = a.bias[n + 0];
-      if (n + 1 < a.N) bv4[rr].y = a.bias[n + 1];
-      if (n + 2 < a.N) bv4[rr].z = a.bias[n + 2];
-      if (n + 3 < a.N) bv4[rr].w = a.bias[n + 3];
+    if (a.bias != nullptr) {               // uniform test; the 4 loads inside are unconditional (clamped index, selected afterwards)
+      const float b0 = a.bias[min(n + 0, a.N - 1)], b1 = a.bias[min(n + 1, a.N - 1)], b2 = a.bias[min(n + 2, a.N - 1)],
+                  b3 = a.bias[min(n + 3, a.N - 1)];
+      bv4[rr] = make_float4(n + 0 < a.N ? b0 : 0.f, n + 1 < a.N ? b1 : 0.f, n + 2 < a.N ? b2 : 0.f, n + 3 < a.N ? b3 : 0.f);
     }
   }
   uint16_t* Cs = halo;
@@ -320,12 +331,16 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   const int o_w = tid >> 6, o_d = (tid >> 3) & 7, o_n = (tid & 7) * 4;
   uint16_t* const o_base = o_n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + o_n : reinterpret_cast<uint16_t*>(a.o1) + (o_n - a.n0);
   const int o_ld = o_n < a.n0 ? a.ldo0 : a.ldo1;
+  // The output stores of a brick are issued AFTER the next brick's halo registers have gone to LDS (a wait for the halo loads
+  // placed behind freshly issued stores would also wait for their acknowledgement: vmcnt is one in-order counter).  Deferring
+  // them by a whole brick was tried as well: 59 -> 55 us at C = 16 but 78 -> 92 us at C = 32; not kept.
+  __syncthreads();                         // the weights are in place
+  if (brick < bricks) store_halo();
+  __syncthreads();
   for (; brick < bricks; brick += gridDim.x) {
-    __syncthreads();                       // staging reads of the previous brick are done (and the weights are in place)
-    store_halo();
-    __syncthreads();
     advance(nxt);
-    if (brick + (int)gridDim.x < bricks) load_halo(nxt);
+    const bool more = brick + (int)gridDim.x < bricks;
+    if (more) load_halo(nxt);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -372,6 +387,11 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
       *reinterpret_cast<uint2*>(&Cs[(wave * 32 + li) * LDC + 8 * rr + 4 * lh]) = pk;
     }
     __syncthreads();
+    uint2 ov[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const uint2*>(&Cs[((tid >> 3) + 32 * it) * LDC + o_n]);
+    __syncthreads();                       // the staging has been read: the region takes the next halo
+    if (more) store_halo();
     {
       const int h0 = cur.bh * 4, w = cur.bw * 4 + o_w, d = cur.bd * 8 + o_d;
       const long long vox0 = (((long long)cur.b * a.H + h0) * a.W + w) * a.D + d;
@@ -379,10 +399,10 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
 #pragma unroll
       for (int it = 0; it < 4; ++it) {     // row ml = (tid >> 3) + 32 it is brick voxel (h = it, w = o_w, d = o_d)
         if (!ok || h0 + it >= a.H) continue;
-        const uint2 v = *reinterpret_cast<const uint2*>(&Cs[((tid >> 3) + 32 * it) * LDC + o_n]);
-        *reinterpret_cast<uint2*>(o_base + (vox0 + (long long)it * a.W * a.D) * o_ld) = v;
+        *reinterpret_cast<uint2*>(o_base + (vox0 + (long long)it * a.W * a.D) * o_ld) = ov[it];
       }
     }
+    __syncthreads();                       // the next halo is in place
     cur = nxt;
   }
 }

@@ -53,10 +53,13 @@ __device__ __forceinline__ void kcur_advance(const IGemmArgs& g, KCur& q, int de
   while (q.c >= g.C && q.slot < g.ntaps) { q.c -= g.C; ++q.slot; }
 }
 // 8 consecutive bf16 channels of the A operand at (row, cursor); zero outside the source / beyond K
-__device__ __forceinline__ uint4 gather_a8c(const IGemmArgs& g, bool row_ok, const RowCoord& rc, const KCur& q) {
+// `taps`: the workgroup's LDS copy of g.tap.  Indexing the kernel-argument copy with a per-thread slot is a vector load from
+// memory whose result the address computation needs at once: its s_waitcnt vmcnt(0) also drained the data loads of the tiles
+// that were supposed to stay in flight (vmcnt is one in-order counter), so every K tile paid a full memory round trip.
+__device__ __forceinline__ uint4 gather_a8c(const IGemmArgs& g, const Tap* taps, bool row_ok, const RowCoord& rc, const KCur& q) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   if (!row_ok || q.slot >= g.ntaps) return z;
-  const Tap tp = g.tap[q.slot];
+  const Tap tp = taps[q.slot];
   int h = rc.h * g.mh + tp.dh, w = rc.w * g.mw + tp.dw, d = rc.d * g.md + tp.dd;
   if ((unsigned)h >= (unsigned)g.sh || (unsigned)w >= (unsigned)g.sw || (unsigned)d >= (unsigned)g.sd) return z;
   int ph = g.sh, pw = g.sw, pd = g.sd;
@@ -123,8 +126,11 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
   __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
   uint16_t* As = smem;                          // [NBUF][BM][LDK]
   uint16_t* Bs = smem + NBUF * BM * LDK;        // [NBUF][BN][LDK]
+  __shared__ Tap s_tap[64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 64) s_tap[tid] = g.tap[tid];
+  __syncthreads();
   const int wm = wave / WN, wn = wave % WN;
   const long long m_blk = (long long)blockIdx.x * BM;
   const int n_blk = blockIdx.y * BN;
@@ -172,9 +178,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
   // loads the NEXT tile of the K sequence into a register set
   auto load_tile = [&](uint4 (&ra)[LA], uint4 (&rb)[LB]) {
 #pragma unroll
-    for (int p = 0; p < LA; ++p) ra[p] = (g.dbg & 4) ? make_uint4(1u, 2u, 3u, 4u) : gather_a8c(g, rok[p], rc[p], cur);
+    for (int p = 0; p < LA; ++p) ra[p] = (g.dbg & 4) ? make_uint4(1u, 2u, 3u, 4u) : gather_a8c(g, s_tap, rok[p], rc[p], cur);
     const bool kin = cur.slot < g.ntaps;
-    const int woff = kin ? (int)g.tap[cur.slot].wt * g.C + cur.c : 0;
+    const int woff = kin ? (int)s_tap[cur.slot].wt * g.C + cur.c : 0;
 #pragma unroll
     for (int p = 0; p < LB; ++p)
       rb[p] = (kin && wrow[p]) ? *reinterpret_cast<const uint4*>(wrow[p] + woff) : make_uint4(0u, 0u, 0u, 0u);
@@ -443,6 +449,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
   constexpr int LG = (BR * BNn / 8 + NT - 1) / NT, LX = (BR * BKk / 8 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) uint16_t Gs[2][BR][LDG];
   __shared__ __attribute__((aligned(16))) uint16_t Xs[2][BR][LDX];
+  __shared__ Tap s_tap[64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -451,6 +458,8 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
   long long m_end = m_begin + wa.rows_per_split;
   if (m_end > g.M) m_end = g.M;
   if (m_begin >= m_end) return;
+  if (tid < 64) s_tap[tid] = g.tap[tid];
+  __syncthreads();
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_tn_bf16_kernel(const WGradA
       const int row = idx / (BKk / 8);
       const long long m = m0 + row;
       const bool ok = idx < BR * BKk / 8 && m < m_end;
-      rx[p] = gather_a8c(g, ok, xrc[p], xcur[p]);
+      rx[p] = gather_a8c(g, s_tap, ok, xrc[p], xcur[p]);
       advance_row(g, xrc[p], BR);
     }
   };
