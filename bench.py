@@ -300,10 +300,10 @@ def main():
         u, h, du = q['m2d']
         _lib.call('ltu_layer_tail_fwd', _p(q['a']), _p(q['x']), _p(q['w'][0]), _p(q['w'][1]), _p(q['w'][2]), _p(q['bias']), _p(q['bias']),
                   _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y),
-                  _p(q['stat'][0]), _p(q['stat'][1]), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, _s())
+                  _p(q['stat'][0]), _p(q['stat'][1]), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, 1, _s())
         _lib.call('ltu_layer_tail_bwd', _p(q['dy']), _p(q['dy2']), _p(z2), _p(z1), _p(u), _p(q['stat'][1]), _p(q['stat'][0]), _p(q['gamma']),
                   _p(q['gamma']), _p(q['wt'][0]), _p(q['wt'][1]), _p(q['wt'][2]), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(q['lnws'][0]),
-                  _p(q['lnws'][1]), M, d, 0.3, 11, 12, 13, 0, 1, _s())
+                  _p(q['lnws'][1]), M, d, 0.3, 11, 12, 13, 0, 1, 1, _s())
 
     def eager_step(i):
         reducer.zero_grad()

@@ -89,28 +89,31 @@ int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias
                         uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* ---- post-attention half of a transformer layer as ONE launch (model/trans_block.py:203-211), bf16 storage, d = 128 | 256 ----
  *   z1 = x + drop(a Wo^T + bo); t1 = LN1(z1); u = t1 W1^T + b1; h = drop(gelu(u)); z2 = t1 + drop(h W2^T + b2); y = LN2(z2)
- * for the small token levels, where the five separate launches (projection, LayerNorm, projection + GELU, projection,
- * LayerNorm) are latency- rather than bandwidth-bound: a workgroup carries 64 token rows through the whole chain in LDS.
+ * a workgroup carries 32 token rows through the whole chain in LDS (the five separate launches - projection, LayerNorm,
+ * projection + GELU, projection, LayerNorm - re-read every intermediate and are latency-bound on the small token levels).
  * wo / w1 / w2: bf16 weights in MFMA fragment order (ltu_weight_prep kind 8 of the [out][in] fp32 masters).  All intermediate
  * tensors the backward pass needs are written (z1, t1, u, h, z2: bf16; stat1 / stat2 [M][2] = mean, rstd).  Rounding points and
- * dropout masks are those of the op-by-op path (ltu_linear_fwd, ltu_layernorm_fwd, ltu_linear_gelu_fwd). */
+ * dropout masks are those of the op-by-op path (ltu_linear_fwd, ltu_layernorm_fwd, ltu_linear_gelu_fwd).
+ * u_mode 0: `u` receives the FFN pre-activation (what ltu_gelu_dropout_bwd expects); u_mode 1: it receives
+ * dropout_mask * gelu'(u) instead, the factor ltu_layer_tail_bwd (same u_mode) multiplies dh by - the forward pass has the
+ * Gaussian terms at hand, and the backward chain then needs no exp / rcp / mask hash for this stage. */
 int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void* w1, const void* w2, const float* bo,
                        const float* b1, const float* b2, const float* g1, const float* be1, const float* g2, const float* be2,
                        void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1, float* stat2, long long M, int d,
-                       float eps, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int dtype,
-                       ltu_stream_t s);
+                       float eps, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int u_mode,
+                       int dtype, ltu_stream_t s);
 
 /* The backward of the same chain as ONE launch: LayerNorm 2 backward, data gradients through linear2 / GELU + dropout / linear1,
  * LayerNorm 1 backward (on dt1 + dz2), data gradient through the out projection.  dy2 (nullable): second gradient of y, summed on
  * load.  w2t / w1t / wot: fragment-ordered TRANSPOSED weights (ltu_weight_prep kind 9 of the fp32 masters).  Outputs: da, dz1
  * (gradient of the residual input x) and dr2 / du / dr1 = the G operands of the three weight gradients (ltu_linear_wgrad_group
- * with X = h / t1 / a).  lnws2 / lnws1: ltu_layer_tail_blocks(M) x 2d floats each = per-workgroup (gamma, beta) column sums,
+ * with X = h / t1 / a).  `u` / u_mode: as written by ltu_layer_tail_fwd with the same u_mode.  lnws2 / lnws1: ltu_layer_tail_blocks(M) x 2d floats each = per-workgroup (gamma, beta) column sums,
  * interleaved, folded by ltu_reduce_batch (mode 1). */
 long long ltu_layer_tail_blocks(long long M);
 int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z2, const void* z1, const void* u, const float* stat2,
                        const float* stat1, const float* g2, const float* g1, const void* w2t, const void* w1t, const void* wot,
                        void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1, long long M, int d, float p,
-                       uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int dtype, ltu_stream_t s);
+                       uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int u_mode, int dtype, ltu_stream_t s);
 
 /* ---- deferred second stage of the two-stage reductions ------------------------------------------
  * ltu_linear_wgrad / ltu_layernorm_bwd can leave the folding of their per-split partial sums to the caller: pass a job

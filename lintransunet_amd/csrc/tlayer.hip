@@ -35,7 +35,7 @@ struct TailArgs {
   const float* be2;
   uint16_t* z1;           // [M][d]   pre-norm sums (LayerNorm backward)
   uint16_t* t1;           // [M][d]   LN1 output
-  uint16_t* u;            // [M][2d]  FFN pre-activation
+  uint16_t* u;            // [M][2d]  FFN pre-activation (u_mode 0) or dropout mask * gelu'(u) (u_mode 1: what the backward chain multiplies by)
   uint16_t* h;            // [M][2d]  dropout(gelu(u))
   uint16_t* z2;           // [M][d]
   uint16_t* y;            // [M][d]   layer output
@@ -45,6 +45,7 @@ struct TailArgs {
   float eps, p;
   uint64_t seed1, seedg, seed2;               // dropout sites: after the out projection, after GELU, after linear2
   const uint64_t* step;
+  int u_mode;
   int dbg;                // ablation (tools/bench_tail.py): 2 = no GELU / dropout arithmetic, 4 = u and h are not stored
 };
 
@@ -225,16 +226,31 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
       const uint4 uv = *reinterpret_cast<const uint4*>(HB + r * LDH + c);
       const float4 u0 = unpack_quad(make_uint2(uv.x, uv.y)), u1 = unpack_quad(make_uint2(uv.z, uv.w));
       float4 h0 = u0, h1 = u1;
-      if (!(ta.dbg & 2)) {
-        const unsigned long long g4 = (unsigned long long)((row * (2 * D) + c) >> 2);
-        h0 = drop4(dcg, g4, make_float4(gelu_erf(u0.x), gelu_erf(u0.y), gelu_erf(u0.z), gelu_erf(u0.w)));
-        h1 = drop4(dcg, g4 + 1, make_float4(gelu_erf(u1.x), gelu_erf(u1.y), gelu_erf(u1.z), gelu_erf(u1.w)));
+      uint4 sv = uv;                                  // what the backward pass gets: u, or (u_mode 1) mask * gelu'(u) - the
+      if (!(ta.dbg & 2)) {                            // Gaussian terms are shared with gelu(u), the backward chain then needs
+        const unsigned long long g4 = (unsigned long long)((row * (2 * D) + c) >> 2);      // no exp / rcp / hash at all
+        const float4 m0 = dropmask4(dcg, g4), m1 = dropmask4(dcg, g4 + 1);
+        const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float hh[8], gg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float e;
+          const float cdf = gelu_cdf(uu[k], e);
+          hh[k] = uu[k] * cdf * mm[k];
+          gg[k] = (cdf + uu[k] * 0.39894228040143267794f * e) * mm[k];
+        }
+        h0 = make_float4(hh[0], hh[1], hh[2], hh[3]); h1 = make_float4(hh[4], hh[5], hh[6], hh[7]);
+        if (ta.u_mode) {
+          const uint2 s0 = pack_quad(gg[0], gg[1], gg[2], gg[3]), s1 = pack_quad(gg[4], gg[5], gg[6], gg[7]);
+          sv = make_uint4(s0.x, s0.y, s1.x, s1.y);
+        }
       }
       const uint2 a0 = pack_quad(h0.x, h0.y, h0.z, h0.w), a1 = pack_quad(h1.x, h1.y, h1.z, h1.w);
       const uint4 hv = make_uint4(a0.x, a0.y, a1.x, a1.y);
       *reinterpret_cast<uint4*>(HB + r * LDH + c) = hv;
       if (row < ta.M && !(ta.dbg & 4)) {
-        *reinterpret_cast<uint4*>(ta.u + row * (2 * D) + c) = uv;
+        *reinterpret_cast<uint4*>(ta.u + row * (2 * D) + c) = sv;
         *reinterpret_cast<uint4*>(ta.h + row * (2 * D) + c) = hv;
       }
     }
@@ -263,7 +279,7 @@ struct TailBwdArgs {
   const uint16_t* dy2;    // second gradient of the layer output (nullable)
   const uint16_t* z2;
   const uint16_t* z1;
-  const uint16_t* u;      // [M][2d]
+  const uint16_t* u;      // [M][2d]  as written by the forward kernel (see TailArgs::u)
   const float* stat2;
   const float* stat1;
   const float* g2;        // LayerNorm weights
@@ -282,6 +298,7 @@ struct TailBwdArgs {
   float p;
   uint64_t seed1, seedg, seed2;
   const uint64_t* step;
+  int u_mode;
 };
 
 // LayerNorm backward over the block's rows.  g = gl (LDS, nullable) + gg1 (global, nullable) + gg2 (global, nullable); writes dz to
@@ -368,7 +385,7 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
   }
 }
 
-template <int D>
+template <int D, int UMODE>
 __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const TailBwdArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
@@ -390,10 +407,10 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const
   // the wave's first linear2^T operands: in flight across the LayerNorm stage
   TlQueue<KS1> q1;
   TlQueue<KS2> q2;
-  tl_issue<KS1>(ta.w2t, wave, lane, q1);
   // stage 0: LayerNorm 2 backward: dz2 -> ZB, dr2 -> RB + global
   tl_layernorm_bwd<D, NTHR, false, false, true, false>(nullptr, nullptr, ta.dy, ta.dy2, ta.z2, ta.stat2, ta.g2, ZB, nullptr, RB, ta.dr2,
                                                       ta.lnws2, red, LD, row0, ta.M, dc2, tid);
+  tl_issue<KS1>(ta.w2t, wave, lane, q1);
   // the thread's 16-byte chunks of the pre-activations u for stage 1b (row-contiguous): in flight across stage 1a
   constexpr int CPR2 = 2 * D / 8, NCH2 = TL_ROWS * CPR2 / NTHR;
   uint4 uch[NCH2];
@@ -428,12 +445,18 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const
     const uint4 dv = *reinterpret_cast<const uint4*>(UB + r * LDH + c);
     const float4 d0 = unpack_quad(make_uint2(dv.x, dv.y)), d1 = unpack_quad(make_uint2(dv.z, dv.w));
     const float4 u0 = unpack_quad(make_uint2(uch[j].x, uch[j].y)), u1 = unpack_quad(make_uint2(uch[j].z, uch[j].w));
-    const unsigned long long g4 = (unsigned long long)((rw * (2 * D) + c) >> 2);
-    const float4 m0 = dropmask4(dcg, g4), m1 = dropmask4(dcg, g4 + 1);
-    const uint2 a0 = pack_quad(d0.x * m0.x * gelu_erf_grad(u0.x), d0.y * m0.y * gelu_erf_grad(u0.y), d0.z * m0.z * gelu_erf_grad(u0.z),
-                               d0.w * m0.w * gelu_erf_grad(u0.w));
-    const uint2 a1 = pack_quad(d1.x * m1.x * gelu_erf_grad(u1.x), d1.y * m1.y * gelu_erf_grad(u1.y), d1.z * m1.z * gelu_erf_grad(u1.z),
-                               d1.w * m1.w * gelu_erf_grad(u1.w));
+    uint2 a0, a1;
+    if constexpr (UMODE == 1) {         // the forward kernel left mask * gelu'(u)
+      a0 = pack_quad(d0.x * u0.x, d0.y * u0.y, d0.z * u0.z, d0.w * u0.w);
+      a1 = pack_quad(d1.x * u1.x, d1.y * u1.y, d1.z * u1.z, d1.w * u1.w);
+    } else {
+      const unsigned long long g4 = (unsigned long long)((rw * (2 * D) + c) >> 2);
+      const float4 m0 = dropmask4(dcg, g4), m1 = dropmask4(dcg, g4 + 1);
+      a0 = pack_quad(d0.x * m0.x * gelu_erf_grad(u0.x), d0.y * m0.y * gelu_erf_grad(u0.y), d0.z * m0.z * gelu_erf_grad(u0.z),
+                     d0.w * m0.w * gelu_erf_grad(u0.w));
+      a1 = pack_quad(d1.x * m1.x * gelu_erf_grad(u1.x), d1.y * m1.y * gelu_erf_grad(u1.y), d1.z * m1.z * gelu_erf_grad(u1.z),
+                     d1.w * m1.w * gelu_erf_grad(u1.w));
+    }
     const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
     *reinterpret_cast<uint4*>(UB + r * LDH + c) = dq;
     if (rw < ta.M) *reinterpret_cast<uint4*>(ta.du + rw * (2 * D) + c) = dq;
@@ -475,11 +498,13 @@ extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z
                                   const float* stat1, const float* g2, const float* g1, const void* w2t, const void* w1t,
                                   const void* wot, void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1,
                                   long long M, int d, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step,
-                                  int dtype, ltu_stream_t s) {
+                                  int u_mode, int dtype, ltu_stream_t s) {
   if (dtype != LTU_BF16) return LTU_E_DTYPE;
   if (d != 128 && d != 256) return LTU_E_SHAPE;
+  if (u_mode != 0 && u_mode != 1) return LTU_E_ARG;
   if (M <= 0) return LTU_OK;
   TailBwdArgs ta;
+  ta.u_mode = u_mode;
   ta.dy = (const uint16_t*)dy; ta.dy2 = (const uint16_t*)dy2; ta.z2 = (const uint16_t*)z2; ta.z1 = (const uint16_t*)z1;
   ta.u = (const uint16_t*)u; ta.stat2 = stat2; ta.stat1 = stat1; ta.g2 = g2; ta.g1 = g1;
   ta.w2t = (const uint16_t*)w2t; ta.w1t = (const uint16_t*)w1t; ta.wot = (const uint16_t*)wot;
@@ -488,14 +513,15 @@ extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z
   ta.M = M; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
   const unsigned blocks = cdiv(M, TL_ROWS);
   const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t);
+  auto launch = [&](auto kern, unsigned threads) {
+    static LtuDevOnce once;                // one latch per kernel instantiation (the lambda body is instantiated per `kern` type)
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)s, ta);
+  };
   if (d == 256) {
-    static LtuDevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((tail_bwd_kernel<256>), dim3(blocks), dim3(512), lds, (hipStream_t)s, ta);
+    if (u_mode) launch(&tail_bwd_kernel<256, 1>, 512); else launch(&tail_bwd_kernel<256, 0>, 512);
   } else {
-    static LtuDevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((tail_bwd_kernel<128>), dim3(blocks), dim3(256), lds, (hipStream_t)s, ta);
+    if (u_mode) launch(&tail_bwd_kernel<128, 1>, 256); else launch(&tail_bwd_kernel<128, 0>, 256);
   }
   return ltu_check_launch();
 }
@@ -504,11 +530,13 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
                                   const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
                                   const float* be2, void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1,
                                   float* stat2, long long M, int d, float eps, float p, uint64_t seed1, uint64_t seedg,
-                                  uint64_t seed2, const uint64_t* step, int dtype, ltu_stream_t s) {
+                                  uint64_t seed2, const uint64_t* step, int u_mode, int dtype, ltu_stream_t s) {
   if (dtype != LTU_BF16) return LTU_E_DTYPE;
   if (d != 128 && d != 256) return LTU_E_SHAPE;
+  if (u_mode != 0 && u_mode != 1) return LTU_E_ARG;
   if (M <= 0) return LTU_OK;
   TailArgs ta;
+  ta.u_mode = u_mode;
   ta.a = (const uint16_t*)a; ta.x = (const uint16_t*)x;
   ta.wo = (const uint16_t*)wo; ta.w1 = (const uint16_t*)w1; ta.w2 = (const uint16_t*)w2;
   ta.bo = bo; ta.b1 = b1; ta.b2 = b2; ta.g1 = g1; ta.be1 = be1; ta.g2 = g2; ta.be2 = be2;

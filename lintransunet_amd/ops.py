@@ -978,12 +978,16 @@ class _LayerTail(torch.autograd.Function):
         z1, t1, z2, y = (torch.empty((M, d), device=dev, dtype=dt) for _ in range(4))
         u, h = (torch.empty((M, 2 * d), device=dev, dtype=dt) for _ in range(2))
         stat1, stat2 = (torch.empty((M, 2), device=dev, dtype=torch.float32) for _ in range(2))
+        # u_mode 1: the kernel leaves dropout_mask * gelu'(u) in `u` - all the backward chain kernel needs of it; the op-by-op
+        # backward (no transposed fragments, or switched off) wants the pre-activation itself
+        u_mode = 1 if (USE_LAYER_TAIL_BWD and po.fragT is not None and p1.fragT is not None and p2.fragT is not None) else 0
         _lib.call('ltu_layer_tail_fwd', _p(a), _p(x), _p(po.frag), _p(p1.frag), _p(p2.frag), _p(bo), _p(b1), _p(b2), _p(g1), _p(be1),
                   _p(g2), _p(be2), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(stat1), _p(stat2), M, d, float(eps), float(p),
-                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), _dt(a), _s())
+                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), u_mode, _dt(a), _s())
         ctx.save_for_backward(a, z1, stat1, t1, u, h, z2, stat2)
         ctx.params = (wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
         ctx.cfg = (preps, p, seeds)
+        ctx.u_mode = u_mode
         return (y, y.view_as(y)) if fork else y
 
     @staticmethod
@@ -1021,7 +1025,7 @@ class _LayerTail(torch.autograd.Function):
             _lib.call('ltu_linear_fwd', _p(gy), N, _ptr_array([wt]), 1, _ptr_array([None]), _p(dx), K, M, K, N, 0, dt, _s())
             return dx
 
-        if USE_LAYER_TAIL_BWD and po.fragT is not None and p1.fragT is not None and p2.fragT is not None:
+        if ctx.u_mode == 1:
             # the whole data-gradient chain as one launch (csrc/tlayer.hip: tail_bwd_kernel)
             dr2, dr1, dz1, da = (torch.empty_like(a) for _ in range(4))
             du = torch.empty_like(u)
@@ -1029,7 +1033,7 @@ class _LayerTail(torch.autograd.Function):
             lnws = torch.empty((2, nblk, 2 * d), device=dev, dtype=torch.float32)
             _lib.call('ltu_layer_tail_bwd', _p(g), _p(g2), _p(z2), _p(z1), _p(u), _p(stat2), _p(stat1), _p(gm2), _p(gm1), _p(p2.fragT),
                       _p(p1.fragT), _p(po.fragT), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), M, d, float(p),
-                      seeds[0], seeds[1], seeds[2], lc.step_ptr(), dt, _s())
+                      seeds[0], seeds[1], seeds[2], lc.step_ptr(), 1, dt, _s())
             outs = []
             for k, (gamma, beta) in enumerate(((gm2, be2), (gm1, be1))):
                 dg, fg = _grad_buf(gamma)
