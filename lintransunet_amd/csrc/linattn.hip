@@ -61,6 +61,8 @@ struct GVec<float> {
   static __device__ __forceinline__ void from_lds(float* gdst, const float* src) {
     *reinterpret_cast<float4*>(gdst) = *reinterpret_cast<const float4*>(src);
   }
+  static __device__ __forceinline__ reg pack_lds(const float* src) { return *reinterpret_cast<const float4*>(src); }
+  static __device__ __forceinline__ void store_g(float* gdst, reg v) { *reinterpret_cast<float4*>(gdst) = v; }
 };
 template <>
 struct GVec<bf16_t> {
@@ -86,6 +88,11 @@ struct GVec<bf16_t> {
     v.w = pack_bf16x2(b.z, b.w);
     *reinterpret_cast<uint4*>(gdst) = v;
   }
+  static __device__ __forceinline__ reg pack_lds(const float* src) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+  }
+  static __device__ __forceinline__ void store_g(bf16_t* gdst, reg v) { *reinterpret_cast<uint4*>(gdst) = v; }
 };
 
 // Stages TOK rows of ROWE elements (row r at gbase + (n0 + r)*gstride + goff) into LDS rows of stride LDSROW floats.
@@ -619,20 +626,25 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
   RowTile<T, D, 3 * D, LD3> tq;
   RowTile<T, D, D, LD1> tg;
   // (row max, scaled inverse sum) of token n0 + li travel with the tile prefetch: loaded after it they would wait for it
+  // (unconditional, from a clamped row: a test around the load makes hipcc wait for it - and for the whole tile prefetch issued
+  // just before it - where it stands)
   auto load_qs = [&](int n0) {
-    return n0 + li < n_end ? *reinterpret_cast<const float2*>(qstat + (((long long)b * N + n0 + li) * H + wave) * 2)
-                           : make_float2(0.f, 0.f);
+    return *reinterpret_cast<const float2*>(qstat + (((long long)b * N + min(n0 + li, n_end - 1)) * H + wave) * 2);
   };
+  // Order inside an iteration: the next tile's loads are requested before the arithmetic; the tile's outputs are read back from
+  // the staging into registers, the NEXT tile goes to LDS (its loads are older than any pending store), and only then are the
+  // outputs stored.  vmcnt is one in-order counter and hipcc waits vmcnt(0) at the loop head: stores issued at the end of an
+  // iteration had their acknowledgement waited for before every tile, with one wave per SIMD to hide it.
   tq.load(qb, 3 * D, 0, n_begin, n_end, tid);
   tg.load(gb, D, 0, n_begin, n_end, tid);
   float2 qsn = load_qs(n_begin);
+  tq.store(smem, tid);
+  tg.store(gt, tid);
+  __syncthreads();
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
-    __syncthreads();
-    tq.store(smem, tid);
-    tg.store(gt, tid);
     const float rmax = qsn.x, rinv = qsn.y;
-    __syncthreads();
-    if (n0 + TOK < n_end) {
+    const bool more = n0 + TOK < n_end;
+    if (more) {
       tq.load(qb, 3 * D, 0, n0 + TOK, n_end, tid);
       tg.load(gb, D, 0, n0 + TOK, n_end, tid);
       qsn = load_qs(n0 + TOK);
@@ -713,13 +725,25 @@ __global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__
       *reinterpret_cast<float4*>(&smem[li * LD3 + 2 * D + wave * DK + i0]) = ov;
     }
     __syncthreads();
-    constexpr int VPR = 3 * D / W;
+    constexpr int VPR = 3 * D / W, NOUT = (TOK * VPR + NTHR - 1) / NTHR;
+    typename GVec<T>::reg ovec[NOUT];
 #pragma unroll
-    for (int p = 0; p < (TOK * VPR + NTHR - 1) / NTHR; ++p) {
+    for (int p = 0; p < NOUT; ++p) {
+      const int idx = min(tid + p * NTHR, TOK * VPR - 1);
+      ovec[p] = GVec<T>::pack_lds(&smem[(idx / VPR) * LD3 + (idx % VPR) * W]);
+    }
+    __syncthreads();                       // the staging has been read: the region takes the next tile
+    if (more) {
+      tq.store(smem, tid);
+      tg.store(gt, tid);
+    }
+#pragma unroll
+    for (int p = 0; p < NOUT; ++p) {
       const int idx = tid + p * NTHR;
       const int t = idx / VPR, c = (idx % VPR) * W;
-      if (idx < TOK * VPR && n0 + t < n_end) GVec<T>::from_lds(dqkv + ((long long)b * N + n0 + t) * 3 * D + c, &smem[t * LD3 + c]);
+      if (idx < TOK * VPR && n0 + t < n_end) GVec<T>::store_g(dqkv + ((long long)b * N + n0 + t) * 3 * D + c, ovec[p]);
     }
+    __syncthreads();                       // the next tile is in place
   }
 }
 
