@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256) linattn_dctx_combine(const float* __restr
 //   dPT[i][t]  = sum_j dctx[i][j] v[t][j]      dk[t][i] = P[t][i] (dPT[i][t] - tvec[i])
 // writes dqkv [B*N][3d] (dq | dk | dv).  Same k-index convention and LDS row format as linattn_apply.
 template <typename T, int D>
-__global__ void __launch_bounds__(2 * D) linattn_bwd_apply(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ void __launch_bounds__(2 * D, 2) linattn_bwd_apply(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                           const float* __restrict__ stats, const float* __restrict__ tvec,
                                                           const float* __restrict__ qstat, T* __restrict__ dqkv, int N, int tokb) {
@@ -762,9 +762,9 @@ static int pick_splits(int B, int N, int* tokens_per_split) {
   return (N + tps - 1) / tps;
 }
 // tokens per workgroup of the per-token kernels: ~512 workgroups, whole tiles
-static int pick_tokb(int B, int N) {
-  int blocks = -1;
-  blocks = ltu_knob_pos("LTU_LA_TOKB_BLOCKS", 256);     // swept 256 .. 2048
+static int pick_tokb(int B, int N, int d) {
+  // d <= 128: two workgroups fit a CU (66 KB of LDS, <= 256 VGPRs) -> 512 workgroups; d = 256: one (132 KB) -> 256.  Swept 128 .. 1024.
+  const int blocks = ltu_knob_pos("LTU_LA_TOKB_BLOCKS", d <= 128 ? 512 : 256);
   long long per = ((long long)B * N + blocks - 1) / blocks;
   int tokb = (int)((per + 31) / 32 * 32);
   if (tokb < 32) tokb = 32;
@@ -792,7 +792,7 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
   int tps;
   const int nsplit = pick_splits(B, N, &tps);
   hipStream_t st = (hipStream_t)s;
-  const int tokb = pick_tokb(B, N);
+  const int tokb = pick_tokb(B, N, d);
   LTU_DISPATCH_T(dtype, {
     LA_DISPATCH_D(d, {
       hipLaunchKernelGGL((linattn_kv_partial<T, D>), dim3(nsplit, B), dim3(2 * D), 0, st, (const T*)qkv, part_ws, N, tps);
@@ -829,7 +829,7 @@ extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* c
   const int nsplit = pick_splits(B, N, &tps);
   hipStream_t st = (hipStream_t)s;
   const size_t lds_b = (size_t)(32 * (3 * d + 4) + 32 * (d + 4) + H * 96) * sizeof(float);
-  const int tokb = pick_tokb(B, N);
+  const int tokb = pick_tokb(B, N, d);
   LTU_DISPATCH_T(dtype, {
     LA_DISPATCH_D(d, {
       hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float), st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);

@@ -13,9 +13,12 @@ bash tools/profile_bench.sh
 cp gpurun_out/prof_bench_stats.csv gpurun_out/${R}_bench_kernel_stats.csv
 bash tools/pmc_step.sh
 cp gpurun_out/r02_pmc_step.json gpurun_out/${R}_pmc_step.json 2>/dev/null || true
+bash tools/pmc_valu.sh
+cp gpurun_out/pmc_valu.txt gpurun_out/${R}_pmc_valu.txt
 {
   echo "== bench_tail.py (transformer layer chain kernels vs the op-by-op launches they replace)"; (cd tools && python3 bench_tail.py 2>/dev/null)
   echo; echo "== bench_nt.py (projections: forward kernel | weight gradient incl. second stage)"; python3 tools/bench_nt.py 2>/dev/null
+  echo; echo "== bench_la.py (linear-attention core, forward | backward)"; python3 tools/bench_la.py 2>/dev/null
   echo; echo "== bench_pw.py (LayerNorm, GELU, InstanceNorm)"; python3 tools/bench_pw.py 2>/dev/null
   echo; echo "== bench_conv.py (3x3x3 convs, stride 1)"; python3 tools/bench_conv.py 2>/dev/null
   echo; echo "== bench_class.py (sub-pixel un-embedding forward)"; python3 tools/bench_class.py 2>/dev/null
