@@ -407,6 +407,191 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   }
 }
 
+// The same with the weights in REGISTERS (27 x CC/16 operand fragments per wave: 108 / 216 VGPRs).  In the kernel above every
+// MFMA reads both operands from LDS - 2 KB per 32-cycle instruction and wave, twice what a CU's LDS delivers to four waves - so
+// it is LDS-bound at half the MFMA rate.  Weight fragments that never change are the natural register residents: one LDS read
+// per MFMA is left, and the LDS holds the halo (= output staging) only.
+template <int CC>
+__global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs a, int bricks) {
+  constexpr int VPV = CC / 8, KS = CC / 16, LDC = 40;
+  constexpr int NH = (HALO_VOX * VPV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * CC];     // also the 128 x LDC output staging
+  static_assert(HALO_VOX * CC >= 128 * LDC, "staging fits");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
+
+  // weights once, straight into operand registers: lane (n = li, lh) holds channels ks*16 + lh*8 .. +7 of tap t (mirrored taps for
+  // the data gradient are handled by the halo offset, as above)
+  bf16x8 wreg[27][KS];
+  {
+    const int n = min(li, a.N - 1);
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = min(ks * 16 + lh * 8, a.C - 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + ((long long)n * 27 + t) * a.C + c);
+        const bool ok = li < a.N && ks * 16 + lh * 8 < a.C;
+        wreg[t][ks] = __builtin_bit_cast(bf16x8, ok ? v : make_uint4(0u, 0u, 0u, 0u));
+      }
+  }
+
+  // Index arithmetic is hoisted out of the brick loop: a thread always stages the same halo pieces and stores the same output
+  // pieces relative to the brick origin, and the brick coordinates advance incrementally (a first version re-derived all of
+  // it per brick: ~900 scalar / vector ALU instructions around 27 MFMAs).
+  struct BrickPos { int b, bh, bw, bd; };
+  auto decompose = [&](int brick) {
+    BrickPos q;
+    int t = brick;
+    q.bd = t % nbd; t /= nbd;
+    q.bw = t % nbw; t /= nbw;
+    q.bh = t % nbh;
+    q.b = t / nbh;
+    return q;
+  };
+  const BrickPos stepd = decompose((int)gridDim.x);
+  auto advance = [&](BrickPos& q) {
+    q.bd += stepd.bd; if (q.bd >= nbd) { q.bd -= nbd; ++q.bw; }
+    q.bw += stepd.bw; if (q.bw >= nbw) { q.bw -= nbw; ++q.bh; }
+    q.bh += stepd.bh; if (q.bh >= nbh) { q.bh -= nbh; ++q.b; }
+    q.b += stepd.b;
+  };
+  int p_hh[NH], p_hw[NH], p_hd[NH], p_ld[NH];
+  long long p_rel[NH];
+  const uint16_t* p_src[NH];
+  bool p_ok[NH];
+#pragma unroll
+  for (int p = 0; p < NH; ++p) {
+    const int idx = tid + p * 256;
+    const int hv = idx / VPV, part = idx - hv * VPV;
+    p_hd[p] = hv % HALO_D; p_hw[p] = (hv / HALO_D) % HALO_W; p_hh[p] = hv / (HALO_D * HALO_W);
+    const int c = part * 8;
+    p_ok[p] = idx < HALO_VOX * VPV && c < a.C;
+    p_src[p] = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + c : reinterpret_cast<const uint16_t*>(a.x1) + (c - a.c0);
+    p_ld[p] = c < a.c0 ? a.lda0 : a.lda1;
+    p_rel[p] = ((long long)(p_hh[p] - 1) * a.W + (p_hw[p] - 1)) * a.D + (p_hd[p] - 1);
+  }
+  uint4 hreg[NH];
+  auto load_halo = [&](const BrickPos& q) {
+    const int h0 = q.bh * 4, w0 = q.bw * 4, d0 = q.bd * 8;
+    const long long vox0 = (((long long)q.b * a.H + h0) * a.W + w0) * a.D + d0;
+#pragma unroll
+    for (int p = 0; p < NH; ++p) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      const int h = h0 - 1 + p_hh[p], w = w0 - 1 + p_hw[p], d = d0 - 1 + p_hd[p];
+      if (p_ok[p] && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
+        v = *reinterpret_cast<const uint4*>(p_src[p] + (vox0 + p_rel[p]) * p_ld[p]);
+      hreg[p] = v;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int p = 0; p < NH; ++p) {
+      const int idx = tid + p * 256;
+      if (idx < HALO_VOX * VPV) {
+        const int hv = idx / VPV, part = idx - hv * VPV;
+        const int slot = CC == 32 ? (part ^ ((hv >> 2) & 1)) : part;
+        *reinterpret_cast<uint4*>(&halo[hv * CC + slot * 8]) = hreg[p];
+      }
+    }
+  };
+
+  const int hv0 = (wave * HALO_W + (li >> 3)) * HALO_D + (li & 7);      // halo voxel of this lane's row at tap (0,0,0)
+  float4 bv4[4];                           // bias of this lane's 4 x 4 consecutive output channels
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int n = 8 * rr + 4 * lh;
+    bv4[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias != nullptr) {               // uniform test; the 4 loads inside are unconditional (clamped index, selected afterwards)
+      const float b0 = a.bias[min(n + 0, a.N - 1)], b1 = a.bias[min(n + 1, a.N - 1)], b2 = a.bias[min(n + 2, a.N - 1)],
+                  b3 = a.bias[min(n + 3, a.N - 1)];
+      bv4[rr] = make_float4(n + 0 < a.N ? b0 : 0.f, n + 1 < a.N ? b1 : 0.f, n + 2 < a.N ? b2 : 0.f, n + 3 < a.N ? b3 : 0.f);
+    }
+  }
+  uint16_t* Cs = halo;
+
+  int brick = blockIdx.x;
+  BrickPos cur = decompose(brick), nxt = cur;
+  if (brick < bricks) load_halo(cur);
+  // output pieces of this thread: rows (tid >> 3) + 32 it, 4 channels from (tid & 7) * 4
+  const int o_w = tid >> 6, o_d = (tid >> 3) & 7, o_n = (tid & 7) * 4;
+  uint16_t* const o_base = o_n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + o_n : reinterpret_cast<uint16_t*>(a.o1) + (o_n - a.n0);
+  const int o_ld = o_n < a.n0 ? a.ldo0 : a.ldo1;
+  // The output stores of a brick are issued AFTER the next brick's halo registers have gone to LDS (a wait for the halo loads
+  // placed behind freshly issued stores would also wait for their acknowledgement: vmcnt is one in-order counter).  Deferring
+  // them by a whole brick was tried as well: 59 -> 55 us at C = 16 but 78 -> 92 us at C = 32; not kept.
+  if (brick < bricks) store_halo();
+  __syncthreads();
+  for (; brick < bricks; brick += gridDim.x) {
+    advance(nxt);
+    const bool more = brick + (int)gridDim.x < bricks;
+    if (more) load_halo(nxt);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // taps in 9 groups of 3 (one d-run); all fragments of a group are fetched before its MFMAs are issued (pinned with
+    // sched_barrier: left alone, hipcc sinks each ds_read next to its MFMA, which then waits an LDS round trip).
+    // Transposed product D[n][voxel]: a lane then owns 4 consecutive channels of one voxel (8-byte staging writes).
+    auto load_group = [&](int gidx, bf16x8 (&av)[3][KS]) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int tap = gidx * 3 + q;
+        const int ts = a.flip ? 26 - tap : tap;      // data gradient: tap t reads the mirrored halo offset
+        const int th = ts / 9, tw = (ts / 3) % 3, td = ts % 3;
+        const int hv = hv0 + (th * HALO_W + tw) * HALO_D + td;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ca = CC == 32 ? (((ks * 2 + lh) ^ ((hv >> 2) & 1)) << 3) : (lh << 3);
+          av[q][ks] = *reinterpret_cast<const bf16x8*>(&halo[hv * CC + ca]);
+        }
+      }
+    };
+    auto mma_group = [&](int gidx, const bf16x8 (&av)[3][KS]) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[gidx * 3 + q][ks], av[q][ks], acc, 0, 0, 0);
+    };
+    // one fragment set per group (a second set, the reads of group g+1 in flight during the MFMAs of group g, was slower:
+    // 48 -> 79 us at C = 16)
+#pragma unroll
+    for (int gi = 0; gi < 9; ++gi) {
+      bf16x8 avA[3][KS];
+      load_group(gi, avA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group(gi, avA);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                       // every wave is done with the halo: it becomes the output staging
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      uint2 pk;
+      pk.x = pack_bf16x2(acc[4 * rr + 0] + bv4[rr].x, acc[4 * rr + 1] + bv4[rr].y);
+      pk.y = pack_bf16x2(acc[4 * rr + 2] + bv4[rr].z, acc[4 * rr + 3] + bv4[rr].w);
+      *reinterpret_cast<uint2*>(&Cs[(wave * 32 + li) * LDC + 8 * rr + 4 * lh]) = pk;
+    }
+    __syncthreads();
+    uint2 ov[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const uint2*>(&Cs[((tid >> 3) + 32 * it) * LDC + o_n]);
+    __syncthreads();                       // the staging has been read: the region takes the next halo
+    if (more) store_halo();
+    {
+      const int h0 = cur.bh * 4, w = cur.bw * 4 + o_w, d = cur.bd * 8 + o_d;
+      const long long vox0 = (((long long)cur.b * a.H + h0) * a.W + w) * a.D + d;
+      const bool ok = o_n < a.N && w < a.W && d < a.D;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {     // row ml = (tid >> 3) + 32 it is brick voxel (h = it, w = o_w, d = o_d)
+        if (!ok || h0 + it >= a.H) continue;
+        *reinterpret_cast<uint2*>(o_base + (vox0 + (long long)it * a.W * a.D) * o_ld) = ov[it];
+      }
+    }
+    __syncthreads();                       // the next halo is in place
+    cur = nxt;
+  }
+}
+
 // returns LTU_OK after launching, or 1 when the shape is not handled here (the caller falls back to the implicit GEMM)
 // out[v][n] = bf16(sum_z part[z][v][n] + bias[n]); 4 columns per thread (N, n0 are multiples of 4)
 __global__ void __launch_bounds__(256) conv_halo_fold_kernel(const HaloArgs a, long long M) {
@@ -464,6 +649,15 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
     int wsb = -1;
     wsb = ltu_knob_pos("LTU_HALO_WS_BLOCKS", 512);
     const unsigned nblk = (unsigned)(bricks < wsb ? bricks : wsb);
+    // weights in registers (one LDS operand per MFMA): 59 -> 49 us at C = 16 (236 VGPRs, two workgroups per CU); at C = 32 the
+    // 216 weight registers leave one wave per SIMD and the gain is lost (80 vs 78 us), so the LDS-weights kernel stays there
+    if (ltu_knob("LTU_HALO_WR", a.C <= 16 ? 1 : 0)) {
+      const int wrb = ltu_knob_pos("LTU_HALO_WR_BLOCKS", a.C > 16 ? 256 : 512);
+      const unsigned nb = (unsigned)(bricks < wrb ? bricks : wrb);
+      if (a.C > 16) hipLaunchKernelGGL((conv3_halo_wr_bf16_kernel<32>), dim3(nb), dim3(256), 0, st, a, (int)bricks);
+      else hipLaunchKernelGGL((conv3_halo_wr_bf16_kernel<16>), dim3(nb), dim3(256), 0, st, a, (int)bricks);
+      return ltu_check_launch();
+    }
     if (a.C > 16) hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<32>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     return ltu_check_launch();
