@@ -74,23 +74,54 @@ __device__ __forceinline__ float& f4at(float4& v, int i) { return reinterpret_ca
 __device__ __forceinline__ float f4at(const float4& v, int i) { return reinterpret_cast<const float*>(&v)[i]; }
 
 // ---- wave / block reductions (64-wide wavefronts) ----------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// All-lanes ("butterfly") reductions without the LDS crossbar: four DPP steps give every lane of a 16-lane row the row's value
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows and wave
+// halves - with both operands a copy of v, a + b (or max(a, b)) is the combined value in EVERY lane, no select needed.
+// `__shfl_xor` compiles to ds_bpermute_b32: an LDS round trip (~100 cycles) per step, and the steps of a reduction are
+// dependent: two LayerNorm reductions over 64 lanes cost ~1 300 cycles per row pass and made up a third of the chain kernels.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+struct LtuAdd { static __device__ __forceinline__ float op(float a, float b) { return a + b; } };
+struct LtuMax { static __device__ __forceinline__ float op(float a, float b) { return fmaxf(a, b); } };
+// combine with the other half of the wave (lane ^ 32) / the neighbouring 16-lane row (lane ^ 16)
+// (inline asm: the builtins __builtin_amdgcn_permlane16_swap / 32_swap of hipcc 7.2 return the FIRST result for both elements of
+// their pair - `v_permlane16_swap v1, v2` followed by two uses of v1 -; the s_nop pairs cover the VALU -> swap -> VALU wait
+// states the compiler would otherwise insert)
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <typename OP>
+__device__ __forceinline__ float xhalf_combine(float v) {
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  return OP::op(a, b);
+}
+template <typename OP>
+__device__ __forceinline__ float xrow_combine(float v) {
+  float a = v, b = v;
+  permlane16_swap(a, b);
+  return OP::op(a, b);
+}
+// reduce over aligned groups of G lanes (G power of two <= 64); every lane of the group receives the result
+template <int G, typename OP>
+__device__ __forceinline__ float group_reduce(float v) {
+  if (G >= 2) v = OP::op(v, dpp_mov<0xB1>(v));       // quad_perm [1,0,3,2]
+  if (G >= 4) v = OP::op(v, dpp_mov<0x4E>(v));       // quad_perm [2,3,0,1]
+  if (G >= 8) v = OP::op(v, dpp_mov<0x141>(v));      // row_half_mirror
+  if (G >= 16) v = OP::op(v, dpp_mov<0x140>(v));     // row_mirror
+  if (G >= 32) v = xrow_combine<OP>(v);
+  if (G >= 64) v = xhalf_combine<OP>(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-// reduce over aligned groups of G lanes (G power of two <= 64)
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_reduce<G, LtuAdd>(v); }
+__device__ __forceinline__ float wave_sum(float v) { return group_reduce<64, LtuAdd>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_reduce<64, LtuMax>(v); }
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------
 // Stateless: the keep bits of the 4-element group g4 are a hash of (seed, step counter, g4), so the backward kernels

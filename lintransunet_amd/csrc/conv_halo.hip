@@ -1499,8 +1499,8 @@ __global__ void __launch_bounds__(256) upconv_wgrad_class_bf16_kernel(const UpWg
         }
       }
   if (do_bias) {
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
+    bsum = xrow_combine<LtuAdd>(bsum);
+    bsum = xhalf_combine<LtuAdd>(bsum);
     const int n = n_blk + wn * 16 + (lane & 15);
     if (lane < 16 && n < a.Co) a.bpart[(long long)blockIdx.z * a.Co + n] = bsum;
   }

@@ -134,7 +134,7 @@ __device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ gra
   if (do_bias) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float t = bsum[i] + __shfl_xor(bsum[i], 32);
+      const float t = xhalf_combine<LtuAdd>(bsum[i]);
       if (lh == 0) bz[n_blk + (wm * 2 + i) * 32 + li] = t;
     }
   }

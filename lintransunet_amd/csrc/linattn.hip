@@ -31,7 +31,9 @@
 #define TOK 32
 #define PART_STRIDE (64 + 1024)
 
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// value of the other wave half (lane ^ 32) combined with this lane's: sum / max in both lanes (v_permlane32_swap, no LDS crossbar)
+__device__ __forceinline__ float xhalf_sum(float v) { return xhalf_combine<LtuAdd>(v); }
+__device__ __forceinline__ float xhalf_max(float v) { return xhalf_combine<LtuMax>(v); }
 
 // bf16 storage: the 32x32 products run on v_mfma_f32_32x32x16_bf16 (2 instructions of 8 passes per product instead of 16
 // fp32 instructions of 16 passes, which had made the per-token kernels matrix-core-bound).  Lane (li, lh) supplies the 8
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
 #pragma unroll 4
     for (int t = lh; t < TOK; t += 2)
       if (t < ntok) mt = fmaxf(mt, ks[t * ROW + li]);
-    mt = fmaxf(mt, xhalf(mt));
+    mt = xhalf_max(mt);
     const float m_new = fmaxf(m_run, mt);
     const float alpha = __expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
     m_run = m_new;
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
       }
     }
   }
-  const float s_tot = s_run + xhalf(s_run);
+  const float s_tot = xhalf_sum(s_run);
   float* out = part + (((long long)b * nsplit + sp) * H + wave) * PART_STRIDE;
   if (lh == 0) {
     out[li] = m_run;
@@ -299,14 +301,14 @@ __global__ void __launch_bounds__(2 * D) linattn_apply(const T* __restrict__ qkv
     float mx = -INFINITY;
 #pragma unroll
     for (int s = 0; s < 16; ++s) mx = fmaxf(mx, a[s]);
-    mx = fmaxf(mx, xhalf(mx));
+    mx = xhalf_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       a[s] = __expf(a[s] - mx);
       sum += a[s];
     }
-    sum += xhalf(sum);
+    sum = xhalf_sum(sum);
     const float inv = rs / sum;
     if (lh == 0 && n0 + li < n_end) {
       float* qs = qstat + (((long long)b * N + n0 + li) * H + wave) * 2;
@@ -415,14 +417,14 @@ __global__ void __launch_bounds__(256) linattn_apply_rows(const uint16_t* __rest
       float mx = a[0];
 #pragma unroll
       for (int s = 1; s < 16; ++s) mx = fmaxf(mx, a[s]);
-      mx = fmaxf(mx, xhalf(mx));
+      mx = xhalf_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         a[s] = __expf(a[s] - mx);
         sum += a[s];
       }
-      sum += xhalf(sum);
+      sum = xhalf_sum(sum);
       const float inv = rs / sum;
       st[hh] = make_float2(mx, inv);
 #pragma unroll
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(2 * D, 2) linattn_bwd_apply(const T* __restric
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) t += ctxA[s] * dcA[s];
-    t += xhalf(t);
+    t = xhalf_sum(t);
     if (lane < 32) cs[64 + lane] = t;
   }
   const bf16x8 ctxB[2] = {pack8(ctxA), pack8(ctxA + 8)}, dcTB[2] = {pack8(dcT), pack8(dcT + 8)};
@@ -706,7 +708,7 @@ __global__ void __launch_bounds__(2 * D, 2) linattn_bwd_apply(const T* __restric
         dot += qsv[r] * aq[r];
       }
     }
-    dot += xhalf(dot);
+    dot = xhalf_sum(dot);
     dot *= 5.65685424949238019521f;                           // sum_i p_i dqs_i = sqrt(32) * sum_i qs_i dqs_i
     __syncthreads();   // all waves finished reading the staged tile
 #pragma unroll

@@ -770,9 +770,14 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
 #pragma unroll
     for (int tp = 0; tp < 28; ++tp) {
       float4 v = tp < 27 ? wr[tp] : bs;
+      if constexpr (QV == 16) {            // lanes 16 and 32 apart hold the same channel quad: row / half exchanges, no LDS crossbar
+        v.x = xhalf_combine<LtuAdd>(xrow_combine<LtuAdd>(v.x)); v.y = xhalf_combine<LtuAdd>(xrow_combine<LtuAdd>(v.y));
+        v.z = xhalf_combine<LtuAdd>(xrow_combine<LtuAdd>(v.z)); v.w = xhalf_combine<LtuAdd>(xrow_combine<LtuAdd>(v.w));
+      } else {
 #pragma unroll
-      for (int o = QV; o < 64; o <<= 1) {
-        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+        for (int o = QV; o < 64; o <<= 1) {
+          v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+        }
       }
       if (lane < QV) *reinterpret_cast<float4*>(wsum + (wave * 28 + tp) * CC + lane * 4) = v;
     }

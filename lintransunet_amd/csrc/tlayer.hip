@@ -19,6 +19,9 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 tl_bf16x8;
 
 #define TL_ROWS 32
+#ifndef TL_QDEPTH
+#define TL_QDEPTH 8
+#endif
 
 struct TailArgs {
   const uint16_t* a;      // [M][d] attention output
@@ -60,7 +63,7 @@ __device__ __forceinline__ tl_bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_c
 // sinks each weight load next to its MFMA (one load in flight per wave, an L2 round trip per MFMA).
 template <int KS>
 struct TlQueue {
-  static constexpr int U = KS < 8 ? KS : 8;
+  static constexpr int U = KS < TL_QDEPTH ? KS : TL_QDEPTH;
   uint4 q[U];
 };
 
