@@ -43,6 +43,11 @@ int ltu_version(void);
  * the environment.  Results never depend on a knob beyond fp32 summation order.  Used by the tests to force code
  * paths (e.g. several tiles per split in the linear-attention reductions at small N). */
 int ltu_config_set(const char* name, int value, int clear);
+/* Self-test of the cross-lane reductions every norm / softmax / loss kernel builds on (DPP + v_permlane16/32_swap, common.h):
+ * sum[i] / mx[i] = sum / max of x over the aligned group of G lanes (G = 2 .. 64, a power of two) that holds element i; n is a
+ * multiple of 64.  Exists because the permlane-swap builtins of hipcc 7.2 miscompile (tests/test_gpu_ops.py keeps the inline-asm
+ * replacement honest on the hardware). */
+int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, int n, int G, ltu_stream_t s);
 
 /* ---- window embedding: model/Unet_3Dblock.py:123-136 ------------------------------------------
  * x f32 [B,1,H,W,D] (reference layout) -> y T [B,H/2,W/2,D,8]; channel kh*2+kw, channels 4..7 = 0

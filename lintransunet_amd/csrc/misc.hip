@@ -8,6 +8,30 @@
 
 extern "C" int ltu_version(void) { return 3; }
 
+// ---- self-test of the cross-lane reductions (common.h) ----------------------------------------------------------------
+template <int G>
+__global__ void selftest_reduce_kernel(const float* __restrict__ x, float* __restrict__ sum, float* __restrict__ mx, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float v = i < n ? x[i] : 0.f;          // n is a multiple of 64: whole waves only
+  const float s = group_reduce<G, LtuAdd>(v), m = group_reduce<G, LtuMax>(v);
+  if (i < n) { sum[i] = s; mx[i] = m; }
+}
+extern "C" int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, int n, int G, ltu_stream_t s) {
+  if (n <= 0 || n % 64) return LTU_E_SHAPE;
+  const dim3 grid((unsigned)(n / 64)), block(64);
+  hipStream_t st = (hipStream_t)s;
+  switch (G) {
+    case 2: hipLaunchKernelGGL(selftest_reduce_kernel<2>, grid, block, 0, st, x, sum, mx, n); break;
+    case 4: hipLaunchKernelGGL(selftest_reduce_kernel<4>, grid, block, 0, st, x, sum, mx, n); break;
+    case 8: hipLaunchKernelGGL(selftest_reduce_kernel<8>, grid, block, 0, st, x, sum, mx, n); break;
+    case 16: hipLaunchKernelGGL(selftest_reduce_kernel<16>, grid, block, 0, st, x, sum, mx, n); break;
+    case 32: hipLaunchKernelGGL(selftest_reduce_kernel<32>, grid, block, 0, st, x, sum, mx, n); break;
+    case 64: hipLaunchKernelGGL(selftest_reduce_kernel<64>, grid, block, 0, st, x, sum, mx, n); break;
+    default: return LTU_E_ARG;
+  }
+  return ltu_check_launch();
+}
+
 // ---- knob overrides (ltu_config_set): a small table under a mutex; see common.h ------------------------------------------
 namespace {
 struct KnobOverride { char name[40]; int value; };

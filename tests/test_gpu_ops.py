@@ -779,3 +779,20 @@ def test_label_pyramid(ops):
     got = train.label_pyramid(lab.to(DEV), 5)
     for a, b in zip(got, ref):
         assert torch.equal(a.cpu().float(), b[:, 0].float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('G', [2, 4, 8, 16, 32, 64])
+def test_group_reduce_selftest(G):
+    """the DPP / permlane-swap reductions of common.h against torch, all-negative input (a zero injected by a mis-set DPP bound
+    control, or a swap that returns one half twice, shows in the max as well as in the sum)"""
+    from lintransunet_amd import _lib
+    from lintransunet_amd.ops import _p, _s
+    g = torch.Generator().manual_seed(G)
+    x = (-1.0 - 3.0 * torch.rand(64 * 12, generator=g)).to(DEV)
+    s, m = torch.empty_like(x), torch.empty_like(x)
+    _lib.call('ltu_selftest_group_reduce', _p(x), _p(s), _p(m), x.numel(), G, _s())
+    ref_s = x.view(-1, G).sum(1, keepdim=True).expand(-1, G).reshape(-1)
+    ref_m = x.view(-1, G).max(1, keepdim=True).values.expand(-1, G).reshape(-1)
+    assert torch.allclose(s, ref_s, rtol=1e-5, atol=1e-5)
+    assert torch.equal(m, ref_m)
