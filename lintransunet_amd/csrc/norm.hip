@@ -66,6 +66,20 @@ static void launch_reduce_parts(const float* part, int nparts, int n, int groups
 }
 extern "C" long long ltu_norm_ws_floats(void) { return LTU_NORM_WS_FLOATS; }
 
+// sum over the workgroup's row groups of red[g][n] at column i: 8 independent LDS reads in flight (the plain loop is a chain of up
+// to 64 dependent-latency reads executed by 32 of the 256 threads at the end of every statistics workgroup)
+__device__ __forceinline__ float in_fold_rowgroups(const float* red, int nrg, int n, int i) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int g = 0;
+  for (; g + 8 <= nrg; g += 8) {
+    const float* p = red + (long long)g * n + i;
+    const float v0 = p[0], v1 = p[n], v2 = p[2 * n], v3 = p[3 * n], v4 = p[4 * n], v5 = p[5 * n], v6 = p[6 * n], v7 = p[7 * n];
+    a0 += v0 + v4; a1 += v1 + v5; a2 += v2 + v6; a3 += v3 + v7;
+  }
+  for (; g < nrg; ++g) a0 += red[(long long)g * n + i];
+  return (a0 + a1) + (a2 + a3);
+}
+
 // grid (nchunks, B), block 256.  x [B][S][C]; sums [B][C][3] must be zero on entry.
 template <typename T>
 __global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, float* __restrict__ ws, long long S,
@@ -94,8 +108,7 @@ __global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict
   }
   __syncthreads();
   for (int i = tid; i < C * 2; i += blockDim.x) {
-    float acc = 0.f;
-    for (int g = 0; g < nrg; ++g) acc += red[(long long)g * C * 2 + i];
+    const float acc = in_fold_rowgroups(red, nrg, C * 2, i);
     const int c = i >> 1, which = i & 1;
     float* s = sums + ((long long)b * C + c) * 3;
     if (ws != nullptr) ws[((long long)b * gridDim.x + blockIdx.x) * C * 2 + i] = acc;
@@ -261,8 +274,7 @@ __global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __r
   }
   __syncthreads();
   for (int i = tid; i < C * 2; i += blockDim.x) {
-    float acc = 0.f;
-    for (int g = 0; g < nrg; ++g) acc += red[(long long)g * C * 2 + i];
+    const float acc = in_fold_rowgroups(red, nrg, C * 2, i);
     if (ws != nullptr) ws[((long long)b * gridDim.x + blockIdx.x) * C * 2 + i] = acc;
     else atomicAdd(bsums + (long long)b * C * 2 + i, acc);
   }
