@@ -307,6 +307,11 @@ int ltu_roi_resample(const void* in, void* out, int* plan_i, float* plan_f, int 
  * gradient of a second consumer of the output, summed on load. */
 int ltu_trilinear_up(const void* in, const void* in2, void* out, int adjoint, int B, int H, int W, int D, int C, int sd, int dtype,
                      ltu_stream_t s);
+/* The adjoint in separable form (one 1-D transposed interpolation per upsampled axis: at most 5 candidates per output instead of
+ * ~64 gathers).  ws: ltu_trilinear_adjoint_ws_elems(...) elements of the storage type; intermediates are rounded to it. */
+long long ltu_trilinear_adjoint_ws_elems(int B, int H, int W, int D, int C, int sd);
+int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, int B, int H, int W, int D, int C, int sd, int dtype,
+                          ltu_stream_t s);
 
 /* ---- deep-supervision losses of one level: loss/criterions.py:35-70,416-442,696-735;
  *      loss/multi_criterions.py:58-110,594-615 ------------------------------------------------------

@@ -95,6 +95,8 @@ SIGNATURES = {
     'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P, P],
     'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     'ltu_trilinear_up': [P, P, P, I, I, I, I, I, I, I, I, P],
+    'ltu_trilinear_adjoint_ws_elems': [I, I, I, I, I, I],
+    'ltu_trilinear_adjoint': [P, P, P, P, I, I, I, I, I, I, I, P],
     'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P, P],
     'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
     'ltu_label_maxpool': [P, P, I, I, I, I, I, P],
@@ -122,7 +124,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
-        fn.restype = c_longlong if (name.endswith('_ws_floats') or name == 'ltu_layer_tail_blocks') else c_int
+        fn.restype = c_longlong if (name.endswith(('_ws_floats', '_ws_elems')) or name == 'ltu_layer_tail_blocks') else c_int
     _lib = lib
     return lib
 

@@ -490,8 +490,140 @@ __global__ void __launch_bounds__(256) trilinear_bwd_tab_kernel(const T* __restr
   }
 }
 
+// Separable form of the adjoint: trilinear interpolation is a product of three 1-D linear interpolations, so its transpose is
+// three 1-D transposes applied one axis at a time (depth only when it was upsampled), each with at most 5 candidates per output
+// instead of ~64 (4 x 4 x 4) gathers in the kernels above - those are bound by the number of L1 requests, not by bytes.
+// View per pass: in [outer][L_fine][inner] -> out [outer][L_coarse][inner], `inner` contiguous.  grid (outer * L_coarse, blocks).
+// 16-byte vectors of the storage type (8 bf16 / 4 fp32): accumulate NV floats
+template <typename T> struct TriVec;
+template <> struct TriVec<float> {
+  static constexpr int NV = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct TriVec<bf16_t> {
+  static constexpr int NV = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  }
+};
+// one output row (outer, l) per blockIdx.x; the candidate count n is uniform in the workgroup, so the body is instantiated per
+// n (all loads of a vector issued together, none wasted on empty slots)
+template <typename T, bool HAS2, int N>
+__device__ __forceinline__ void tri_adj1d_body(const T* ib, const T* ib2, T* ob, const int (&os)[8], const float (&ws)[8], long long inner,
+                                               long long nvec) {
+  constexpr int NV = TriVec<T>::NV;
+  for (long long v = (long long)blockIdx.y * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.y * 256) {
+    float q[N][NV], q2[N][NV];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      TriVec<T>::load(ib + (long long)os[k] * inner + v * NV, q[k]);
+      if constexpr (HAS2) TriVec<T>::load(ib2 + (long long)os[k] * inner + v * NV, q2[k]);
+    }
+    float acc[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int e = 0; e < NV; ++e) acc[e] += (HAS2 ? q[k][e] + q2[k][e] : q[k][e]) * ws[k];
+    TriVec<T>::store(ob + v * NV, acc);
+  }
+}
+struct TriEntry { int n; int o[8]; float w[8]; int pad[15]; };       // 128 bytes
+// entries [0, H) for the height axis, [H, H+W) width, [H+W, H+W+D) depth
+__global__ void tri_table_kernel(TriEntry* __restrict__ t, int H, int W, int D, int Ho, int Wo, int Do, TriScale sc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H + W + D) return;
+  int os[8];
+  float ws[8];
+  int n;
+  if (i < H) n = tri_cands(i, H, Ho, sc.h, sc.ih, os, ws);
+  else if (i < H + W) n = tri_cands(i - H, W, Wo, sc.w, sc.iw, os, ws);
+  else n = tri_cands(i - H - W, D, Do, sc.d, sc.id, os, ws);
+  t[i].n = n;
+  for (int q = 0; q < 8; ++q) { t[i].o[q] = q < n ? os[q] : os[0]; t[i].w[q] = q < n ? ws[q] : 0.f; }
+}
+template <typename T, bool HAS2>
+__global__ void __launch_bounds__(256) tri_adj1d_kernel(const T* __restrict__ in, const T* __restrict__ in2, T* __restrict__ out,
+                                                        int L_fine, int L_coarse, long long inner, const TriEntry* __restrict__ table) {
+  const unsigned row = blockIdx.x;
+  const unsigned outer = row / (unsigned)L_coarse, l = row - outer * (unsigned)L_coarse;
+  // the candidate list of the row comes from a table built once per call (tri_table_kernel): deriving it is a serial search
+  // with dynamically indexed arrays, ~150 instructions and scratch traffic - more than the few vectors a thread moves
+  const TriEntry* te = table + l;
+  int os[8];
+  float ws[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { os[q] = te->o[q]; ws[q] = te->w[q]; }
+  const int n = te->n;
+  const long long nvec = inner / TriVec<T>::NV;
+  const T* ib = in + (long long)outer * L_fine * inner;
+  const T* ib2 = HAS2 ? in2 + (long long)outer * L_fine * inner : nullptr;
+  T* ob = out + ((long long)outer * L_coarse + l) * inner;
+  if (n <= 1) tri_adj1d_body<T, HAS2, 1>(ib, ib2, ob, os, ws, inner, nvec);
+  else if (n == 2) tri_adj1d_body<T, HAS2, 2>(ib, ib2, ob, os, ws, inner, nvec);
+  else if (n == 3) tri_adj1d_body<T, HAS2, 3>(ib, ib2, ob, os, ws, inner, nvec);
+  else if (n == 4) tri_adj1d_body<T, HAS2, 4>(ib, ib2, ob, os, ws, inner, nvec);
+  else if (n == 5) tri_adj1d_body<T, HAS2, 5>(ib, ib2, ob, os, ws, inner, nvec);
+  else tri_adj1d_body<T, HAS2, 8>(ib, ib2, ob, os, ws, inner, nvec);
+}
+
 static float tri_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 static float tri_inv(int in, int out) { return (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1); }
+
+template <typename T>
+static void launch_tri_adj1d(const T* in, const T* in2, T* out, long long outer, int L_fine, int L_coarse, long long inner,
+                             const TriEntry* table, hipStream_t st) {
+  const long long nv = inner / TriVec<T>::NV;
+  unsigned gx = (unsigned)((nv + 255) / 256);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)(outer * L_coarse), gx);
+  if (in2 != nullptr) hipLaunchKernelGGL((tri_adj1d_kernel<T, true>), grid, dim3(256), 0, st, in, in2, out, L_fine, L_coarse, inner, table);
+  else hipLaunchKernelGGL((tri_adj1d_kernel<T, false>), grid, dim3(256), 0, st, in, (const T*)nullptr, out, L_fine, L_coarse, inner, table);
+}
+
+extern "C" long long ltu_trilinear_adjoint_ws_elems(int B, int H, int W, int D, int C, int sd) {
+  // depth pass output [B][2H][2W][D][C] (only when sd == 2) + width pass output [B][2H][W][D][C], in elements of the storage type,
+  // + the candidate tables (H + W + D entries of 128 bytes, counted as 4-byte elements at most)
+  const long long t2 = (long long)B * 2 * H * W * D * C;
+  return (sd == 2 ? 2 * t2 + t2 : t2) + (long long)(H + W + D + 1) * 64;
+}
+
+extern "C" int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, int B, int H, int W, int D, int C, int sd,
+                                     int dtype, ltu_stream_t s) {
+  if (C % 4 || (dtype == LTU_BF16 && C % 8) || (sd != 1 && sd != 2) || ws == nullptr) return LTU_E_SHAPE;
+  const int Ho = 2 * H, Wo = 2 * W, Do = sd * D;
+  if ((long long)B * Ho * Wo * D >= (1LL << 31)) return LTU_E_SHAPE;
+  hipStream_t st = (hipStream_t)s;
+  TriScale sc;
+  sc.h = tri_scale(H, Ho); sc.w = tri_scale(W, Wo); sc.d = tri_scale(D, Do);
+  sc.ih = tri_inv(H, Ho); sc.iw = tri_inv(W, Wo); sc.id = tri_inv(D, Do);
+  LTU_DISPATCH_T(dtype, {
+    const long long t2n = (long long)B * Ho * W * D * C;
+    T* t2 = (T*)ws;                                              // [B][Ho][W][D][C]
+    T* t1 = t2 + t2n;                                            // [B][Ho][Wo][D][C] (sd == 2 only)
+    T* tend = sd == 2 ? t1 + 2 * t2n : t1;
+    TriEntry* table = reinterpret_cast<TriEntry*>((reinterpret_cast<uintptr_t>(tend) + 127) & ~(uintptr_t)127);
+    hipLaunchKernelGGL(tri_table_kernel, dim3((unsigned)((H + W + D + 127) / 128)), dim3(128), 0, st, table, H, W, D, Ho, Wo, Do, sc);
+    const T* src = (const T*)dy;
+    const T* src2 = (const T*)dy2;
+    if (sd == 2) {                                               // depth: [B Ho Wo][Do -> D][C]
+      launch_tri_adj1d<T>(src, src2, t1, (long long)B * Ho * Wo, Do, D, C, table + H + W, st);
+      src = t1; src2 = nullptr;
+    }
+    launch_tri_adj1d<T>(src, src2, t2, (long long)B * Ho, Wo, W, (long long)D * C, table + H, st);       // width: [B Ho][Wo -> W][D C]
+    launch_tri_adj1d<T>(t2, (const T*)nullptr, (T*)dx, B, Ho, H, (long long)W * D * C, table, st);        // height: [B][Ho -> H][W D C]
+  });
+  return ltu_check_launch();
+}
 
 extern "C" int ltu_trilinear_up(const void* in, const void* in2, void* out, int adjoint, int B, int H, int W, int D, int C, int sd,
                                 int dtype, ltu_stream_t s) {

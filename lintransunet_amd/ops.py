@@ -1149,6 +1149,9 @@ def pos_conv(x, w, b, p=0.0, seed=0, fork=1):
     return _PosConv.apply(x, w, b, p, seed, fork)
 
 
+SEPARABLE_TRILINEAR_ADJOINT = True      # three 1-D passes instead of the 64-tap gather (tests flip it to compare)
+
+
 class _Trilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sd, fork):
@@ -1166,7 +1169,11 @@ class _Trilinear(torch.autograd.Function):
         B, H, W, D, C, sd = ctx.cfg
         g, g2, _ = _grads(gs)
         dx = torch.empty((B, H, W, D, C), device=g.device, dtype=g.dtype)
-        _lib.call('ltu_trilinear_up', _p(g), _p(g2), _p(dx), 1, B, H, W, D, C, sd, _dt(g), _s())
+        if SEPARABLE_TRILINEAR_ADJOINT and (C % 8 == 0 or g.dtype == torch.float32):
+            ws = torch.empty(_lib.load().ltu_trilinear_adjoint_ws_elems(B, H, W, D, C, sd), device=g.device, dtype=g.dtype)
+            _lib.call('ltu_trilinear_adjoint', _p(g), _p(g2), _p(dx), _p(ws), B, H, W, D, C, sd, _dt(g), _s())
+        else:
+            _lib.call('ltu_trilinear_up', _p(g), _p(g2), _p(dx), 1, B, H, W, D, C, sd, _dt(g), _s())
         return dx, None, None
 
 
