@@ -264,10 +264,11 @@ def main():
     from lintransunet_amd.ops import _p, _s
 
     def tail_bytes(ctx, a, x, *rest):
-        # forward: reads a, x; writes z1, t1, z2, y (d wide) and u, h (2d wide); backward: reads dy, dy2, z2, z1, u; writes dr2, dr1,
-        # dz1, da, du; weights (8 d^2 forward + 8 d^2 backward, bf16) are read once per launch from HBM
-        M, d = a.shape
-        return float((10 + 13) * M * d + 16 * d * d) * 2.0
+        # forward: reads q (the q third of the qkv rows: the attention's phase B runs inside the kernel), x; writes a, z1, t1, z2, y
+        # (d wide) and u, h (2d wide); backward: reads dy, dy2, z2, z1, u; writes dr2, dr1, dz1, da, du; weights (8 d^2 forward +
+        # 8 d^2 backward, bf16) are read once per launch from HBM
+        M, d = x.shape
+        return float((11 + 13) * M * d + 16 * d * d) * 2.0
     ops._LayerTail.forward = staticmethod(timer.wrap(ops._LayerTail.forward, tail_bytes, 'tail'))
     chain_cache = {}
 
@@ -286,6 +287,7 @@ def main():
             nblk = _lib.load().ltu_layer_tail_blocks(M)
             chain_cache[(M, d)] = dict(
                 a=bf(M, d), x=bf(M, d), dy=bf(M, d), dy2=bf(M, d), w=[fragw(d, d, 8), fragw(2 * d, d, 8), fragw(d, 2 * d, 8)],
+                qkv=bf(M, 3 * d), ctx=torch.randn(2 * (d // 32), 32, 32, device=dev) * 0.05, qstat=torch.empty(M, d // 32, 2, device=dev),
                 wt=[fragw(d, 2 * d, 9), fragw(2 * d, d, 9), fragw(d, d, 9)], bias=torch.zeros(2 * d, device=dev),
                 gamma=torch.ones(d, device=dev), md=[torch.empty(M, d, device=dev, dtype=torch.bfloat16) for _ in range(8)],
                 m2d=[torch.empty(M, 2 * d, device=dev, dtype=torch.bfloat16) for _ in range(3)],
@@ -293,14 +295,15 @@ def main():
         return chain_cache[(M, d)]
 
     def replay(c):
-        a_ = c[1]
-        M, d = a_.shape
+        M, d = c[2].shape                  # x [M, d] (c[1] is a [M, d] or, with the fused attention phase B, qkv [M, 3d])
+        fused = c[1].shape[1] == 3 * d
         q = chain_buffers(M, d)
         z1, t1, z2, y, dr2, dr1, dz1, da = q['md']
         u, h, du = q['m2d']
         _lib.call('ltu_layer_tail_fwd', _p(q['a']), _p(q['x']), _p(q['w'][0]), _p(q['w'][1]), _p(q['w'][2]), _p(q['bias']), _p(q['bias']),
                   _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y),
-                  _p(q['stat'][0]), _p(q['stat'][1]), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, 1, _s())
+                  _p(q['stat'][0]), _p(q['stat'][1]), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, _p(q['qkv']) if fused else 0,
+                  _p(q['ctx']) if fused else 0, _p(q['qstat']) if fused else 0, M // 2 if fused else 0, 1, _s())
         _lib.call('ltu_layer_tail_bwd', _p(q['dy']), _p(q['dy2']), _p(z2), _p(z1), _p(u), _p(q['stat'][1]), _p(q['stat'][0]), _p(q['gamma']),
                   _p(q['gamma']), _p(q['wt'][0]), _p(q['wt'][1]), _p(q['wt'][2]), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(q['lnws'][0]),
                   _p(q['lnws'][1]), M, d, 0.3, 11, 12, 13, 0, 1, 1, _s())

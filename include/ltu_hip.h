@@ -101,12 +101,16 @@ int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias
  * dropout masks are those of the op-by-op path (ltu_linear_fwd, ltu_layernorm_fwd, ltu_linear_gelu_fwd).
  * u_mode 0: `u` receives the FFN pre-activation (what ltu_gelu_dropout_bwd expects); u_mode 1: it receives
  * dropout_mask * gelu'(u) instead, the factor ltu_layer_tail_bwd (same u_mode) multiplies dh by - the forward pass has the
- * Gaussian terms at hand, and the backward chain then needs no exp / rcp / mask hash for this stage. */
+ * Gaussian terms at hand, and the backward chain then needs no exp / rcp / mask hash for this stage.
+ * qkv != NULL fuses phase B of the linear attention in front of the chain (trans_block.py:41-67 after the context has been
+ * formed): the block's q rows are read from qkv [M][3d], `ctx` [B*H][32][32] is the merged context of ltu_linattn_ctx,
+ * ntok = tokens per sample (a multiple of 32); `a` is then an OUTPUT ([M][d], the attention output the out-projection weight
+ * gradient needs) and qstat [M][H][2] receives the row statistics ltu_linattn_bwd expects.  qkv == NULL: `a` is the input. */
 int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void* w1, const void* w2, const float* bo,
                        const float* b1, const float* b2, const float* g1, const float* be1, const float* g2, const float* be2,
                        void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1, float* stat2, long long M, int d,
                        float eps, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int u_mode,
-                       int dtype, ltu_stream_t s);
+                       const void* qkv, const float* ctx, float* qstat, int ntok, int dtype, ltu_stream_t s);
 
 /* The backward of the same chain as ONE launch: LayerNorm 2 backward, data gradients through linear2 / GELU + dropout / linear1,
  * LayerNorm 1 backward (on dt1 + dz2), data gradient through the out projection.  dy2 (nullable): second gradient of y, summed on
@@ -220,6 +224,9 @@ int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int 
 int ltu_linattn_splits(int B, int N);
 int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws, int B, int N,
                     int d, int dtype, ltu_stream_t s);
+/* phase A of ltu_linattn_fwd alone: ctx [B*H][32][32] and colstats [B*H][64] (same workspace); phase B then runs inside
+ * ltu_layer_tail_fwd (its qkv / ctx / qstat arguments) */
+int ltu_linattn_ctx(const void* qkv, float* ctx, float* colstats, float* part_ws, int B, int N, int d, int dtype, ltu_stream_t s);
 /* dqkv [B*N][3d] from dout [B*N][d]; dctx [B*H][32][32] is a scratch output; tvec [B*H][32] is reserved (may be NULL: the term it
  * held is formed inside the per-token kernel since round 2) */
 int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const float* colstats, const float* qstat,
@@ -318,10 +325,12 @@ int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, i
  * p f32 [B][S][C] probabilities, label u8 [B][S].  total = w_ce*CE + w_bal*BalancedDice + sum_c w_dice[c]*Dice_c
  * + w_dice[4]*Dice of the foreground union (1 - p_0 vs label != 0: multi_criterions.py:30-56, DiceClassLoss0); w_dice: 5 host floats.
  * values (9 floats): [0] = total, [1] = CE, [2] = balanced Dice, [3+c] = Dice_c, [7] = union Dice, [8] = total again;
- * sums [B][C][4] zero-filled scratch;
+ * sums: scratch of ltu_loss_ws_floats(B, S, C) floats (no initialisation needed: per-block partial sums behind the final
+ * [B][C][4] sums, folded in a fixed order - no floating-point atomics, the loss and its gradient are reproducible bit for bit);
  * coef [B][C][3] feeds ltu_loss_bwd: dp = gscale[0] * dTotal/dp.  scale_dev (nullable): device-resident factor on all three
  * weights, read at run time (the per-epoch level weight of train3D.py:122-137 divided by the accumulation count of
  * utils/utils_3D_embed_full.py:85, so a captured graph follows both without re-capture). */
+long long ltu_loss_ws_floats(int B, long long S, int C);
 int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
                  float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s);
 int ltu_loss_bwd(const float* p, const uint8_t* label, const float* coef, const float* gscale, float* dp, int B,

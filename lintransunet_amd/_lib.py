@@ -39,7 +39,7 @@ SIGNATURES = {
     'ltu_wgrad_ws_floats': [L, I, I],
     'ltu_upconv_wgrad_ws_floats': [L, I, I],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
-    'ltu_layer_tail_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, U, U, U, P, I, I, P],
+    'ltu_layer_tail_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, U, U, U, P, I, P, P, P, I, I, P],
     'ltu_layer_tail_blocks': [L],
     'ltu_layer_tail_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, U, U, P, I, I, P],
     'ltu_reduce_batch': [P, I, P],
@@ -65,6 +65,7 @@ SIGNATURES = {
     'ltu_upconv_wgrad': [P, P, P, P, P, I, I, P, I, I, I, I, I, I, I, P],
     'ltu_linattn_splits': [I, I],
     'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],
+    'ltu_linattn_ctx': [P, P, P, P, I, I, I, I, P],
     'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     'ltu_window_gather': [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_vote_accumulate': [P, P, P, P, I, I, I, I, I, I, I, I, P],
@@ -97,6 +98,7 @@ SIGNATURES = {
     'ltu_trilinear_up': [P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_trilinear_adjoint_ws_elems': [I, I, I, I, I, I],
     'ltu_trilinear_adjoint': [P, P, P, P, I, I, I, I, I, I, I, P],
+    'ltu_loss_ws_floats': [I, L, I],
     'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P, P],
     'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
     'ltu_label_maxpool': [P, P, I, I, I, I, I, P],

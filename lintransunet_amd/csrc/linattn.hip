@@ -789,6 +789,14 @@ extern "C" int ltu_linattn_splits(int B, int N) {
   } while (0)
 
 extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws,
+                               int B, int N, int d, int dtype, ltu_stream_t s);
+// phase A alone (online softmax over the tokens + context, merged): for callers that run phase B themselves
+// (ltu_layer_tail_fwd with its qkv argument: the chain kernel applies the context to its own row block)
+extern "C" int ltu_linattn_ctx(const void* qkv, float* ctx, float* colstats, float* part_ws, int B, int N, int d, int dtype,
+                               ltu_stream_t s) {
+  return ltu_linattn_fwd(qkv, nullptr, ctx, colstats, nullptr, part_ws, B, N, d, dtype, s);
+}
+extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws,
                                int B, int N, int d, int dtype, ltu_stream_t s) {
   const int H = d / 32;
   int tps;
@@ -807,7 +815,9 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
       } else {
         hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part_ws, nsplit, nsplit, nullptr, colstats, ctx, H, 1);
       }
-      if constexpr (IsBf16<T>::value && D >= 128) {
+      if (out == nullptr) {
+        // phase A only (ltu_linattn_ctx)
+      } else if constexpr (IsBf16<T>::value && D >= 128) {
         // wave-private form: a wave per (4 heads, token chunk); ~LTU_LA_APPLY_WAVES waves in flight
         constexpr int CG = D / DK / LAW_HEADS;
         const long long tiles = cdiv(N, TOK);

@@ -53,7 +53,9 @@ __global__ void loss_sums_kernel(const float* __restrict__ p, const uint8_t* __r
   if (threadIdx.x < C * 4) {
     float v = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[w][threadIdx.x];
-    atomicAdd(sums + (long long)b * C * 4 + threadIdx.x, v);
+    // per-block partial [block][b][C*4] behind the final sums (no fp32 atomics: their order, and with it the last bit of every
+    // loss coefficient, changed from run to run - bf16 rounding downstream turns that bit into 1e-2 of some gradients)
+    sums[((long long)(1 + blockIdx.x) * gridDim.y + b) * C * 4 + threadIdx.x] = v;
   }
 }
 
@@ -66,8 +68,37 @@ struct LossCfg {
 
 // scale_dev (nullable): a device-resident factor applied to all loss weights of this level (the per-epoch deep-supervision weight
 // divided by the number of accumulated micro-steps): a captured HIP graph then follows weight changes without being re-captured.
-__global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ values, float* __restrict__ coef, int B,
+__global__ void loss_finalize_kernel(float* __restrict__ sums, int nblk, float* __restrict__ values, float* __restrict__ coef, int B,
                                      long long S, int C, LossCfg cfg, const float* __restrict__ scale_dev) {
+  {
+    // fold the per-block partials in a fixed order: output o = tid % nout is shared by the 256 / nout thread groups (each sums
+    // every ngrp-th block, 8 loads in flight), which meet in LDS
+    __shared__ float fold[256];
+    const int nout = B * C * 4;                          // <= 256
+    const int ngrp = 256 / nout;
+    const int o = threadIdx.x % nout, grp = threadIdx.x / nout;
+    float a0 = 0.f, a1 = 0.f;
+    if (grp < ngrp) {
+      const float* pp = sums + nout + o;
+      int z = grp;
+      for (; z + 7 * ngrp < nblk; z += 8 * ngrp) {
+        const float v0 = pp[(long long)z * nout], v1 = pp[(long long)(z + ngrp) * nout], v2 = pp[(long long)(z + 2 * ngrp) * nout],
+                    v3 = pp[(long long)(z + 3 * ngrp) * nout], v4 = pp[(long long)(z + 4 * ngrp) * nout],
+                    v5 = pp[(long long)(z + 5 * ngrp) * nout], v6 = pp[(long long)(z + 6 * ngrp) * nout],
+                    v7 = pp[(long long)(z + 7 * ngrp) * nout];
+        a0 += (v0 + v1) + (v2 + v3); a1 += (v4 + v5) + (v6 + v7);
+      }
+      for (; z < nblk; z += ngrp) a0 += pp[(long long)z * nout];
+    }
+    fold[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if ((int)threadIdx.x < nout) {
+      float t = 0.f;
+      for (int g = 0; g < ngrp; ++g) t += fold[g * nout + threadIdx.x];
+      sums[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (scale_dev != nullptr) {
     const float sc = scale_dev[0];
@@ -158,19 +189,26 @@ __global__ void loss_bwd_kernel(const float* __restrict__ p, const uint8_t* __re
   }
 }
 
-extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
-                            float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s) {
-  if (C < 1 || C > LOSS_MAXC) return LTU_E_SHAPE;
+static long long loss_rows(int B, long long S) {
   long long want = 1024 / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   long long rows = (S + want - 1) / want;
   if (rows < 256) rows = 256;
+  return rows;
+}
+extern "C" long long ltu_loss_ws_floats(int B, long long S, int C) { return (1 + cdiv(S, loss_rows(B, S))) * (long long)B * C * 4; }
+
+extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
+                            float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s) {
+  if (C < 1 || C > LOSS_MAXC || B * C * 4 > 256) return LTU_E_SHAPE;
+  const long long rows = loss_rows(B, S);
+  const int nblk = (int)cdiv(S, rows);
   LossCfg cfg;
   cfg.w_ce = w_ce; cfg.w_bal = w_bal;
   for (int c = 0; c < LOSS_MAXC; ++c) cfg.w_dice[c] = (c < C && w_dice) ? w_dice[c] : 0.f;
   cfg.w_fg = w_dice ? w_dice[LOSS_MAXC] : 0.f;
-  hipLaunchKernelGGL(loss_sums_kernel, dim3(cdiv(S, rows), B), dim3(256), 0, (hipStream_t)s, p, label, sums, S, C, (int)rows);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, sums, values, coef, B, S, C, cfg, scale_dev);
+  hipLaunchKernelGGL(loss_sums_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)s, p, label, sums, S, C, (int)rows);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, sums, nblk, values, coef, B, S, C, cfg, scale_dev);
   return ltu_check_launch();
 }
 

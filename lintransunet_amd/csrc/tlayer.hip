@@ -48,6 +48,13 @@ struct TailArgs {
   float eps, p;
   uint64_t seed1, seedg, seed2;               // dropout sites: after the out projection, after GELU, after linear2
   const uint64_t* step;
+  // fused attention phase B (ATTN kernels): q rows come from qkv [M][3d], the per-(sample, head) context from ctx [B*H][32][32];
+  // the attention output goes to a_out [M][d] (the out-projection weight gradient reads it) and the row statistics to qstat
+  const uint16_t* qkv;
+  const float* ctx;
+  uint16_t* a_out;
+  float* qstat;           // [M][H][2] = (row max, 1 / (row sum * sqrt(32)))
+  int ntok;               // tokens per sample (a multiple of 32: a row block never straddles samples)
   int u_mode;
   int dbg;                // ablation (tools/bench_tail.py): 2 = no GELU / dropout arithmetic, 4 = u and h are not stored
 };
@@ -145,7 +152,7 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
   }
 }
 
-template <int D>
+template <int D, bool ATTN>
 __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const TailArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;          // padded rows: +16 bytes rotates the banks from row to row
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
@@ -158,6 +165,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   uint16_t* HB = TB + TL_ROWS * LD;                   // [32][LDH]  x (stage 0-2), then h
   float* PB = reinterpret_cast<float*>(HB + TL_ROWS * LDH);   // bo[D] b1[2D] b2[D] g1[D] be1[D] g2[D] be2[D]: no parameter is loaded
                                                               // from global memory behind a store (see tl_issue)
+  float* QS = PB + 8 * D;                                     // ATTN: [32][H][2] row statistics of the block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
@@ -179,13 +187,68 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
     const int r = i / (D / 8), c = (i % (D / 8)) * 8;
     uint4 v = make_uint4(0u, 0u, 0u, 0u), xv = v;
     if (row0 + r < ta.M) {
-      v = *reinterpret_cast<const uint4*>(ta.a + (row0 + r) * D + c);
+      if constexpr (ATTN) v = *reinterpret_cast<const uint4*>(ta.qkv + (row0 + r) * (3 * D) + c);      // the q third of the row
+      else v = *reinterpret_cast<const uint4*>(ta.a + (row0 + r) * D + c);
       xv = *reinterpret_cast<const uint4*>(ta.x + (row0 + r) * D + c);
     }
     *reinterpret_cast<uint4*>(XA + r * LD + c) = v;
     *reinterpret_cast<uint4*>(HB + r * LD + c) = xv;
   }
-  __syncthreads();
+  if constexpr (ATTN) {
+    // Phase B of the linear attention (linattn.hip: linattn_apply_rows) on the block's q rows, wave = head: row softmax over the
+    // head's 32 channels, out^T[j][t] = sum_i ctx[i][j] qs[t][i] with A = ctx^T; the lane's quads of token li go back into XA in
+    // place - XA then holds the attention output `a`, which stage 1 consumes - and leave for global memory in whole rows below.
+    constexpr int H = D / 32;
+    const long long bh = (row0 / ta.ntok) * H + wave;
+    const float* cx = ta.ctx + bh * 1024;
+    tl_bf16x8 ca[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      tl_bf16x8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (__bf16)cx[(16 * lh + 8 * u + e) * 32 + li];
+      ca[u] = t;
+    }
+    __syncthreads();                       // the q rows are in XA
+    const uint16_t* qr = XA + li * LD + wave * 32 + 16 * lh;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(qr), v1 = *reinterpret_cast<const uint4*>(qr + 8);
+    const uint32_t wv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[2 * k] = __uint_as_float(wv[k] << 16); a[2 * k + 1] = __uint_as_float(wv[k] & 0xffff0000u); }
+    float mx = a[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, a[k]);
+    mx = xhalf_combine<LtuMax>(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a[k] = __expf(a[k] - mx); sum += a[k]; }
+    sum = xhalf_combine<LtuAdd>(sum);
+    const float inv = 0.17677669529663688110f / sum;      // 1 / (sqrt(32) * row sum)
+    if (lh == 0) *reinterpret_cast<float2*>(QS + (li * H + wave) * 2) = make_float2(mx, inv);
+    tl_bf16x8 p0, p1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p0[k] = (__bf16)(a[k] * inv); p1[k] = (__bf16)(a[8 + k] * inv); }
+    f32x16 oa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oa[r] = 0.f;
+    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], p0, oa, 0, 0, 0);
+    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], p1, oa, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<uint2*>(XA + li * LD + wave * 32 + 8 * q + 4 * lh) = pack_quad(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
+    __syncthreads();                       // `a` complete in XA
+    for (int i = tid; i < TL_ROWS * (D / 8); i += NTHR) {
+      const int r = i / (D / 8), c = (i % (D / 8)) * 8;
+      if (row0 + r < ta.M) *reinterpret_cast<uint4*>(ta.a_out + (row0 + r) * D + c) = *reinterpret_cast<const uint4*>(XA + r * LD + c);
+    }
+    for (int i = tid; i < TL_ROWS * H / 2; i += NTHR) {       // 32 rows x H pairs = TL_ROWS * H * 2 floats, 4 per thread
+      const int r = (i * 4) / (2 * H);
+      if (row0 + r < ta.M) *reinterpret_cast<float4*>(ta.qstat + row0 * (2 * H) + i * 4) = *reinterpret_cast<const float4*>(QS + i * 4);
+    }
+  } else {
+    __syncthreads();
+  }
   const float* bo = PB, *b1 = PB + D, *b2 = PB + 3 * D, *g1 = PB + 4 * D, *be1 = PB + 5 * D, *g2 = PB + 6 * D, *be2 = PB + 7 * D;
 
   // stage 1: out projection -> TB (bf16)
@@ -533,13 +596,16 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
                                   const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
                                   const float* be2, void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1,
                                   float* stat2, long long M, int d, float eps, float p, uint64_t seed1, uint64_t seedg,
-                                  uint64_t seed2, const uint64_t* step, int u_mode, int dtype, ltu_stream_t s) {
+                                  uint64_t seed2, const uint64_t* step, int u_mode, const void* qkv, const float* ctx, float* qstat,
+                                  int ntok, int dtype, ltu_stream_t s) {
   if (dtype != LTU_BF16) return LTU_E_DTYPE;
   if (d != 128 && d != 256) return LTU_E_SHAPE;
   if (u_mode != 0 && u_mode != 1) return LTU_E_ARG;
+  if (qkv != nullptr && (ctx == nullptr || qstat == nullptr || ntok <= 0 || ntok % TL_ROWS || M % ntok)) return LTU_E_ARG;
   if (M <= 0) return LTU_OK;
   TailArgs ta;
   ta.u_mode = u_mode;
+  ta.qkv = (const uint16_t*)qkv; ta.ctx = ctx; ta.qstat = qstat; ta.ntok = ntok; ta.a_out = (uint16_t*)const_cast<void*>(a);
   ta.a = (const uint16_t*)a; ta.x = (const uint16_t*)x;
   ta.wo = (const uint16_t*)wo; ta.w1 = (const uint16_t*)w1; ta.w2 = (const uint16_t*)w2;
   ta.bo = bo; ta.b1 = b1; ta.b2 = b2; ta.g1 = g1; ta.be1 = be1; ta.g2 = g2; ta.be2 = be2;
@@ -548,15 +614,17 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   ta.M = M; ta.eps = eps; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
   ta.dbg = ltu_knob("LTU_TAIL_DBG", 0);
   const unsigned blocks = cdiv(M, TL_ROWS);
-  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)8 * d * sizeof(float);
+  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)8 * d * sizeof(float) +
+                     (qkv != nullptr ? (size_t)TL_ROWS * (d / 32) * 2 * sizeof(float) : 0);
+  auto launch = [&](auto kern, unsigned threads) {
+    static LtuDevOnce once;                // one latch per kernel instantiation
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)s, ta);
+  };
   if (d == 256) {
-    static LtuDevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((tail_fwd_kernel<256>), dim3(blocks), dim3(512), lds, (hipStream_t)s, ta);
+    if (qkv != nullptr) launch(&tail_fwd_kernel<256, true>, 512); else launch(&tail_fwd_kernel<256, false>, 512);
   } else {
-    static LtuDevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((tail_fwd_kernel<128>), dim3(blocks), dim3(256), lds, (hipStream_t)s, ta);
+    if (qkv != nullptr) launch(&tail_fwd_kernel<128, true>, 256); else launch(&tail_fwd_kernel<128, false>, 256);
   }
   return ltu_check_launch();
 }

@@ -293,16 +293,20 @@ class MaskTransUnet(nn.Module):
             t = ops.wgrad_flush_point(t)     # the qkv data gradient is the last backward op of a layer
         qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
                          prep=wl[(id(lay), 'qkv')])
-        a = ops.linear_attention(qkv, B, N, d)
         po, p1, p2 = wl[(id(lay), 'o')], wl[(id(lay), 'f1')], wl[(id(lay), 'f2')]
         if (po is not None and po.frag is not None and d in (128, 256) and B * N <= ops.TAIL_MAX_TOKENS and B * N >= 64
                 and ops.USE_LAYER_TAIL):
-            # small token levels: the rest of the layer as one launch (csrc/tlayer.hip)
+            # the rest of the layer as one launch (csrc/tlayer.hip); with N a multiple of the kernel's 32-row blocks the
+            # attention's phase B runs inside it too (the chain kernel reads its q rows and applies the merged context)
             s1, sg, s2 = ((seeds.next(), seeds.next(), seeds.next()) if p > 0 else (0, 0, 0))
+            fuse = ops.FUSE_ATTN_APPLY and N % 32 == 0 and qkv.dtype == torch.bfloat16
+            a = qkv if fuse else ops.linear_attention(qkv, B, N, d)
             out = ops.layer_tail(a, tres, (lin[3].weight, lin[3].bias, lay.linear1.weight, lay.linear1.bias, lay.linear2.weight,
                                            lay.linear2.bias, lay.layer_norm1.weight, lay.layer_norm1.bias, lay.layer_norm2.weight,
-                                           lay.layer_norm2.bias), (po, p1, p2), 1e-6, p, (s1, sg, s2), fork=not last)
+                                           lay.layer_norm2.bias), (po, p1, p2), 1e-6, p, (s1, sg, s2), fork=not last,
+                                 attn=(B, N) if fuse else None)
             return out if not last else (out, out)
+        a = ops.linear_attention(qkv, B, N, d)
         a = ops.linear(a, [lin[3].weight], [lin[3].bias], prep=wl[(id(lay), 'o')])
         t, tres = ops.res_layernorm(tres, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0,
                                     fork=True)

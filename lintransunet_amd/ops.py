@@ -964,17 +964,33 @@ def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):
     return [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)], [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
 
 
+FUSE_ATTN_APPLY = True      # phase B of the linear attention inside the forward chain kernel (tests flip it to compare)
+
+
 class _LayerTail(torch.autograd.Function):
     """the post-attention half of a transformer layer (model/trans_block.py:203-211) as one launch (csrc/tlayer.hip):
     y = LN2(t1 + drop(W2 drop(gelu(W1 t1)))),  t1 = LN1(x + drop(Wo a)).  Backward: the op-by-op kernels on the saved tensors."""
 
     @staticmethod
-    def forward(ctx, a, x, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, preps, eps, p, seeds, fork):
+    def forward(ctx, a, x, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, preps, eps, p, seeds, fork, attn):
         lc = ctx.lc = current()
         _chk(a, 'a'); _chk(x, 'x')
-        M, d = a.shape
-        dev, dt = a.device, a.dtype
+        M, d = x.shape
+        dev, dt = x.device, x.dtype
         po, p1, p2 = preps
+        qkv = cx = colstats = qstat = None
+        if attn is not None:
+            # `a` is the fused projection output qkv [M, 3d]: phase A of the linear attention here, phase B inside the chain
+            # kernel (its row blocks read their q rows and apply the merged context), which also writes the attention output
+            B, N = attn
+            qkv, H = a, d // 32
+            nsplit = _lib.load().ltu_linattn_splits(B, N)
+            cx = torch.empty((B * H, 32, 32), device=dev, dtype=torch.float32)
+            colstats = torch.empty((B * H, 64), device=dev, dtype=torch.float32)
+            qstat = torch.empty((M, H, 2), device=dev, dtype=torch.float32)
+            ws = torch.empty(B * (nsplit + nsplit // 16 + 2) * H * 1088, device=dev, dtype=torch.float32)
+            _lib.call('ltu_linattn_ctx', _p(qkv), _p(cx), _p(colstats), _p(ws), B, N, d, _dt(qkv), _s())
+            a = torch.empty((M, d), device=dev, dtype=dt)
         z1, t1, z2, y = (torch.empty((M, d), device=dev, dtype=dt) for _ in range(4))
         u, h = (torch.empty((M, 2 * d), device=dev, dtype=dt) for _ in range(2))
         stat1, stat2 = (torch.empty((M, 2), device=dev, dtype=torch.float32) for _ in range(2))
@@ -983,11 +999,12 @@ class _LayerTail(torch.autograd.Function):
         u_mode = 1 if (USE_LAYER_TAIL_BWD and po.fragT is not None and p1.fragT is not None and p2.fragT is not None) else 0
         _lib.call('ltu_layer_tail_fwd', _p(a), _p(x), _p(po.frag), _p(p1.frag), _p(p2.frag), _p(bo), _p(b1), _p(b2), _p(g1), _p(be1),
                   _p(g2), _p(be2), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(stat1), _p(stat2), M, d, float(eps), float(p),
-                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), u_mode, _dt(a), _s())
+                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), u_mode, _p(qkv), _p(cx), _p(qstat), attn[1] if attn else 0, _dt(a), _s())
         ctx.save_for_backward(a, z1, stat1, t1, u, h, z2, stat2)
         ctx.params = (wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
         ctx.cfg = (preps, p, seeds)
         ctx.u_mode = u_mode
+        ctx.attn = None if attn is None else (attn, qkv, cx, colstats, qstat)
         return (y, y.view_as(y)) if fork else y
 
     @staticmethod
@@ -1050,7 +1067,7 @@ class _LayerTail(torch.autograd.Function):
             (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)
             (dw1,), (db1,) = _wgrad_now_or_group(lc, du, t1, [w1], [b1], M, 2 * d, d)
             (dwo,), (dbo,) = _wgrad_now_or_group(lc, dr1, a, [wo], [bo], M, d, d)
-            return da, dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None
+            return _LayerTail._attn_bwd(ctx, da), dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None, None
         dz2, dr2, dgm2, dbe2 = ln_bwd(g, g2, z2, stat2, gm2, be2, seeds[2])
         dh = dgrad(dr2, p2, w2, d, 2 * d)
         (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)
@@ -1061,13 +1078,31 @@ class _LayerTail(torch.autograd.Function):
         dz1, dr1, dgm1, dbe1 = ln_bwd(dt1, dz2, z1, stat1, gm1, be1, seeds[0])
         da = dgrad(dr1, po, wo, d, d)
         (dwo,), (dbo,) = _wgrad_now_or_group(lc, dr1, a, [wo], [bo], M, d, d)
-        return da, dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None
+        return _LayerTail._attn_bwd(ctx, da), dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None, None
+
+    @staticmethod
+    def _attn_bwd(ctx, da):
+        """gradient of the first input: da itself, or (fused attention) dqkv from the attention core's backward pass"""
+        if ctx.attn is None:
+            return da
+        (B, N), qkv, cx, colstats, qstat = ctx.attn
+        d = da.shape[1]
+        H = d // 32
+        nsplit = _lib.load().ltu_linattn_splits(B, N)
+        dqkv = torch.empty_like(qkv)
+        dctx = torch.empty_like(cx)
+        ws = torch.empty(B * nsplit * H * 1088, device=da.device, dtype=torch.float32)
+        _lib.call('ltu_linattn_bwd', _p(qkv), _p(da), _p(cx), _p(colstats), _p(qstat), _p(dqkv), _p(dctx), 0, _p(ws), B, N, d,
+                  _dt(qkv), _s())
+        return dqkv
 
 
-def layer_tail(a, x, lay_params, preps, eps, p, seeds, fork):
+def layer_tail(a, x, lay_params, preps, eps, p, seeds, fork, attn=None):
     """a: attention output [M,d], x: layer input [M,d]; lay_params = (Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2);
-    preps = LinPrep of (out, linear1, linear2) with fragment-ordered operands; seeds = dropout sites (LN1, GELU, LN2)"""
-    return _LayerTail.apply(a, x, *lay_params, preps, eps, p, tuple(seeds), fork)
+    preps = LinPrep of (out, linear1, linear2) with fragment-ordered operands; seeds = dropout sites (LN1, GELU, LN2).
+    attn = (B, N): `a` is the fused q|k|v projection [M, 3d] instead and the linear attention runs in front of the chain (its
+    phase B inside the chain kernel); the gradient returned for `a` is then dqkv."""
+    return _LayerTail.apply(a, x, *lay_params, preps, eps, p, tuple(seeds), fork, attn)
 
 
 # ---------------------------------------------------------------------------------------------- linear attention
@@ -1367,7 +1402,7 @@ class _LevelLoss(torch.autograd.Function):
         B, C = p.shape[0], p.shape[-1]
         S = p.numel() // (B * C)
         dev = p.device
-        sums = lc.scratch_zeros((B, C, 4), dev)
+        sums = torch.empty(_lib.load().ltu_loss_ws_floats(B, S, C), device=dev, dtype=torch.float32)      # partials + sums: no zero fill
         buf = torch.empty(9, device=dev, dtype=torch.float32)
         values = buf[:8]                 # the report (non-differentiable); buf[8] repeats the total as the differentiable output, so
         coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)          # no copy kernel is needed to separate the two
