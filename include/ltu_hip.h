@@ -292,9 +292,12 @@ int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* 
  * axes (D,H,W); nn.Dropout3d draws one keep/drop per (sample, channel). */
 int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C, float p,
                    uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
-/* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller); dy2 (nullable): gradient of a second consumer, summed on load */
-int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dw, float* db, int B, int H,
-                   int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+/* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller); dy2 (nullable): gradient of a second consumer, summed on load.
+ * ws: ltu_dwconv_bwd_ws_floats(...) floats for the per-workgroup partial sums of dw / db, folded in a fixed order; NULL falls
+ * back to float atomics (the two gradients then differ in the last bits from run to run). */
+long long ltu_dwconv_bwd_ws_floats(int B, int H, int W, int D, int C, int dtype);
+int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dw, float* db, float* ws, int B,
+                   int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- dynamic ROI: model/Unet_3Dblock.py:821-873, 37-49 (box), 51-82 (index maps), 985-1117 (warps) ----
  * prob f32 [B,H,W,D,C]: foreground = (1 - prob[...,0]) >= thr.  Writes box [B][6] = (x0,y0,0,x1,y1,D-1)

@@ -91,7 +91,8 @@ SIGNATURES = {
     'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, P, I, P],
-    'ltu_dwconv_bwd': [P, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
+    'ltu_dwconv_bwd_ws_floats': [I, I, I, I, I, I],
+    'ltu_dwconv_bwd': [P, P, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
     'ltu_roi_plan_size': [I, I, I, I, P, P, P],
     'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P, P],
     'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],

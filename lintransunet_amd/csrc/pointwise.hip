@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           T* __restrict__ y, float* __restrict__ dwt, float* __restrict__ db, int B,
                                                           int H, int W, int D, int C, int bricks, int bricks_per_block, float p,
-                                                          uint64_t seed, const uint64_t* step) {
+                                                          uint64_t seed, const uint64_t* step, float* __restrict__ part) {
   constexpr int CC = 128 / (int)sizeof(T);          // channels per chunk (one 128-byte LDS row per voxel)
   constexpr int QV = CC / 4;                        // channel quads per voxel
   constexpr int NV = 256 / QV;                      // voxel slots
@@ -787,19 +787,50 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
       const int cl = f / 27, tp = f - cl * 27;
       if (blockIdx.x * CC + cl >= C) continue;
       const float v = wsum[tp * CC + cl] + wsum[(28 + tp) * CC + cl] + wsum[(56 + tp) * CC + cl] + wsum[(84 + tp) * CC + cl];
-      atomicAdd(dwt + (long long)blockIdx.x * CC * 27 + f, v);
+      // two-stage (part != nullptr): this workgroup's sums go to part[block][chunk][28 CC] and dwconv_fold_kernel adds the blocks
+      // in a fixed order; the atomics of the fallback make these two gradients differ in the last bits from run to run
+      if (part != nullptr) part[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 28 * CC + f] = v;
+      else atomicAdd(dwt + (long long)blockIdx.x * CC * 27 + f, v);
     }
     if (tid < CC && blockIdx.x * CC + tid < C) {
       const float v = wsum[27 * CC + tid] + wsum[(28 + 27) * CC + tid] + wsum[(56 + 27) * CC + tid] + wsum[(84 + 27) * CC + tid];
-      atomicAdd(db + blockIdx.x * CC + tid, v);
+      if (part != nullptr) part[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 28 * CC + 27 * CC + tid] = v;
+      else atomicAdd(db + blockIdx.x * CC + tid, v);
     }
+  }
+}
+
+// dwt[chunk channels][27] / db[chunk channels] += sum over blocks of part[block][chunk][28 CC]; grid (nchunk, 28 CC / 64), block 256:
+// 64 consecutive outputs x 4 thread groups that share the blocks
+__global__ void __launch_bounds__(256) dwconv_fold_kernel(const float* __restrict__ part, int nblk, int nchunk, int CC, int C,
+                                                          float* __restrict__ dwt, float* __restrict__ db) {
+  __shared__ float red[3][64];
+  const int chunk = blockIdx.x, l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int f = blockIdx.y * 64 + l;                     // index inside the chunk's 28 CC run
+  float a0 = 0.f, a1 = 0.f;
+  if (f < 28 * CC) {
+    const float* p = part + (long long)chunk * 28 * CC + f;
+    const long long bs = (long long)nchunk * 28 * CC;
+    int z = grp;
+    for (; z + 12 < nblk; z += 16) { a0 += p[z * bs] + p[(z + 8) * bs]; a1 += p[(z + 4) * bs] + p[(z + 12) * bs]; }
+    for (; z < nblk; z += 4) a0 += p[z * bs];
+  }
+  const float a = a0 + a1;
+  if (grp > 0) red[grp - 1][l] = a;
+  __syncthreads();
+  if (grp != 0 || f >= 28 * CC) return;
+  const float v = a + red[0][l] + red[1][l] + red[2][l];
+  if (f < 27 * CC) {
+    if (chunk * CC + f / 27 < C) dwt[(long long)chunk * CC * 27 + f] += v;
+  } else if (chunk * CC + (f - 27 * CC) < C) {
+    db[chunk * CC + (f - 27 * CC)] += v;
   }
 }
 
 template <typename T, int MODE>
 static void launch_dwconv_halo(const void* x, const void* x2, const void* g, const void* g2, const float* w, const float* bias, void* y,
                                float* dwt, float* db, int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step,
-                               hipStream_t st) {
+                               hipStream_t st, float* part = nullptr) {
   constexpr int CC = 128 / (int)sizeof(T);
   const int nchunk = cdiv(C, CC);
   const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
@@ -809,7 +840,21 @@ static void launch_dwconv_halo(const void* x, const void* x2, const void* g, con
   const int bpb = (int)((bricks + nblk - 1) / nblk);
   nblk = (bricks + bpb - 1) / bpb;
   hipLaunchKernelGGL((dwconv_halo_kernel<T, MODE>), dim3(nchunk, (unsigned)nblk), dim3(256), 0, st, (const T*)x, (const T*)x2, (const T*)g,
-                     (const T*)g2, w, bias, (T*)y, dwt, db, B, H, W, D, C, (int)bricks, bpb, p, seed, step);
+                     (const T*)g2, w, bias, (T*)y, dwt, db, B, H, W, D, C, (int)bricks, bpb, p, seed, step, part);
+  if (MODE == 2 && part != nullptr)
+    hipLaunchKernelGGL(dwconv_fold_kernel, dim3(nchunk, (unsigned)cdiv(28 * CC, 64)), dim3(256), 0, st, part, (int)nblk, nchunk, CC, C, dwt, db);
+}
+// blocks x chunks x 28 CC floats of the weight-gradient pass (same geometry as launch_dwconv_halo<T, 2>)
+extern "C" long long ltu_dwconv_bwd_ws_floats(int B, int H, int W, int D, int C, int dtype) {
+  const int CC = dtype == LTU_BF16 ? 64 : 32;
+  const int nchunk = cdiv(C, CC);
+  const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
+  long long nblk = 512 / nchunk;
+  if (nblk < 1) nblk = 1;
+  if (nblk > bricks) nblk = bricks;
+  const int bpb = (int)((bricks + nblk - 1) / nblk);
+  nblk = (bricks + bpb - 1) / bpb;
+  return nblk * nchunk * 28LL * CC;
 }
 
 extern "C" int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int D, int C,
@@ -818,12 +863,12 @@ extern "C" int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, 
   LTU_DISPATCH_T(dtype, { launch_dwconv_halo<T, 0>(x, nullptr, nullptr, nullptr, w, bias, y, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s); });
   return ltu_check_launch();
 }
-extern "C" int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dwt, float* db, int B,
-                              int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+extern "C" int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dwt, float* db, float* ws,
+                              int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
   LTU_DISPATCH_T(dtype, {
     launch_dwconv_halo<T, 1>(dy, dy2, nullptr, nullptr, w, nullptr, dx, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s);
-    launch_dwconv_halo<T, 2>(x, nullptr, dy, dy2, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s);
+    launch_dwconv_halo<T, 2>(x, nullptr, dy, dy2, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s, ws);
   });
   return ltu_check_launch();
 }

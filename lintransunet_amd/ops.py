@@ -1173,8 +1173,9 @@ class _PosConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W, D, C, float(p), seed, lc.step_ptr(),
-                  _dt(x), _s())
+        ws = torch.empty(_lib.load().ltu_dwconv_bwd_ws_floats(B, H, W, D, C, _dt(x)), device=x.device, dtype=torch.float32)
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), _p(dw), _p(db), _p(ws), B, H, W, D, C, float(p), seed,
+                  lc.step_ptr(), _dt(x), _s())
         return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None, None
 
 

@@ -623,8 +623,8 @@ def test_full_size_properties():
 def test_step_is_reproducible():
     """two identical training steps (bf16 storage, reference channel configuration, 32^3 x 2) give bit-identical gradients: the
     reductions of the step are two-stage with a fixed order - the level losses included, whose fp32 atomics used to move the last
-    bit of every loss coefficient from run to run, which bf16 rounding downstream turned into 1e-2 of some gradients.  Only
-    the positional depthwise conv still sums its weight / bias gradient with atomics (1e-6 relative on those five tensors)."""
+    bit of every loss coefficient from run to run, which bf16 rounding downstream turned into 1e-2 of some gradients - and so is
+    the weight / bias gradient of the positional depthwise conv (the last atomics of the step)."""
     from lintransunet_amd import train
     cfg = O_net.NetConfig()
     x = seedgen.seeded_volume((2, 1, 32, 32, 32), 81).to(DEV)
@@ -643,7 +643,4 @@ def test_step_is_reproducible():
         l, g = run()
         assert l == l0
         for k in g0:
-            if 'pos_encoder' in k:
-                assert (g[k] - g0[k]).double().norm().item() <= 1e-4 * g0[k].double().norm().item() + 1e-12, k
-            else:
-                assert torch.equal(g[k], g0[k]), k
+            assert torch.equal(g[k], g0[k]), k
