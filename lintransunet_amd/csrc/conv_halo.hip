@@ -27,10 +27,13 @@ template <int WM, int WN, int TM, int TN, int TS>
 __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) {
   static_assert(WM * TM == 4 && WM * WN == 4, "128-row brick on 4 waves");
   constexpr int BN = WN * TN * 32, NSTAGE = 27 / TS;
-  constexpr int HALO_ELEMS = HALO_VOX * LDH, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
+  constexpr int HALO_ELEMS = HALO_VOX * 32, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
   constexpr int SMEM_ELEMS = (HALO_ELEMS + B_ELEMS) > STAGE_ELEMS ? (HALO_ELEMS + B_ELEMS) : STAGE_ELEMS;
   __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
-  uint16_t* halo = smem;                   // [HALO_VOX][LDH]
+  // halo image: voxel (hh, hw, hd) at row (hh * HALO_W + hw) * PD + hd, CC elements per row, the 16-byte parts XOR-ed with the
+  // low bits of hw (PD = 12 for 32-byte rows): conflict-free ds_read_b128 fragments for every tap (tools/lds_conflicts.py; the
+  // padded [360][40] image this kernel started with was a 3-way conflict)
+  uint16_t* halo = smem;
   uint16_t* Bs = smem + HALO_ELEMS;        // [2][TS][BN][LDH]
   constexpr int LBV = (TS * BN * 4 + 255) / 256;       // weight vectors per thread and stage (4 = max 16-byte parts per row)
 
@@ -46,6 +49,7 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
   const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
   const int n_blk = blockIdx.y * BN;
   const int VPV = a.CC / 8;                // 16-byte parts per voxel / weight row of one chunk
+  const int CCe = a.CC, PD = a.CC == 16 ? 12 : HALO_D, vmask = VPV - 1;
   const int nchunk = (a.C + a.CC - 1) / a.CC;
 
   f32x16 acc[TM][TN];
@@ -61,7 +65,7 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = (wm * TM + i) * 32 + li;
-    arow[i] = (((r >> 5) * HALO_W + ((r >> 3) & 3)) * HALO_D + (r & 7)) * LDH + lh * 8;
+    arow[i] = (((r >> 5) * HALO_W + ((r >> 3) & 3)) * PD + (r & 7)) * CCe;
   }
 
   uint4 hreg[6];
@@ -91,7 +95,8 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
       const int idx = tid + p * 256;
       if (idx < HALO_VOX * VPV) {
         const int hv = idx / VPV, part = idx - hv * VPV;
-        *reinterpret_cast<uint4*>(&halo[hv * LDH + part * 8]) = hreg[p];
+        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+        *reinterpret_cast<uint4*>(&halo[((hh * HALO_W + hw) * PD + hd) * CCe + ((part ^ (hw & vmask)) << 3)]) = hreg[p];
       }
     }
   };
@@ -140,11 +145,13 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
         const int tap = s * TS + t;
         int th = tap / 9, tw = (tap / 3) % 3, td = tap % 3;
         if (a.flip) { th = 2 - th; tw = 2 - tw; td = 2 - td; }
-        const int tapoff = ((th * HALO_W + tw) * HALO_D + td) * LDH;
+        const int tapoff = ((th * HALO_W + tw) * PD + td) * CCe;
+        const int sw = ((li >> 3) + tw) & vmask;
         for (int ks = 0; ks < ksteps; ++ks) {
           bf16x8 av[TM], bv[TN];
+          const int ca = ((ks * 2 + lh) ^ sw) << 3;
 #pragma unroll
-          for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&halo[arow[i] + tapoff + ks * 16]);
+          for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&halo[arow[i] + tapoff + ca]);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[((buf * TS + t) * BN + (wn * TN + j) * 32 + li) * LDH + ks * 16 + lh * 8]);
@@ -210,15 +217,20 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
 // MFMAs per wave and the kernel above is bound by workgroup turnover (8192 short-lived workgroups, each exposing one halo
 // round trip and re-streaming the same 27 weight tiles).  Here the whole weight tensor [27][32][CC] stays in LDS, a workgroup
 // is persistent over bricks and the next brick's halo is in flight (registers) during the current MFMAs and epilogue.
-// Unpadded LDS rows (2 workgroups per CU): 64-byte rows are bank-spread by slot = chunk ^ ((row >> 2) & 1), 32-byte rows
-// need nothing.
+// Unpadded LDS rows (2 workgroups per CU), bank-spread by XOR (see the kernel).
 template <int CC>
 __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs a, int bricks) {
   constexpr int VPV = CC / 8, KS = CC / 16, LDC = 40;
   constexpr int NH = (HALO_VOX * VPV + 255) / 256, NWV = (27 * 32 * VPV + 255) / 256;
-  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * CC];     // also the 128 x LDC output staging
+  // LDS images (bank analysis: tools/lds_conflicts.py).  Halo voxel (hh, hw, hd) at row (hh * HALO_W + hw) * PD + hd with its
+  // 16-byte parts XOR-ed by hw; weight row (tap, n) with its parts XOR-ed by n >> 2 (64-byte rows) or n >> 3 (32-byte rows).
+  // The images first written here (plain 32-byte voxels, 64-byte voxels XOR-ed by one bit of the row index) put the 16 lanes
+  // a ds_read_b128 serves together on the same 16-byte columns four times over for the halo and twice for the weights.
+  constexpr int PD = CC == 16 ? 12 : HALO_D;
+  constexpr int HROWS = HALO_H * HALO_W * PD;
+  __shared__ __attribute__((aligned(16))) uint16_t halo[HROWS * CC];        // also the 128 x LDC output staging
   __shared__ __attribute__((aligned(16))) uint16_t Wl[27 * 32 * CC];
-  static_assert(HALO_VOX * CC >= 128 * LDC, "staging fits");
+  static_assert(HROWS * CC >= 128 * LDC, "staging fits");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
@@ -243,7 +255,7 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
         const int part = idx % VPV, row = idx / VPV;
         const int n = row & 31;
         const uint4 v = (n < a.N && part * 8 < a.C) ? wv[p] : make_uint4(0u, 0u, 0u, 0u);
-        const int slot = CC == 32 ? (part ^ ((row >> 2) & 1)) : part;
+        const int slot = part ^ (CC == 32 ? ((row >> 2) & 3) : ((row >> 3) & 1));
         *reinterpret_cast<uint4*>(&Wl[row * CC + slot * 8]) = v;
       }
     }
@@ -302,15 +314,16 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
     for (int p = 0; p < NH; ++p) {
       const int idx = tid + p * 256;
       if (idx < HALO_VOX * VPV) {
-        const int hv = idx / VPV, part = idx - hv * VPV;
-        const int slot = CC == 32 ? (part ^ ((hv >> 2) & 1)) : part;
-        *reinterpret_cast<uint4*>(&halo[hv * CC + slot * 8]) = hreg[p];
+        const int part = idx % VPV;
+        const int row = (p_hh[p] * HALO_W + p_hw[p]) * PD + p_hd[p];
+        const int slot = part ^ (p_hw[p] & (VPV - 1));
+        *reinterpret_cast<uint4*>(&halo[row * CC + slot * 8]) = hreg[p];
       }
     }
   };
 
-  const int hv0 = (wave * HALO_W + (li >> 3)) * HALO_D + (li & 7);      // halo voxel of this lane's row at tap (0,0,0)
-  const int wsw = (li >> 2) & 1;
+  const int hv0 = (wave * HALO_W + (li >> 3)) * PD + (li & 7);          // halo row of this lane's voxel at tap (0,0,0)
+  const int wsw = CC == 32 ? ((li >> 2) & 3) : ((li >> 3) & 1);
   float4 bv4[4];                           // bias of this lane's 4 x 4 consecutive output channels
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
@@ -353,11 +366,12 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
         const int tap = gidx * 3 + q;
         const int ts = a.flip ? 26 - tap : tap;      // data gradient: tap t reads the mirrored halo offset
         const int th = ts / 9, tw = (ts / 3) % 3, td = ts % 3;
-        const int hv = hv0 + (th * HALO_W + tw) * HALO_D + td;
+        const int hv = hv0 + (th * HALO_W + tw) * PD + td;
+        const int sw = ((li >> 3) + tw) & (VPV - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const int ca = CC == 32 ? (((ks * 2 + lh) ^ ((hv >> 2) & 1)) << 3) : (lh << 3);
-          const int cb = CC == 32 ? (((ks * 2 + lh) ^ wsw) << 3) : (lh << 3);
+          const int ca = ((ks * 2 + lh) ^ sw) << 3;
+          const int cb = ((ks * 2 + lh) ^ wsw) << 3;
           av[q][ks] = *reinterpret_cast<const bf16x8*>(&halo[hv * CC + ca]);
           bv[q][ks] = *reinterpret_cast<const bf16x8*>(&Wl[(tap * 32 + li) * CC + cb]);
         }
@@ -407,16 +421,29 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   }
 }
 
-// The same with the weights in REGISTERS (27 x CC/16 operand fragments per wave: 108 / 216 VGPRs).  In the kernel above every
-// MFMA reads both operands from LDS - 2 KB per 32-cycle instruction and wave, twice what a CU's LDS delivers to four waves - so
-// it is LDS-bound at half the MFMA rate.  Weight fragments that never change are the natural register residents: one LDS read
-// per MFMA is left, and the LDS holds the halo (= output staging) only.
+// The same with the weights in REGISTERS (27 x CC/16 operand fragments per wave: 108 / 216 VGPRs): one LDS read per MFMA is
+// left.  In-kernel clock stamps of the first version of this loop (4 barriers per brick, output staging shared by the four waves,
+// addresses re-derived per brick with 64-bit per-lane multiplies) showed 1 270 of a brick's 4 100 cycles in the 27 MFMAs, 1 500 in
+// ISSUING three loads and four stores (address arithmetic), the rest in barriers and staging.  This version:
+//   * per-thread pointers are loop invariants; a brick adds one scalar offset (two with a concatenated input / split output);
+//   * the halo is double-buffered in LDS and the output staging is private to a wave (a wave's 32 voxels are one h plane of the
+//     brick), so ONE barrier per brick is left;
+//   * the halo of brick i + 2 is requested at the end of brick i, in front of that brick's output stores (vmcnt is one in-order
+//     counter: a wait for loads placed behind stores also waits for their acknowledgement), and goes to LDS at the end of brick
+//     i + 1; the loads are unconditional (clamped address, selected when written to LDS: a test around a load gives it a basic
+//     block and a wait of its own);
+//   * LDS image of the halo: voxel (hh, hw, hd) at row (hh * HALO_W + hw) * PD + hd, its 16-byte parts XOR-ed with the low bits
+//     of hw.  ds_read_b128 serves 16 lanes at a time ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32) from 64
+//     banks: a lane's voxel is (w = li >> 3, d = li & 7) + tap, so a group touches four w rows; with the plain [360][CC] image
+//     those land on the same 16-byte columns 4 times over (tools/lds_conflicts.py) and every fragment read took four LDS
+//     passes.  64-byte voxels: XOR with hw & 3; 32-byte voxels: d pitch 12 and XOR with hw & 1.
 template <int CC>
 __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs a, int bricks) {
   constexpr int VPV = CC / 8, KS = CC / 16, LDC = 40;
   constexpr int NH = (HALO_VOX * VPV + 255) / 256;
-  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * CC];     // also the 128 x LDC output staging
-  static_assert(HALO_VOX * CC >= 128 * LDC, "staging fits");
+  constexpr int PD = CC == 16 ? 12 : HALO_D;
+  constexpr int HROWS = HALO_H * HALO_W * PD, HELEMS = HROWS * CC, SELEMS = 32 * LDC;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * HELEMS + 4 * SELEMS];     // halo[2] | staging[4 waves]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int nbh = (a.H + 3) / 4, nbw = (a.W + 3) / 4, nbd = (a.D + 7) / 8;
@@ -437,9 +464,6 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
       }
   }
 
-  // Index arithmetic is hoisted out of the brick loop: a thread always stages the same halo pieces and stores the same output
-  // pieces relative to the brick origin, and the brick coordinates advance incrementally (a first version re-derived all of
-  // it per brick: ~900 scalar / vector ALU instructions around 27 MFMAs).
   struct BrickPos { int b, bh, bw, bd; };
   auto decompose = [&](int brick) {
     BrickPos q;
@@ -457,47 +481,67 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
     q.bh += stepd.bh; if (q.bh >= nbh) { q.bh -= nbh; ++q.b; }
     q.b += stepd.b;
   };
-  int p_hh[NH], p_hw[NH], p_hd[NH], p_ld[NH];
-  long long p_rel[NH];
-  const uint16_t* p_src[NH];
-  bool p_ok[NH];
+  auto origin = [&](const BrickPos& q) { return (((long long)q.b * a.H + q.bh * 4) * a.W + q.bw * 4) * a.D + q.bd * 8; };
+
+  // ---- halo pieces of this thread (loop invariants): source pointer at the brick origin's offset, LDS slot, halo coordinates
+  const char* h_ptr[NH];
+  int h_lds[NH], h_pos[NH];                // h_pos: hh | hw << 8 | hd << 16 | source 1 << 24 | exists << 25
 #pragma unroll
   for (int p = 0; p < NH; ++p) {
     const int idx = tid + p * 256;
     const int hv = idx / VPV, part = idx - hv * VPV;
-    p_hd[p] = hv % HALO_D; p_hw[p] = (hv / HALO_D) % HALO_W; p_hh[p] = hv / (HALO_D * HALO_W);
+    const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
     const int c = part * 8;
-    p_ok[p] = idx < HALO_VOX * VPV && c < a.C;
-    p_src[p] = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + c : reinterpret_cast<const uint16_t*>(a.x1) + (c - a.c0);
-    p_ld[p] = c < a.c0 ? a.lda0 : a.lda1;
-    p_rel[p] = ((long long)(p_hh[p] - 1) * a.W + (p_hw[p] - 1)) * a.D + (p_hd[p] - 1);
+    const bool ok = idx < HALO_VOX * VPV && c < a.C;
+    const bool s1 = ok && c >= a.c0;
+    const uint16_t* src = s1 ? reinterpret_cast<const uint16_t*>(a.x1) + (c - a.c0) : reinterpret_cast<const uint16_t*>(a.x0) + (ok ? c : 0);
+    const long long rel = ((long long)(hh - 1) * a.W + (hw - 1)) * a.D + (hd - 1);
+    h_ptr[p] = reinterpret_cast<const char*>(src + rel * (s1 ? a.lda1 : a.lda0));
+    h_lds[p] = ((hh * HALO_W + hw) * PD + hd) * CC + ((part ^ (hw & (VPV - 1))) << 3);
+    h_pos[p] = hh | (hw << 8) | (hd << 16) | ((s1 ? 1 : 0) << 24) | ((ok ? 1 : 0) << 25);
   }
   uint4 hreg[NH];
+  bool hin[NH];                            // piece inside the volume (decided at request time, applied when it goes to LDS)
   auto load_halo = [&](const BrickPos& q) {
-    const int h0 = q.bh * 4, w0 = q.bw * 4, d0 = q.bd * 8;
-    const long long vox0 = (((long long)q.b * a.H + h0) * a.W + w0) * a.D + d0;
+    const long long vox0 = origin(q);
+    const long long sb0 = vox0 * a.lda0 * 2, sb1 = vox0 * a.lda1 * 2;       // scalar byte offsets of the brick origin
+    const int h0 = q.bh * 4 - 1, w0 = q.bw * 4 - 1, d0 = q.bd * 8 - 1;
 #pragma unroll
     for (int p = 0; p < NH; ++p) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      const int h = h0 - 1 + p_hh[p], w = w0 - 1 + p_hw[p], d = d0 - 1 + p_hd[p];
-      if (p_ok[p] && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D)
-        v = *reinterpret_cast<const uint4*>(p_src[p] + (vox0 + p_rel[p]) * p_ld[p]);
-      hreg[p] = v;
+      const int h = h0 + (h_pos[p] & 255), w = w0 + ((h_pos[p] >> 8) & 255), d = d0 + ((h_pos[p] >> 16) & 255);
+      const bool in = (h_pos[p] >> 25) != 0 && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D;
+      const char* ad = h_ptr[p] + (((h_pos[p] >> 24) & 1) ? sb1 : sb0);
+      ad = in ? ad : reinterpret_cast<const char*>(a.x0);
+      hreg[p] = *reinterpret_cast<const uint4*>(ad);
+      hin[p] = in;
     }
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](uint16_t* dst) {
 #pragma unroll
-    for (int p = 0; p < NH; ++p) {
-      const int idx = tid + p * 256;
-      if (idx < HALO_VOX * VPV) {
-        const int hv = idx / VPV, part = idx - hv * VPV;
-        const int slot = CC == 32 ? (part ^ ((hv >> 2) & 1)) : part;
-        *reinterpret_cast<uint4*>(&halo[hv * CC + slot * 8]) = hreg[p];
-      }
-    }
+    for (int p = 0; p < NH; ++p)
+      if (tid + p * 256 < HALO_VOX * VPV)
+        *reinterpret_cast<uint4*>(&dst[h_lds[p]]) = hin[p] ? hreg[p] : make_uint4(0u, 0u, 0u, 0u);
   };
 
-  const int hv0 = (wave * HALO_W + (li >> 3)) * HALO_D + (li & 7);      // halo voxel of this lane's row at tap (0,0,0)
+  // ---- output pieces of this thread: the wave's 32 voxels (h = wave) x N/4 pieces of 4 channels, dealt linearly to the lanes
+  const int npr = a.N >> 2;                // pieces per voxel (N <= 32: at most 8)
+  char* o_ptr[4];
+  int o_lds[4], o_pos[4];                  // o_pos: w | d << 8 | destination 1 << 16 | exists << 17
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = lane + 64 * it;
+    const int row = q / npr, pc = q - row * npr;
+    const bool ok = row < 32;
+    const int on = pc * 4, rw = (row >> 3) & 3, rd = row & 7;
+    const bool d1 = on >= a.n0;
+    uint16_t* base = d1 ? reinterpret_cast<uint16_t*>(a.o1) + (on - a.n0) : reinterpret_cast<uint16_t*>(a.o0) + on;
+    const long long rel = ((long long)wave * a.W + rw) * a.D + rd;
+    o_ptr[it] = reinterpret_cast<char*>(base + rel * (d1 ? a.ldo1 : a.ldo0));
+    o_lds[it] = (row & 31) * LDC + on;
+    o_pos[it] = rw | (rd << 8) | ((d1 ? 1 : 0) << 16) | ((ok ? 1 : 0) << 17);
+  }
+
+  const int hv0 = (wave * HALO_W + (li >> 3)) * PD + (li & 7);          // halo row of this lane's voxel at tap (0,0,0)
   float4 bv4[4];                           // bias of this lane's 4 x 4 consecutive output channels
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
@@ -509,24 +553,20 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
       bv4[rr] = make_float4(n + 0 < a.N ? b0 : 0.f, n + 1 < a.N ? b1 : 0.f, n + 2 < a.N ? b2 : 0.f, n + 3 < a.N ? b3 : 0.f);
     }
   }
-  uint16_t* Cs = halo;
+  uint16_t* const Cs = smem + 2 * HELEMS + wave * SELEMS;
 
   int brick = blockIdx.x;
+  if (brick >= bricks) return;             // never taken: the grid is at most `bricks` wide
   BrickPos cur = decompose(brick), nxt = cur;
-  if (brick < bricks) load_halo(cur);
-  // output pieces of this thread: rows (tid >> 3) + 32 it, 4 channels from (tid & 7) * 4
-  const int o_w = tid >> 6, o_d = (tid >> 3) & 7, o_n = (tid & 7) * 4;
-  uint16_t* const o_base = o_n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + o_n : reinterpret_cast<uint16_t*>(a.o1) + (o_n - a.n0);
-  const int o_ld = o_n < a.n0 ? a.ldo0 : a.ldo1;
-  // The output stores of a brick are issued AFTER the next brick's halo registers have gone to LDS (a wait for the halo loads
-  // placed behind freshly issued stores would also wait for their acknowledgement: vmcnt is one in-order counter).  Deferring
-  // them by a whole brick was tried as well: 59 -> 55 us at C = 16 but 78 -> 92 us at C = 32; not kept.
-  if (brick < bricks) store_halo();
+  load_halo(cur);
+  store_halo(smem);
+  advance(nxt);
+  if (brick + (int)gridDim.x < bricks) load_halo(nxt);
   __syncthreads();
+  int buf = 0;
   for (; brick < bricks; brick += gridDim.x) {
-    advance(nxt);
     const bool more = brick + (int)gridDim.x < bricks;
-    if (more) load_halo(nxt);
+    const uint16_t* const halo = smem + buf * HELEMS;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -539,10 +579,11 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
         const int tap = gidx * 3 + q;
         const int ts = a.flip ? 26 - tap : tap;      // data gradient: tap t reads the mirrored halo offset
         const int th = ts / 9, tw = (ts / 3) % 3, td = ts % 3;
-        const int hv = hv0 + (th * HALO_W + tw) * HALO_D + td;
+        const int hv = hv0 + (th * HALO_W + tw) * PD + td;
+        const int sw = ((li >> 3) + tw) & (VPV - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const int ca = CC == 32 ? (((ks * 2 + lh) ^ ((hv >> 2) & 1)) << 3) : (lh << 3);
+          const int ca = ((ks * 2 + lh) ^ sw) << 3;
           av[q][ks] = *reinterpret_cast<const bf16x8*>(&halo[hv * CC + ca]);
         }
       }
@@ -563,32 +604,37 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
       mma_group(gi, avA);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                       // every wave is done with the halo: it becomes the output staging
+    // wave-private staging: the LDS executes one wave's instructions in order, so no barrier between these writes and reads
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       uint2 pk;
       pk.x = pack_bf16x2(acc[4 * rr + 0] + bv4[rr].x, acc[4 * rr + 1] + bv4[rr].y);
       pk.y = pack_bf16x2(acc[4 * rr + 2] + bv4[rr].z, acc[4 * rr + 3] + bv4[rr].w);
-      *reinterpret_cast<uint2*>(&Cs[(wave * 32 + li) * LDC + 8 * rr + 4 * lh]) = pk;
+      *reinterpret_cast<uint2*>(&Cs[li * LDC + 8 * rr + 4 * lh]) = pk;
     }
-    __syncthreads();
     uint2 ov[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const uint2*>(&Cs[((tid >> 3) + 32 * it) * LDC + o_n]);
-    __syncthreads();                       // the staging has been read: the region takes the next halo
-    if (more) store_halo();
+    for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const uint2*>(&Cs[o_lds[it]]);
+    const BrickPos done = cur;
+    cur = nxt;
+    if (more) {
+      store_halo(smem + (buf ^ 1) * HELEMS);
+      advance(nxt);
+      if (brick + 2 * (int)gridDim.x < bricks) load_halo(nxt);
+    }
     {
-      const int h0 = cur.bh * 4, w = cur.bw * 4 + o_w, d = cur.bd * 8 + o_d;
-      const long long vox0 = (((long long)cur.b * a.H + h0) * a.W + w) * a.D + d;
-      const bool ok = o_n < a.N && w < a.W && d < a.D;
+      const long long vox0 = origin(done);
+      const long long so0 = vox0 * a.ldo0 * 2, so1 = vox0 * a.ldo1 * 2;
+      const int w0 = done.bw * 4, d0 = done.bd * 8;
+      const bool hok = done.bh * 4 + wave < a.H;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {     // row ml = (tid >> 3) + 32 it is brick voxel (h = it, w = o_w, d = o_d)
-        if (!ok || h0 + it >= a.H) continue;
-        *reinterpret_cast<uint2*>(o_base + (vox0 + (long long)it * a.W * a.D) * o_ld) = ov[it];
+      for (int it = 0; it < 4; ++it) {
+        const bool ok = hok && (o_pos[it] >> 17) != 0 && w0 + (o_pos[it] & 255) < a.W && d0 + ((o_pos[it] >> 8) & 255) < a.D;
+        if (ok) *reinterpret_cast<uint2*>(o_ptr[it] + (((o_pos[it] >> 16) & 1) ? so1 : so0)) = ov[it];
       }
     }
-    __syncthreads();                       // the next halo is in place
-    cur = nxt;
+    __syncthreads();                       // the next halo is in place; everybody has left the current one
+    buf ^= 1;
   }
 }
 
@@ -695,10 +741,14 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
 // their tiles to part[split][N][27*C] (+ bias partials) and wgrad_reduce_kernel (gemm_bf16.hip) folds them.
 typedef __attribute__((ext_vector_type(4))) short hs16x4;
 typedef __attribute__((address_space(3))) hs16x4 lds_hs16x4;
-#define LDGH 40
+// Row pitch of both LDS images: 32 elements, unpadded.  A ds_read_b64_tr_b16 serves the two 32-lane halves separately; a half
+// reads 4 consecutive rows x 64 bytes, which tile the 64 banks exactly at a 64-byte pitch (the 80-byte pitch of the forward
+// kernel's first image made rows 0 and 3 overlap: a 2-way conflict on every operand read; tools/lds_conflicts.py).
+#define LDGH 32
+#define LDWH 32
 
 __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * LDH];
+  __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * LDWH];
   __shared__ __attribute__((aligned(16))) uint16_t Gs[128 * LDGH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -718,7 +768,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int tap = wave + 4 * i;
-    tapoff[i] = (((tap / 9) * HALO_W + (tap / 3) % 3) * HALO_D + tap % 3) * LDH;
+    tapoff[i] = (((tap / 9) * HALO_W + (tap / 3) % 3) * HALO_D + tap % 3) * LDWH;
   }
   // transposing-read lane geometry (see wgrad_tn_bf16_kernel): lane -> (row trow (+4), columns tcol..tcol+3) of a 16-row slab
   const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -726,7 +776,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
   const int trow = 8 * (gq >> 1) + tq;
   const int gbase = trow * LDGH + tcol;
   // slab ks covers brick rows 16ks..16ks+15 = (h = ks>>1, w = 2(ks&1) + (row>>3), d = row&7)
-  const int hbase = ((gq >> 1) * HALO_D + tq) * LDH + tcol;
+  const int hbase = ((gq >> 1) * HALO_D + tq) * LDWH + tcol;
 
   uint4 hreg[6], greg[2];
   auto load_brick = [&](int brick) {
@@ -775,7 +825,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
       const int idx = tid + p * 256;
       if (idx < HALO_VOX * VPV) {
         const int hv = idx / VPV, part = idx - hv * VPV;
-        *reinterpret_cast<uint4*>(&halo[hv * LDH + part * 8]) = hreg[p];
+        *reinterpret_cast<uint4*>(&halo[hv * LDWH + part * 8]) = hreg[p];
       }
     }
 #pragma unroll
@@ -806,7 +856,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
       const uint16_t* pg = &Gs[ks * 16 * LDGH + gbase];
       ua.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)pg);
       ua.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(pg + 4 * LDGH));
-      const int slab = ((ks >> 1) * HALO_W * HALO_D + (ks & 1) * 2 * HALO_D) * LDH + hbase;
+      const int slab = ((ks >> 1) * HALO_W * HALO_D + (ks & 1) * 2 * HALO_D) * LDWH + hbase;
       if (do_bias) acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ones, acc[6], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
@@ -814,7 +864,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
           union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
           const uint16_t* px = &halo[slab + tapoff[i]];
           ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
-          ub.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(px + 4 * LDH));
+          ub.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(px + 4 * LDWH));
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
         }
       }
@@ -895,10 +945,10 @@ int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
 template <int NC, int TN>
 __global__ void __launch_bounds__(256) conv_class_halo_bf16_kernel(const ClassHaloArgs a) {
   constexpr int BN = 32 * TN, TS = 4;
-  constexpr int HALO_ELEMS = HALO_VOX * LDH, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
+  constexpr int HALO_ELEMS = HALO_VOX * 32, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
   constexpr int SMEM_ELEMS = (HALO_ELEMS + B_ELEMS) > STAGE_ELEMS ? (HALO_ELEMS + B_ELEMS) : STAGE_ELEMS;
   __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
-  uint16_t* halo = smem;                   // [HALO_VOX][LDH]
+  uint16_t* halo = smem;                   // [HALO_VOX][32], 16-byte parts XOR-ed with hw & 3 (see conv3_halo_bf16_kernel)
   uint16_t* Bs = smem + HALO_ELEMS;        // [2][TS][BN][LDH]
   constexpr int LBV = TS * BN * 4 / 256;   // weight vectors per thread and stage
 
@@ -924,7 +974,7 @@ __global__ void __launch_bounds__(256) conv_class_halo_bf16_kernel(const ClassHa
       for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
 
   // wave w owns brick rows 32w..32w+31 = the h-plane w of the brick; row r -> (w, (r >> 3) & 3, r & 7)
-  const int arow = ((wave * HALO_W + (li >> 3)) * HALO_D + (li & 7)) * LDH + lh * 8;
+  const int arow = ((wave * HALO_W + (li >> 3)) * HALO_D + (li & 7)) * 32;
 
   uint4 hreg[6];
   auto load_halo = [&](int chunk) {
@@ -947,7 +997,10 @@ __global__ void __launch_bounds__(256) conv_class_halo_bf16_kernel(const ClassHa
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
       const int idx = tid + p * 256;
-      if (idx < HALO_VOX * 4) *reinterpret_cast<uint4*>(&halo[(idx >> 2) * LDH + (idx & 3) * 8]) = hreg[p];
+      if (idx < HALO_VOX * 4) {
+        const int hv = idx >> 2, hw = (hv / HALO_D) % HALO_W;
+        *reinterpret_cast<uint4*>(&halo[hv * 32 + (((idx & 3) ^ (hw & 3)) << 3)]) = hreg[p];
+      }
     }
   };
   uint4 breg[LBV];
@@ -988,11 +1041,12 @@ __global__ void __launch_bounds__(256) conv_class_halo_bf16_kernel(const ClassHa
         const int e = s * TS + t;
         if (e < a.nent) {
           const ClsEntry en = a.ent[e];
-          const int tapoff = (((en.dh + 1) * HALO_W + (en.dw + 1)) * HALO_D + (en.dd + 1)) * LDH;
+          const int tapoff = (((en.dh + 1) * HALO_W + (en.dw + 1)) * HALO_D + (en.dd + 1)) * 32;
+          const int sw = ((li >> 3) + en.dw + 1) & 3;
           bf16x8 av[2], bv[2][TN];
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            av[ks] = *reinterpret_cast<const bf16x8*>(&halo[arow + tapoff + ks * 16]);
+            av[ks] = *reinterpret_cast<const bf16x8*>(&halo[arow + tapoff + (((ks * 2 + lh) ^ sw) << 3)]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               bv[ks][j] = *reinterpret_cast<const bf16x8*>(&Bs[((buf * TS + t) * BN + j * 32 + li) * LDH + ks * 16 + lh * 8]);
