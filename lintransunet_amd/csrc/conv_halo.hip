@@ -747,7 +747,11 @@ typedef __attribute__((address_space(3))) hs16x4 lds_hs16x4;
 #define LDGH 32
 #define LDWH 32
 
-__global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloArgs a) {
+// PACK (16-channel chunks): a column tile holds TWO taps x 16 channels - lanes with columns 16..31 read the halo at the second
+// tap's offset - so a wave owns 4 tap pairs instead of 7 taps: 32 MFMAs per brick instead of 56, none of them on padding columns.
+template <bool PACK>
+__global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kernel(const WHaloArgs a) {
+  constexpr int NA = PACK ? 4 : 7;         // accumulators per wave; the last one of wave 3 is spare and takes the bias sums
   __shared__ __attribute__((aligned(16))) uint16_t halo[HALO_VOX * LDWH];
   __shared__ __attribute__((aligned(16))) uint16_t Gs[128 * LDGH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -759,15 +763,16 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
   int brick_hi = brick_lo + a.bricks_per_split;
   if (brick_hi > a.bricks) brick_hi = a.bricks;
 
-  f32x16 acc[7];
+  f32x16 acc[NA];
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  int tapoff[7];
+  int tapoff[NA];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = wave + 4 * i;
+  for (int i = 0; i < NA; ++i) {
+    // PACK: pair wave + 4 i = taps 2 (wave + 4 i) (columns 0..15) and + 1 (columns 16..31; tap 27 does not exist: clamped, dropped)
+    const int tap = PACK ? min(2 * (wave + 4 * i) + ((lane >> 4) & 1), 26) : wave + 4 * i;
     tapoff[i] = (((tap / 9) * HALO_W + (tap / 3) % 3) * HALO_D + tap % 3) * LDWH;
   }
   // transposing-read lane geometry (see wgrad_tn_bf16_kernel): lane -> (row trow (+4), columns tcol..tcol+3) of a 16-row slab
@@ -776,7 +781,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
   const int trow = 8 * (gq >> 1) + tq;
   const int gbase = trow * LDGH + tcol;
   // slab ks covers brick rows 16ks..16ks+15 = (h = ks>>1, w = 2(ks&1) + (row>>3), d = row&7)
-  const int hbase = ((gq >> 1) * HALO_D + tq) * LDWH + tcol;
+  const int hbase = ((gq >> 1) * HALO_D + tq) * LDWH + (PACK ? 4 * tp : tcol);
 
   uint4 hreg[6], greg[2];
   auto load_brick = [&](int brick) {
@@ -857,10 +862,10 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
       ua.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)pg);
       ua.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(pg + 4 * LDGH));
       const int slab = ((ks >> 1) * HALO_W * HALO_D + (ks & 1) * 2 * HALO_D) * LDWH + hbase;
-      if (do_bias) acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ones, acc[6], 0, 0, 0);
+      if (do_bias) acc[NA - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ones, acc[NA - 1], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        if (wave + 4 * i < 27) {
+      for (int i = 0; i < NA; ++i) {
+        if (wave + 4 * i < (PACK ? 14 : 27)) {
           union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
           const uint16_t* px = &halo[slab + tapoff[i]];
           ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
@@ -876,15 +881,15 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n_blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (n < a.N) a.bpart[(long long)blockIdx.z * a.npad + n] = acc[6][r];
+      if (n < a.N) a.bpart[(long long)blockIdx.z * a.npad + n] = acc[NA - 1][r];
     }
   }
-  const int c = chunk * a.CC + li;
-  if (li >= a.CC || c >= a.C) return;
+  const int c = PACK ? chunk * 16 + (li & 15) : chunk * a.CC + li;
+  if ((!PACK && li >= a.CC) || c >= a.C) return;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = wave + 4 * i;
-    if (tap >= 27) continue;
+  for (int i = 0; i < NA; ++i) {
+    const int tap = PACK ? 2 * (wave + 4 * i) + (li >> 4) : wave + 4 * i;
+    if (tap >= 27 || wave + 4 * i >= (PACK ? 14 : 27)) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n_blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -893,9 +898,10 @@ __global__ void __launch_bounds__(256) conv3_wgrad_halo_bf16_kernel(const WHaloA
   }
 }
 
-static int whalo_blocks() {
+// workgroups of the halo weight gradient: 2 per CU; the packed 16-channel variant runs 3 per CU (168 registers)
+static int whalo_blocks(int CC) {
   int v = -1;
-  v = ltu_knob_pos("LTU_WHALO_BLOCKS", 512);
+  v = ltu_knob_pos("LTU_WHALO_BLOCKS", CC == 16 && !ltu_knob("LTU_WHALO_NO_PACK", 0) ? 768 : 512);
   return v;
 }
 
@@ -906,7 +912,7 @@ long long conv_wgrad_halo_ws_floats(int N, int K) {
   const int C = K / 27;
   if (!whalo_shape_ok(C, N)) return 0;
   const int CC = C % 32 == 0 ? 32 : 16;
-  long long ns = whalo_blocks() / ((long long)cdiv(C, CC) * cdiv(N, 32));
+  long long ns = whalo_blocks(CC) / ((long long)cdiv(C, CC) * cdiv(N, 32));
   if (ns < 1) ns = 1;
   return ns * N * ((long long)K + 1);
 }
@@ -920,7 +926,7 @@ int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
   const int nchunk = cdiv(a.C, a.CC), ntile = cdiv(a.N, 32);
-  long long ns = whalo_blocks() / ((long long)nchunk * ntile);
+  long long ns = whalo_blocks(a.CC) / ((long long)nchunk * ntile);
   if (ns < 1) ns = 1;
   if (ns > bricks) ns = bricks;
   a.bricks = (int)bricks;
@@ -930,7 +936,10 @@ int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
   a.kpad = 27 * a.C;
   a.bpart = a.part + (long long)nsplit * a.npad * a.kpad;
   *nsplit_out = nsplit;
-  hipLaunchKernelGGL(conv3_wgrad_halo_bf16_kernel, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
+  if (a.CC == 16 && !ltu_knob("LTU_WHALO_NO_PACK", 0))
+    hipLaunchKernelGGL(conv3_wgrad_halo_bf16_kernel<true>, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(conv3_wgrad_halo_bf16_kernel<false>, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
   return ltu_check_launch();
 }
 
