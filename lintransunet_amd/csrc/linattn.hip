@@ -121,7 +121,32 @@ struct RowTile {
       if (idx < TOK * VPR) GVec<T>::to_lds(lds + t * LDSROW + c, r[p]);
     }
   }
+  // the 16-byte pieces as they are (bf16 tiles read back with the transposing ds_read_b64_tr_b16; LDSROW in bf16 elements)
+  __device__ __forceinline__ void store_raw(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int idx = tid + p * NTHR;
+      const int t = idx / VPR, c = (idx % VPR) * W;
+      if (idx < TOK * VPR) *reinterpret_cast<typename GVec<T>::reg*>(lds + t * LDSROW + c) = r[p];
+    }
+  }
 };
+
+// bf16 token-major tile [TOK][PITCH] -> MFMA operand fragment: lane (li, lh) receives rows (tokens) 16 u + 8 lh .. + 7 of column
+// col0 + li.  Two transposing reads (4 rows x 16 columns per 16-lane group each).  A 32-lane half reads 4 consecutive rows x 64
+// bytes per instruction: conflict-free when the row pitch is 64 bytes modulo 256 (tools/lds_conflicts.py), i.e. PITCH = row + 32.
+typedef __attribute__((ext_vector_type(4))) short la_s16x4;
+typedef __attribute__((address_space(3))) la_s16x4 la_lds_s16x4;
+__device__ __forceinline__ int tr_lane_offset(int lane, int pitch) {
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  return (8 * (gq >> 1) + tq) * pitch + 16 * (gq & 1) + 4 * tp;
+}
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p, int pitch) {
+  union { struct { la_s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((la_lds_s16x4*)p);
+  u.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((la_lds_s16x4*)(p + 4 * pitch));
+  return u.v;
+}
 
 // ------------------------------------------------------------------------------------------------ phase A
 // grid (nsplit, B), block 2D.  part layout: [B][nsplit][H][32 (m) + 32 (s) + 1024 (accT[j][i])]
@@ -129,7 +154,10 @@ template <typename T, int D>
 __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict__ qkv, float* __restrict__ part, int N,
                                                            int tokens_per_split) {
   constexpr int H = D / DK, ROW = 2 * D;
-  __shared__ __attribute__((aligned(16))) float smem[TOK * ROW];   // k | v rows of one tile
+  // fp32 storage: one fp32 tile; bf16 storage: two bf16 tiles [TOK][ROW + 32] (double-buffered: one barrier per tile)
+  constexpr int PITCH = ROW + 32;
+  constexpr int SMEM_FLOATS = IsBf16<T>::value ? (2 * TOK * PITCH) / 2 : TOK * ROW;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];   // k | v rows
   const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -142,6 +170,59 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  if constexpr (IsBf16<T>::value) {
+    // The tile stays bf16 in LDS and the operand fragments come from transposing reads: 8 LDS reads per tile and wave instead
+    // of 48 scalar ones, half the LDS bytes, no conversion when the tile is written, and with two buffers a single barrier
+    // per tile.  The arithmetic is the fp32 path's, operation for operation (bf16 -> fp32 is exact).
+    uint16_t* sm = reinterpret_cast<uint16_t*>(smem);
+    RowTile<T, D, ROW, PITCH> tile;
+    const int koff = tr_lane_offset(lane, PITCH) + wave * DK, voff = koff + D;
+    tile.load(base, 3 * D, D, n_begin, n_end, tid);
+    tile.store_raw(sm, tid);
+    __syncthreads();
+    int buf = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
+      const bool more = n0 + TOK < n_end;
+      if (more) tile.load(base, 3 * D, D, n0 + TOK, n_end, tid);
+      const uint16_t* S = sm + buf * (TOK * PITCH);
+      bf16x8 kf[2], vf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        kf[u] = tr_frag(S + 16 * u * PITCH + koff, PITCH);
+        vf[u] = tr_frag(S + 16 * u * PITCH + voff, PITCH);
+      }
+      const int ntok = min(TOK, n_end - n0);
+      float kx[2][8];
+      float mt = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kx[u][e] = (float)kf[u][e];
+          if (16 * u + 8 * lh + e < ntok) mt = fmaxf(mt, kx[u][e]);
+        }
+      mt = xhalf_max(mt);
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+      m_run = m_new;
+      s_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float pe[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pe[e] = 16 * u + 8 * lh + e < ntok ? __expf(kx[u][e] - m_new) : 0.f;
+          s_run += pe[e];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u], pack8(pe), acc, 0, 0, 0);
+      }
+      if (more) tile.store_raw(sm + (buf ^ 1) * (TOK * PITCH), tid);
+      __syncthreads();                          // the next tile is in place; everybody has left the current one
+      buf ^= 1;
+    }
+  } else {
   RowTile<T, D, ROW, ROW> tile;
   tile.load(base, 3 * D, D, n_begin, n_end, tid);
   for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
@@ -193,6 +274,7 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p, acc, 0, 0, 0);
       }
     }
+  }
   }
   const float s_tot = xhalf_sum(s_run);
   float* out = part + (((long long)b * nsplit + sp) * H + wave) * PART_STRIDE;
@@ -487,6 +569,54 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
   auto load_stat = [&](int n0) {
     return (tid < TOK * H * 2 && n0 + tid / (H * 2) < n_end) ? qstat[((long long)b * N + n0) * H * 2 + tid] : 0.f;
   };
+  if constexpr (IsBf16<T>::value) {
+    // bf16 tiles + transposing reads, double-buffered (see linattn_kv_partial): LDS [2][q tile | dO tile][TOK][D + 32], then
+    // [2][TOK * H * 2] row statistics
+    constexpr int PQ = D + 32;
+    uint16_t* sm = reinterpret_cast<uint16_t*>(smem);
+    float* stf = reinterpret_cast<float*>(sm + 4 * TOK * PQ);
+    RowTile<T, D, D, PQ> bq, bg;
+    const int off = tr_lane_offset(lane, PQ) + wave * DK;
+    bq.load(qb, 3 * D, 0, n_begin, n_end, tid);
+    bg.load(gb, D, 0, n_begin, n_end, tid);
+    float stn = load_stat(n_begin);
+    bq.store_raw(sm, tid);
+    bg.store_raw(sm + TOK * PQ, tid);
+    if (tid < TOK * H * 2) stf[tid] = stn;
+    __syncthreads();
+    int buf = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += TOK) {
+      const bool more = n0 + TOK < n_end;
+      if (more) {
+        bq.load(qb, 3 * D, 0, n0 + TOK, n_end, tid);
+        bg.load(gb, D, 0, n0 + TOK, n_end, tid);
+        stn = load_stat(n0 + TOK);
+      }
+      const uint16_t* S = sm + buf * (2 * TOK * PQ);
+      const float* ST = stf + buf * (TOK * H * 2);
+      const int ntok = min(TOK, n_end - n0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 qf = tr_frag(S + 16 * u * PQ + off, PQ), gf = tr_frag(S + (TOK + 16 * u) * PQ + off, PQ);
+        float qe[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int t = 16 * u + 8 * lh + e;
+          const float2 rs = *reinterpret_cast<const float2*>(ST + (t * H + wave) * 2);
+          qe[e] = t < ntok ? __expf((float)qf[e] - rs.x) * rs.y : 0.f;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, pack8(qe), acc, 0, 0, 0);
+      }
+      if (more) {
+        uint16_t* Sn = sm + (buf ^ 1) * (2 * TOK * PQ);
+        bq.store_raw(Sn, tid);
+        bg.store_raw(Sn + TOK * PQ, tid);
+        if (tid < TOK * H * 2) stf[(buf ^ 1) * (TOK * H * 2) + tid] = stn;
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
   tq.load(qb, 3 * D, 0, n_begin, n_end, tid);
   tg.load(gb, D, 0, n_begin, n_end, tid);
   float stn = load_stat(n_begin);
@@ -529,6 +659,7 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, qv, acc, 0, 0, 0);
       }
     }
+  }
   }
   float* out = part + (((long long)b * nsplit + sp) * H + wave) * 1024;
 #pragma unroll
@@ -844,7 +975,9 @@ extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* c
   const int tokb = pick_tokb(B, N, d);
   LTU_DISPATCH_T(dtype, {
     LA_DISPATCH_D(d, {
-      hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float), st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);
+      const size_t lds_p = IsBf16<T>::value ? (size_t)4 * TOK * (D + 32) * 2 + (size_t)2 * TOK * H * 2 * sizeof(float)
+                                            : (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float);
+      hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), lds_p, st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);
       hipLaunchKernelGGL(linattn_dctx_combine, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
       hipLaunchKernelGGL((linattn_bwd_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), lds_b, st, (const T*)qkv, (const T*)dout, ctx, dctx, colstats, tvec, qstat, (T*)dqkv, N, tokb);
     });
