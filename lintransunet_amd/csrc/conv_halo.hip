@@ -666,7 +666,7 @@ static int halo_split(long long bricks, int N, int C, int CC, int* cps) {
   const int ntn = (N > 64 && bricks * cdiv(N, 128) >= 256) ? cdiv(N, 128) : (N > 32 ? cdiv(N, 64) : 1);
   const long long blocks = bricks * ntn;
   const int nchunk = (C + CC - 1) / CC;
-  if (blocks >= 200 || nchunk < 2) return 1;
+  if (blocks >= ltu_knob_pos("LTU_HALO_SPLIT_BELOW", 200) || nchunk < 2) return 1;
   int want = (int)((512 + blocks - 1) / blocks);
   if (want > 8) want = 8;
   if (want > nchunk) want = nchunk;
