@@ -21,10 +21,11 @@
 //                                  sum_n P[n][i] dP[n][i] collapses to this, so no second pass over N).
 //          pass 2   (bwd_apply):   per token: dq, dk, dv (three 32x32 products).
 //
-// All four streaming kernels share one structure: 32-token tiles staged in LDS as fp32, the NEXT tile's
-// 16-byte global loads issued (fully unrolled, compile-time counts) before the current tile is consumed,
-// so HBM latency overlaps the matrix work inside a workgroup.  The products use v_mfma_f32_32x32x2_f32
-// (exact fp32): the core is HBM-bound (AI = 16 FLOP/B) and fp32 MFMA time stays below the streaming time.
+// All four streaming kernels share one structure: 32-token tiles staged in LDS, the NEXT tile's 16-byte global
+// loads issued (fully unrolled, compile-time counts) before the current tile is consumed, so HBM latency
+// overlaps the matrix work inside a workgroup.  fp32 storage: fp32 tiles, v_mfma_f32_32x32x2_f32 (exact);
+// bf16 storage: v_mfma_f32_32x32x16_bf16, and in the two reductions over tokens (kv_partial, dctx_partial) the
+// tiles stay bf16 and the fragments come from transposing LDS reads.  The core is HBM-bound (AI = 16 FLOP/B).
 #include "common.h"
 
 #define DK 32
