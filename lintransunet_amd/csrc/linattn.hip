@@ -31,6 +31,9 @@
 #define DK 32
 #define TOK 32
 #define PART_STRIDE (64 + 1024)
+#ifndef LA_TR_PAD
+#define LA_TR_PAD 32          // row padding (bf16 elements) of the token tiles read with ds_read_b64_tr_b16
+#endif
 
 // value of the other wave half (lane ^ 32) combined with this lane's: sum / max in both lanes (v_permlane32_swap, no LDS crossbar)
 __device__ __forceinline__ float xhalf_sum(float v) { return xhalf_combine<LtuAdd>(v); }
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(2 * D) linattn_kv_partial(const T* __restrict_
                                                            int tokens_per_split) {
   constexpr int H = D / DK, ROW = 2 * D;
   // fp32 storage: one fp32 tile; bf16 storage: two bf16 tiles [TOK][ROW + 32] (double-buffered: one barrier per tile)
-  constexpr int PITCH = ROW + 32;
+  constexpr int PITCH = ROW + LA_TR_PAD;
   constexpr int SMEM_FLOATS = IsBf16<T>::value ? (2 * TOK * PITCH) / 2 : TOK * ROW;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];   // k | v rows
   const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
@@ -573,7 +576,7 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
   if constexpr (IsBf16<T>::value) {
     // bf16 tiles + transposing reads, double-buffered (see linattn_kv_partial): LDS [2][q tile | dO tile][TOK][D + 32], then
     // [2][TOK * H * 2] row statistics
-    constexpr int PQ = D + 32;
+    constexpr int PQ = D + LA_TR_PAD;
     uint16_t* sm = reinterpret_cast<uint16_t*>(smem);
     float* stf = reinterpret_cast<float*>(sm + 4 * TOK * PQ);
     RowTile<T, D, D, PQ> bq, bg;
@@ -976,7 +979,7 @@ extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* c
   const int tokb = pick_tokb(B, N, d);
   LTU_DISPATCH_T(dtype, {
     LA_DISPATCH_D(d, {
-      const size_t lds_p = IsBf16<T>::value ? (size_t)4 * TOK * (D + 32) * 2 + (size_t)2 * TOK * H * 2 * sizeof(float)
+      const size_t lds_p = IsBf16<T>::value ? (size_t)4 * TOK * (D + LA_TR_PAD) * 2 + (size_t)2 * TOK * H * 2 * sizeof(float)
                                             : (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float);
       hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), lds_p, st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);
       hipLaunchKernelGGL(linattn_dctx_combine, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);

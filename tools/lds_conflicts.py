@@ -9,6 +9,11 @@ ds_read_b128 group sit on four w rows, which the images first used ([360][CC] un
 columns 3-4 times over.  Measured effect of the images marked `now` (µs, forward): 32x32x128 C=32->32 30.2 -> 22.3,
 64x64x128 C=16+16->16 96.6 -> 73.2, 64x64x128 C=16->16 47.0 -> 40.3.
 
+The ds_read_b128 part of the model matches the measurements above.  The transposing-read part does NOT predict hardware
+behaviour reliably: an image it rates conflict-free for the 16x16x32 geometry of upconv_wgrad_class_bf16_kernel (64-byte rows,
+32-byte half XOR-ed with row bit 3) ran 2.3x slower than the padded 80-byte rows it rates 2-way, and the row padding of the
+attention tiles (8..64 elements) made no measurable difference.  Treat tr_reads() as a hint only.
+
     python tools/lds_conflicts.py
 """
 HW, HD = 6, 10
