@@ -23,10 +23,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define HALO_VOX (HALO_H * HALO_W * HALO_D)
 #define LDH 40            // LDS row stride in bf16 elements (32 channels + 8 pad = 80 bytes)
 
-template <int WM, int WN, int TM, int TN, int TS>
+template <int WM, int WN, int TM, int TN, int TS, int CC>
 __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) {
   static_assert(WM * TM == 4 && WM * WN == 4, "128-row brick on 4 waves");
   constexpr int BN = WN * TN * 32, NSTAGE = 27 / TS;
+  constexpr int VPV = CC / 8, KS = CC / 16;               // 16-byte parts per voxel / weight row of one chunk; k-steps per tap
+  constexpr int PD = CC == 16 ? 12 : HALO_D, VMASK = VPV - 1;
   constexpr int HALO_ELEMS = HALO_VOX * 32, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
   constexpr int SMEM_ELEMS = (HALO_ELEMS + B_ELEMS) > STAGE_ELEMS ? (HALO_ELEMS + B_ELEMS) : STAGE_ELEMS;
   __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
@@ -35,7 +37,8 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
   // padded [360][40] image this kernel started with was a 3-way conflict)
   uint16_t* halo = smem;
   uint16_t* Bs = smem + HALO_ELEMS;        // [2][TS][BN][LDH]
-  constexpr int LBV = (TS * BN * 4 + 255) / 256;       // weight vectors per thread and stage (4 = max 16-byte parts per row)
+  constexpr int NH = (HALO_VOX * VPV + 255) / 256;       // halo vectors per thread and chunk
+  constexpr int LBV = (TS * BN * VPV + 255) / 256;       // weight vectors per thread and stage
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -48,9 +51,7 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
   const int b = bid / nbh;
   const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
   const int n_blk = blockIdx.y * BN;
-  const int VPV = a.CC / 8;                // 16-byte parts per voxel / weight row of one chunk
-  const int CCe = a.CC, PD = a.CC == 16 ? 12 : HALO_D, vmask = VPV - 1;
-  const int nchunk = (a.C + a.CC - 1) / a.CC;
+  const int nchunk = (a.C + CC - 1) / CC;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -65,54 +66,55 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = (wm * TM + i) * 32 + li;
-    arow[i] = (((r >> 5) * HALO_W + ((r >> 3) & 3)) * PD + (r & 7)) * CCe;
+    arow[i] = (((r >> 5) * HALO_W + ((r >> 3) & 3)) * PD + (r & 7)) * CC;
   }
 
-  uint4 hreg[6];
+  // Global loads are UNCONDITIONAL (clamped address; padding is selected to zero when the registers go to LDS): with a test
+  // around each load hipcc gives it a basic block of its own and drains vmcnt at the next one, so the halo prefetch and the
+  // weight prefetch of a stage were complete round trips one after the other instead of loads in flight behind the MFMAs.
+  uint4 hreg[NH];
+  bool hin[NH];
   auto load_halo = [&](int chunk) {
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < NH; ++p) {
       const int idx = tid + p * 256;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (idx < HALO_VOX * VPV) {
-        const int hv = idx / VPV, part = idx - hv * VPV;
-        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
-        const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
-        const int c = chunk * a.CC + part * 8;
-        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C) {
-          const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
-          const uint16_t* src = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + c
-                                         : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (c - a.c0);
-          v = *reinterpret_cast<const uint4*>(src);
-        }
-      }
-      hreg[p] = v;
+      const int hv = idx / VPV, part = idx - hv * VPV;
+      const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+      const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+      const int c = chunk * CC + part * 8;
+      const bool in = idx < HALO_VOX * VPV && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C;
+      const long long vox = in ? (((long long)b * a.H + h) * a.W + w) * a.D + d : 0;
+      const int cc = in ? c : 0;
+      const uint16_t* src = cc < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + cc
+                                      : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (cc - a.c0);
+      hreg[p] = *reinterpret_cast<const uint4*>(src);
+      hin[p] = in;
     }
   };
   auto store_halo = [&]() {
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < NH; ++p) {
       const int idx = tid + p * 256;
       if (idx < HALO_VOX * VPV) {
         const int hv = idx / VPV, part = idx - hv * VPV;
         const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
-        *reinterpret_cast<uint4*>(&halo[((hh * HALO_W + hw) * PD + hd) * CCe + ((part ^ (hw & vmask)) << 3)]) = hreg[p];
+        *reinterpret_cast<uint4*>(&halo[((hh * HALO_W + hw) * PD + hd) * CC + ((part ^ (hw & VMASK)) << 3)]) =
+            hin[p] ? hreg[p] : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
   uint4 breg[LBV];
+  bool bok[LBV];
   auto load_b = [&](int chunk, int stage) {
 #pragma unroll
     for (int p = 0; p < LBV; ++p) {
       const int idx = tid + p * 256;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (idx < TS * BN * VPV) {
-        const int part = idx % VPV, nl = (idx / VPV) % BN, t = idx / (VPV * BN);
-        const int n = n_blk + nl, tap = stage * TS + t, c = chunk * a.CC + part * 8;
-        if (n < a.N && c < a.C)
-          v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + ((long long)n * 27 + tap) * a.C + c);
-      }
-      breg[p] = v;
+      const int part = idx % VPV, nl = (idx / VPV) % BN, t = idx / (VPV * BN);
+      const int n = n_blk + nl, tap = stage * TS + t, c = chunk * CC + part * 8;
+      const bool ok = idx < TS * BN * VPV && n < a.N && c < a.C;
+      const long long off = ok ? ((long long)n * 27 + tap) * a.C + c : 0;
+      breg[p] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w) + off);
+      bok[p] = ok;
     }
   };
   auto store_b = [&](int buf) {
@@ -121,45 +123,66 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
       const int idx = tid + p * 256;
       if (idx < TS * BN * VPV) {
         const int part = idx % VPV, nl = (idx / VPV) % BN, t = idx / (VPV * BN);
-        *reinterpret_cast<uint4*>(&Bs[((buf * TS + t) * BN + nl) * LDH + part * 8]) = breg[p];
+        *reinterpret_cast<uint4*>(&Bs[((buf * TS + t) * BN + nl) * LDH + part * 8]) = bok[p] ? breg[p] : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
 
-  const int ksteps = a.CC / 16;
+  // fragments of one tap: KS k-steps x (TM halo rows + TN weight rows); the fragments of tap t + 1 are requested before the
+  // MFMAs of tap t are issued (pinned with sched_barrier: the k loop used to be a run-time loop of two MFMAs behind their own
+  // LDS round trip)
+  struct Frags { bf16x8 av[KS][TM], bv[KS][TN]; };
+  auto load_frags = [&](int s, int t, int buf, Frags& f) {
+    const int tap = s * TS + t;
+    int th = tap / 9, tw = (tap / 3) % 3, td = tap % 3;
+    if (a.flip) { th = 2 - th; tw = 2 - tw; td = 2 - td; }
+    const int tapoff = ((th * HALO_W + tw) * PD + td) * CC;
+    const int sw = ((li >> 3) + tw) & VMASK;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ca = ((ks * 2 + lh) ^ sw) << 3;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.av[ks][i] = *reinterpret_cast<const bf16x8*>(&halo[arow[i] + tapoff + ca]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        f.bv[ks][j] = *reinterpret_cast<const bf16x8*>(&Bs[((buf * TS + t) * BN + (wn * TN + j) * 32 + li) * LDH + ks * 16 + lh * 8]);
+    }
+  };
+  auto mma = [&](const Frags& f) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.av[ks][i], f.bv[ks][j], acc[i][j], 0, 0, 0);
+  };
+
   const int c_lo = a.part != nullptr ? (int)blockIdx.z * a.cps : 0;
   const int c_hi = a.part != nullptr ? (c_lo + a.cps < nchunk ? c_lo + a.cps : nchunk) : nchunk;
   load_halo(c_lo);
+  load_b(c_lo, 0);
   for (int chunk = c_lo; chunk < c_hi; ++chunk) {
     __syncthreads();                       // previous chunk fully consumed (halo and both weight buffers)
     store_halo();
-    load_b(chunk, 0);
     store_b(0);
     __syncthreads();
     if (chunk + 1 < c_hi) load_halo(chunk + 1);       // in flight during the 27 taps below
     for (int s = 0; s < NSTAGE; ++s) {
       const int buf = s & 1;
       if (s + 1 < NSTAGE) load_b(chunk, s + 1);
+      else if (chunk + 1 < c_hi) load_b(chunk + 1, 0);  // the next chunk's first stage travels with its halo
+      Frags fa, fb;
+      load_frags(s, 0, buf, fa);
 #pragma unroll
-      for (int t = 0; t < TS; ++t) {
-        const int tap = s * TS + t;
-        int th = tap / 9, tw = (tap / 3) % 3, td = tap % 3;
-        if (a.flip) { th = 2 - th; tw = 2 - tw; td = 2 - td; }
-        const int tapoff = ((th * HALO_W + tw) * PD + td) * CCe;
-        const int sw = ((li >> 3) + tw) & vmask;
-        for (int ks = 0; ks < ksteps; ++ks) {
-          bf16x8 av[TM], bv[TN];
-          const int ca = ((ks * 2 + lh) ^ sw) << 3;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&halo[arow[i] + tapoff + ca]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[((buf * TS + t) * BN + (wn * TN + j) * 32 + li) * LDH + ks * 16 + lh * 8]);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+      for (int t = 0; t < TS; t += 2) {
+        if (t + 1 < TS) load_frags(s, t + 1, buf, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < TS) load_frags(s, t + 2, buf, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < TS) mma(fb);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (s + 1 < NSTAGE) store_b(buf ^ 1);
       __syncthreads();
@@ -713,16 +736,22 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   a.cps = cps;
   if (a.ksplit < 2) a.part = nullptr;
   const unsigned gz = (unsigned)a.ksplit;
+#define HALO_LAUNCH(...)                                                                                 \
+  do {                                                                                                   \
+    if (a.CC == 32) hipLaunchKernelGGL((conv3_halo_bf16_kernel<__VA_ARGS__, 32>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((conv3_halo_bf16_kernel<__VA_ARGS__, 16>), grid, dim3(256), 0, st, a);            \
+  } while (0)
   if (a.N > 64 && bricks * cdiv(a.N, 128) >= 256) {
     dim3 grid((unsigned)bricks, cdiv(a.N, 128), gz);
-    hipLaunchKernelGGL((conv3_halo_bf16_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, a);
+    HALO_LAUNCH(2, 2, 2, 2, 1);
   } else if (a.N > 32) {                    // also wide outputs on small grids: 64-column tiles double the workgroup count
     dim3 grid((unsigned)bricks, cdiv(a.N, 64), gz);
-    hipLaunchKernelGGL((conv3_halo_bf16_kernel<4, 1, 1, 2, 3>), grid, dim3(256), 0, st, a);
+    HALO_LAUNCH(4, 1, 1, 2, 3);
   } else {
     dim3 grid((unsigned)bricks, 1, gz);
-    hipLaunchKernelGGL((conv3_halo_bf16_kernel<4, 1, 1, 1, 3>), grid, dim3(256), 0, st, a);
+    HALO_LAUNCH(4, 1, 1, 1, 3);
   }
+#undef HALO_LAUNCH
   if (a.part != nullptr) {
     const long long M = (long long)a.B * a.H * a.W * a.D;
     long long blocks = (M * (a.N / 4) + 255) / 256;
