@@ -62,7 +62,7 @@ __device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ gra
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum[2] = {0.f, 0.f};
+  float bsum = 0.f;
 
   // LDS-DMA sources: wave w fills pieces w and w + 4 (4 rows x 256 B each) of G and of X; lane -> (row = lane >> 4, slot = lane & 15)
   const int prow = 4 * wave + (lane >> 4);
@@ -90,7 +90,10 @@ __device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ gra
     acol[i] = ((((wm * 2 + i) * 4 + (tcol >> 3)) ^ (tq << 2)) << 3) + (tcol & 7);
     bcol[i] = ((((wn * 2 + i) * 4 + (tcol >> 3)) ^ (tq << 2)) << 3) + (tcol & 7);
   }
-  const bool do_bias = k_blk == 0 && wn == 0;
+  // bias gradient = column sums of G.  Every wave sums ONE of its two G fragments (wave (wm, wn) takes tile wm * 2 + wn), with no
+  // test in the loop: summed by the wn == 0 waves only, inside `if (do_bias)`, the k loop was cut into basic blocks at every step
+  // (the wave index comes from threadIdx: a divergent branch for the compiler) and the two busy waves carried 32 extra VALU
+  // instructions per step - 10 % of the grouped weight-gradient kernel.
 
   for (int u = 0; u < R - 1 && u < niter; ++u) issue(u);
   for (int it = 0; it < niter; ++it) {
@@ -121,22 +124,18 @@ __device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ gra
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {          // the A fragment holds 8 rows of column n = lane & 31: column sums for free
+      {                       // the A fragment holds 8 rows of column n = lane & 31: column sums from registers
+        const bf16x8 ab = wn ? a[1] : a[0];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[i] += (float)a[i][e];
+        for (int e = 0; e < 8; ++e) bsum += (float)ab[e];
       }
     }
   }
 
   const int li = lane & 31, lh = lane >> 5;
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float t = xhalf_combine<LtuAdd>(bsum[i]);
-      if (lh == 0) bz[n_blk + (wm * 2 + i) * 32 + li] = t;
-    }
+  if (k_blk == 0) {
+    const float t = xhalf_combine<LtuAdd>(bsum);
+    if (lh == 0) bz[n_blk + (wm * 2 + wn) * 32 + li] = t;
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
