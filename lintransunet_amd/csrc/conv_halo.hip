@@ -874,13 +874,7 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
   // as the wave's 56 MFMAs, with the other three waves waiting at the barrier.
   // Wave 3 owns only 6 taps (3, 7, .., 23): its seventh accumulator is free and takes the sums - no extra registers (a separate
   // accumulator in wave 0 cost the fourth workgroup per CU: 60 -> 84 us).
-  // wave-uniform conditions from an SGPR copy of the wave index: taken from threadIdx they are divergent branches for the compiler,
-  // and `if (wave + 4 * i < 27)` around every MFMA cut the slab loop into ~100 basic blocks with exec masking and a wait each.
-  // Only the LAST accumulator of a wave can be without a tap (wave + 4 * (NA - 1) >= the tap / pair count).
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  constexpr int NOWN = PACK ? 14 : 27;     // taps (tap pairs) dealt to the waves
-  const bool last_ok = wave_u + 4 * (NA - 1) < NOWN;
-  const bool do_bias = chunk == 0 && wave_u == 3;
+  const bool do_bias = chunk == 0 && wave == 3;
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -900,7 +894,7 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
       if (do_bias) acc[NA - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ones, acc[NA - 1], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        if (i < NA - 1 || last_ok) {
+        if (wave + 4 * i < (PACK ? 14 : 27)) {
           union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
           const uint16_t* px = &halo[slab + tapoff[i]];
           ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
@@ -924,7 +918,7 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int tap = PACK ? 2 * (wave + 4 * i) + (li >> 4) : wave + 4 * i;
-    if (tap >= 27 || (i == NA - 1 && !last_ok)) continue;
+    if (tap >= 27 || wave + 4 * i >= (PACK ? 14 : 27)) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n_blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
