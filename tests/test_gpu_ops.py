@@ -117,6 +117,8 @@ def test_linear_bf16(ops, M, K, N, nw):
     (1, 40, 32, 8, 5, 17, (2, 2, 1), 0, False, None),    # 4 classes
     (2, 128, 128, 8, 8, 8, (2, 2, 2), 0, False, None),   # strided forward on a tiny grid with K = 3456: K-split implicit GEMM + fold
     (1, 256, 128, 4, 4, 8, (1, 1, 1), 0, False, None),   # stride-1 halo conv on one brick row: channel-split + fold
+    (1, 16, 16, 36, 38, 60, (1, 1, 1), 0, False, None),  # persistent few-channel kernels: 720 ragged bricks on 512 workgroups (the
+    (1, 32, 32, 36, 38, 60, (1, 1, 1), 0, False, None),  # double-buffered brick loop runs more than once), 16 and 32 channels
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
