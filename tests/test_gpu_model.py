@@ -149,6 +149,27 @@ def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, batch, wseed):
 # drift up to the first moved box, 3e-1 right after it).  The element-wise gate therefore applies when the boxes agree.
 BF16_DICE_TOL = 3e-4
 BF16_DICE_TOL_MOVED_BOX = 1e-3
+# Gradient norms of the bf16 step against the reference's 600 fp32 norms (same fixture the fp32 path is held to at 1e-2), when the
+# boxes agree.  This random-weight network amplifies bf16 rounding of the activations (a whole-gradient rel-L2 of ~0.15 between
+# bf16 and fp32 storage, test_layer_tail_matches_op_by_op), so single tensors move by a few per cent; gates are the measured
+# distribution with margin: median, 95th percentile and maximum of |norm - ref| / max(ref, 1e-3) over the ~590 tensors.
+BF16_GRADNORM_TOL = dict(median=2e-2, p95=8e-2, max=0.35)
+
+
+def bf16_gradnorm_check(model, G, tag):
+    norms = dict(zip(G['grad_keys'], G['grad_norms']))
+    sd = dict(model.named_parameters())
+    rel = []
+    for k, n in norms.items():
+        if exact_zero_grad(k):
+            continue
+        got = sd[k].grad.double().norm().item()
+        assert np.isfinite(got), k
+        rel.append((abs(got - n) / max(n, 1e-3), k))
+    rel.sort()
+    med, p95, mx = rel[len(rel) // 2][0], rel[int(len(rel) * 0.95)][0], rel[-1][0]
+    print(f'[bf16 {tag}] gradient norms vs reference over {len(rel)} tensors: median {med:.2e}, p95 {p95:.2e}, max {mx:.2e} ({rel[-1][1]})')
+    assert med <= BF16_GRADNORM_TOL['median'] and p95 <= BF16_GRADNORM_TOL['p95'] and mx <= BF16_GRADNORM_TOL['max'], (med, p95, mx, rel[-3:])
 
 
 @pytest.mark.parametrize('tag,cfgkw,size,batch,wseed', [c for c in SAMPLED if c[0] in ('full128', 'full96', 'full32', 'win512')])
@@ -172,6 +193,7 @@ def test_model_sampled_bf16(golden_dir, tag, cfgkw, size, batch, wseed):
     assert abs(total - float(G['total'])) <= 1e-2 * abs(float(G['total']))
     if moved == 0:
         assert rel_l2 <= 3e-2
+        bf16_gradnorm_check(model, G, tag)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
@@ -540,6 +562,11 @@ def test_model_multiclass_128(golden_dir, dtype):
         assert abs(d1 - float(G['dice1'])) <= BF16_DICE_TOL_MOVED_BOX and abs(d2 - float(G['dice2'])) <= BF16_DICE_TOL_MOVED_BOX
         assert abs(total - float(G['total'])) <= 1e-2 * abs(float(G['total']))
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        ref = torch.from_numpy(G['out_sample']).double()
+        rel_l2 = ((flat.double() - ref).norm() / ref.norm()).item()
+        print(f'[bf16 multi128] sampled rel-L2 {rel_l2:.2e}')
+        if rel_l2 <= 3e-2:          # the fixture holds no boxes: bf16-level agreement of the output means none has moved
+            bf16_gradnorm_check(model, G, 'multi128')
 
 
 def test_model_multiclass_bf16(golden_dir):
