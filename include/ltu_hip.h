@@ -34,7 +34,8 @@ extern "C" {
 typedef void* ltu_stream_t; /* hipStream_t */
 
 enum { LTU_F32 = 0, LTU_BF16 = 1 };
-enum { LTU_OK = 0, LTU_E_DTYPE = -1, LTU_E_SHAPE = -2, LTU_E_ALIGN = -3, LTU_E_ARG = -4 };
+enum { LTU_OK = 0, LTU_E_DTYPE = -1, LTU_E_SHAPE = -2, LTU_E_ALIGN = -3, LTU_E_ARG = -4,
+       LTU_E_COMM = -100 /* RCCL not loaded / not loadable; LTU_E_COMM - r = RCCL returned ncclResult_t r > 0 */ };
 enum { LTU_ACT_NONE = 0, LTU_ACT_LRELU = 1 };
 
 int ltu_version(void);
@@ -372,6 +373,22 @@ int ltu_keep_largest_component(float* pred, int* labels, int* counts, unsigned l
  * decoupled weight decay, bias correction with `step` (>= 1), gradient multiplied by grad_scale on load. */
 int ltu_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, long long step, float grad_scale, ltu_stream_t s);
+
+/* ---- data-parallel gradient exchange (replaces the reduce half of nn.DataParallel, train3D.py:119) -------------------------------
+ * Direct RCCL calls: one communicator per process (= per GPU), created from a 128-byte unique id that rank 0 generates and the
+ * host side distributes (lintransunet_amd/comm.py: over the gloo control group).  librccl is not linked: ltu_comm_load dlopens
+ * the copy the process already holds (PyTorch's torch/lib/librccl.so, bound to the HIP runtime that owns the caller's streams).
+ * The all-reduce only ENQUEUES RCCL's kernel on `s`: no thread, no event polling, no synchronisation - inside a stream capture it
+ * becomes a graph node (train.GraphedStep captures every bucket's all-reduce as a side branch of the step graph).
+ * `comm` is an opaque handle owned by the caller; the only process-global state are the resolved function pointers.
+ *   ltu_comm_allreduce_avg: buf[i] <- mean over ranks of buf[i] (fp32, in place, ncclAvg)
+ *   ltu_comm_broadcast:     nbytes of buf from rank `root` to all (initial parameter sync) */
+int ltu_comm_load(const char* librccl_path);
+int ltu_comm_unique_id(void* id128);
+int ltu_comm_init(void** comm, const void* id128, int world, int rank);
+int ltu_comm_allreduce_avg(void* comm, float* buf, long long n, ltu_stream_t s);
+int ltu_comm_broadcast(void* comm, void* buf, long long nbytes, int root, ltu_stream_t s);
+int ltu_comm_destroy(void* comm);
 
 /* ---- data side (dataset/CT_pancreas_ids.py:143-173): raw scan f32 [D][H][W] -> img f32 [H][W][D] = (clamp(raw, lo, hi) - mean) / std,
  * raw label u8 [D][H][W] -> lab u8 [H][W][D] (either pair may be NULL); reference constants lo -91, hi 250, mean 86.9, std 39.4 */

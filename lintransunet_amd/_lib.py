@@ -103,6 +103,12 @@ SIGNATURES = {
     'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P, P],
     'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
     'ltu_label_maxpool': [P, P, I, I, I, I, I, P],
+    'ltu_comm_load': [ctypes.c_char_p],
+    'ltu_comm_unique_id': [P],
+    'ltu_comm_init': [P, P, I, I],
+    'ltu_comm_allreduce_avg': [P, P, L, P],
+    'ltu_comm_broadcast': [P, P, L, I, P],
+    'ltu_comm_destroy': [P],
 }
 
 _lib = None
@@ -138,7 +144,9 @@ _ERR = {-1: 'LTU_E_DTYPE', -2: 'LTU_E_SHAPE', -3: 'LTU_E_ALIGN', -4: 'LTU_E_ARG'
 def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
-        raise LtuError(f'{name} failed: {_ERR.get(rc, "hipError_t " + str(rc))}')
+        what = _ERR.get(rc) or ('LTU_E_COMM (RCCL not loaded)' if rc == -100 else f'ncclResult_t {-100 - rc}' if rc < -100
+                                else f'hipError_t {rc}')
+        raise LtuError(f'{name} failed: {what}')
 
 
 def config_set(name, value=None):

@@ -6,7 +6,7 @@ Both sides start from the same bf16-representable inputs and weights (the oracle
 the rounding of the stored intermediates (every tensor the chain writes is bf16) and any wrong term.  Gates, per tensor:
   activations / data gradients: max |diff| / max |ref| <= 1.5e-2, relative L2 <= 6e-3 (bf16 has 8 significant bits: one rounding is
   2e-3 rms, the chain stacks a handful of them; observed 2.9e-3 / 3.6e-3);
-  weight and bias gradients (sums over all tokens: rounding noise averages out): relative L2 <= 5e-3, the q / k projections
+  weight and bias gradients (sums over all tokens: rounding noise averages out): relative L2 <= 8e-3, the q / k projections
   (near-cancelling sums) <= 1.5e-2;
   the key-projection bias, whose gradient is mathematically zero (softmax over tokens is shift invariant): absolute floor.
 The dropout test rebuilds the three masks of a layer from the stand-alone kernels (same counter hash, same element index), checks
@@ -102,9 +102,9 @@ QK = ('self_attn.linears.0.', 'self_attn.linears.1.')      # q / k projections: 
                                                             # absolute noise is a larger relative error
 
 
-def _compare(tag, y, dx, grads, yr, dxr, gr, act_max=1.5e-2, act_l2=6e-3, w_l2=5e-3, qk_l2=1.5e-2, w_max=2.5e-2):
+def _compare(tag, y, dx, grads, yr, dxr, gr, act_max=1.5e-2, act_l2=6e-3, w_l2=8e-3, qk_l2=1.5e-2, w_max=2.5e-2):
     """observed (MI355X): y rel-L2 2.9e-3 (3.1e-3 with dropout), dx 3.6e-3 (3.9e-3), max errors <= 7e-3; parameter gradients: q / k
-    projections <= 7.7e-3 rel-L2, all others lower (printed)"""
+    projections <= 7.7e-3 rel-L2, all others <= 4.8e-3"""
     ym, yl = _errs(y, yr)
     dm, dl = _errs(dx, dxr)
     worst = {'qk': (0.0, None), 'other': (0.0, None), 'max': (0.0, None)}
