@@ -6,8 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU, weak scaling (2 patches per GPU, BASELINE.json config 3): every rank draws its own
-synthetic patches, gradients are all-reduced (mean) over RCCL in buckets overlapped with backward (captured as
-side branches of the step's HIP graph).  A "step" is one inner training step of
+synthetic patches, gradients are all-reduced (mean) over RCCL in buckets overlapped with backward (direct RCCL calls behind the
+C-ABI, captured as side branches of the step's HIP graph; the host control plane - rendezvous, barriers, max over ranks - is gloo).  A "step" is one inner training step of
 utils/utils_3D_embed_full.py:55-86 (dropout 0.3 as in training, no optimizer step, inputs resident in HBM).
 Rank 0 prints ONE JSON line.
 
@@ -235,19 +235,24 @@ def main():
         return dry_run(args, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
-
     from lintransunet_amd.model import get_model_dict
     from lintransunet_amd import train, ops
+    from lintransunet_amd import comm as C
+
+    comm = None
+    if world > 1:
+        # host control plane (unique id, barriers, max over ranks): gloo on 127.0.0.1; gradient exchange: direct RCCL calls behind
+        # the C-ABI (lintransunet_amd/comm.py) - no ProcessGroupNCCL, hence no watchdog thread next to the graph captures
+        dist.init_process_group('gloo')
+        comm = C.RcclComm(dev, control=C.GlooComm())
 
     torch.manual_seed(1234)          # same initial weights on every rank (then broadcast for good measure)
     act = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = get_model_dict('MaskTransUnet')([16, 32, 64, 128, 256], [100, 65, 40, 25, 10], [False, True, True, True, True],
                                             1, args.classes, dropout=0.3, act_dtype=act).to(dev).train()
-    train.broadcast_parameters(model)
+    train.broadcast_parameters(model, comm)
     torch.manual_seed(1234 + rank)   # dropout streams differ per rank
-    reducer = train.GradReducer(model, bucket_mb=16.0, unused=train.UNUSED_PARAMETERS)
+    reducer = train.GradReducer(model, bucket_mb=16.0, unused=train.UNUSED_PARAMETERS, comm=comm)
     size = (args.size,) * 3
     weights = train.get_dynamic_weight(1)[0]
     batches = [synthetic_batch(args.batch, size, 100 + 10 * rank + i, dev, args.classes) for i in range(2)]
@@ -353,21 +358,20 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        comm.barrier()
     dt = time.perf_counter() - t0
     timer.on = False
-    tmax = torch.tensor([dt], device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+        dt = comm.max_float(dt)
 
     if rank == 0:
         patches = args.batch * world * args.steps
@@ -404,6 +408,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(size)
         print(json.dumps(out))
     if world > 1:
+        comm.close()
         dist.destroy_process_group()
 
 

@@ -1,11 +1,12 @@
-// Row-block chain kernels for the post-attention half of a transformer layer (model/trans_block.py:203-211) on the SMALL token
-// levels (a few thousand to ~20 000 tokens), bf16 storage.
+// Row-block chain kernels for the post-attention half of a transformer layer (model/trans_block.py:203-211), bf16 storage, at every
+// token level of the step (1 024 ... 114 816 tokens; d = 128 / 256).
 //
 //   z1 = x + drop(a Wo^T + bo);  t1 = LN1(z1);  u = t1 W1^T + b1;  h = drop(gelu(u));  z2 = t1 + drop(h W2^T + b2);  y = LN2(z2)
 //
-// Launched op by op (projection, LayerNorm, projection + GELU, projection, LayerNorm) every one of these is a 5-20 us kernel whose
-// time is pipeline fill and drain, not bytes: the three small levels cost 40 % of the step for 20 % of the tokens.  Every op of
-// the chain is per token, so a workgroup can carry a block of 32 token rows through all of it (67 KB of LDS: two workgroups per CU):
+// Launched op by op (projection, LayerNorm, projection + GELU, projection, LayerNorm) every one of these is a 5-20 us kernel at
+// the small levels - pipeline fill and drain, not bytes - and a full read + write of the activations at the large one.  Every op of
+// the chain is per token, so a workgroup can carry a block of 32 token rows through all of it (38 KB of LDS at d = 128, 75 KB at
+// d = 256):
 //   * the activations of the block stay in LDS between the stages (bf16, padded rows);
 //   * the weights are read straight from L2 into MFMA operand registers: they are prepared once per step in fragment order
 //     (weight-prep kind 8 / 9: a wave's 16 x 32 operand is one coalesced 1 KiB load), are shared by all workgroups and never

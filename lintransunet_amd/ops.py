@@ -946,8 +946,7 @@ def gelu_dropout(u, p=0.0, seed=0):
 # against 27 / 51 / 72 / 130 us for the five launches at 1 024 / 8 640 / 21 504 / 114 816 tokens); LTU_TAIL_MAX_TOKENS caps it
 USE_LAYER_TAIL = _os.environ.get('LTU_NO_LAYER_TAIL', '') == ''
 USE_LAYER_TAIL_BWD = _os.environ.get('LTU_NO_LAYER_TAIL_BWD', '') == ''
-TAIL_MAX_TOKENS = int(_os.environ.get('LTU_TAIL_MAX_TOKENS', '1000000000'))      # the row-block chain kernel serves the small token levels (measured; the 115 k-token level keeps the
-                             # streaming ring kernels, which are bandwidth- rather than latency-bound)
+TAIL_MAX_TOKENS = int(_os.environ.get('LTU_TAIL_MAX_TOKENS', '1000000000'))      # no cap by default: the chain kernels serve every level
 
 
 def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):

@@ -25,6 +25,7 @@ class FusedAdamW:
 
     def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.reducer = reducer
+        self.generation = reducer.generation          # the flat layout this optimizer's parameter / moment buffers mirror
         self.param_groups = [dict(lr=float(lr), betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay))]
         self.step_count = 0
         self.flat_p, self.m, self.v = [], [], []
@@ -46,6 +47,9 @@ class FusedAdamW:
         self.reducer.zero_grad()
 
     def step(self, grad_scale=1.0):
+        if self.reducer.generation != self.generation:
+            raise RuntimeError('the reducer re-assigned its gradient buckets (rebucket) after this optimizer was built: its flat '
+                               'parameter / moment buffers no longer match; call rebucket() before constructing the optimizer')
         g = self.param_groups[0]
         self.step_count += 1
         for p, gr, m, v in zip(self.flat_p, self.reducer.flat, self.m, self.v):

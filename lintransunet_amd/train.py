@@ -3,16 +3,17 @@
 One process per GPU.  The batch is sharded over ranks; every normalisation, ROI box, softmax-over-tokens
 and loss term of this network is per-sample, so averaging the per-rank gradients reproduces the
 full-batch gradient of the reference's nn.DataParallel step.  The only exchange is
-one bucketed all-reduce of the gradients over RCCL/xGMI (gloo on CPU tests), launched bucket by bucket
-from autograd hooks so that it overlaps the rest of backward.
+one bucketed all-reduce of the gradients over RCCL/xGMI, launched bucket by bucket from autograd hooks so that it
+overlaps the rest of backward.  The exchange goes through a communicator object (lintransunet_amd/comm.py): `RcclComm` = direct RCCL
+calls behind the C-ABI on the GPU, `GlooComm` = the same interface on CPU tensors (host control plane and CPU tests).
 """
 import math
 import os
-import time
 
 import torch
 import torch.distributed as dist
 
+from . import comm as _comm
 from . import ops
 from .losses import LevelCriterion
 
@@ -111,14 +112,20 @@ class GradReducer:
     post-accumulate hook counts arrivals and launches `all_reduce(async_op=True)` when a bucket is full, so the
     collective of one bucket runs while backward produces the next.  Inside a captured step (GraphedStep) the same
     calls are captured: each bucket's RCCL kernel becomes a side branch of the HIP graph, forked where the bucket's
-    last gradient is produced and joined at the end of the step.
+    last gradient is produced and joined at the end of the step (comm.RcclComm: the RCCL kernel is enqueued on the
+    communicator's stream by a plain C call; no process-group thread takes part).
     Parameters that never receive a gradient (the 14 unused pos_encoders tensors) are left out.
     With gradient accumulation only the last micro-step reduces (`prepare(reduce=False)` otherwise).
     """
 
-    def __init__(self, model, bucket_mb=16.0, unused=None, group=None, fused=True):
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    def __init__(self, model, bucket_mb=16.0, unused=None, comm=None, fused=True):
+        """comm: a communicator of lintransunet_amd.comm (RcclComm on the GPU, GlooComm on CPU tensors); None = LocalComm, or -
+        when torch.distributed is initialised with a gloo group - a GlooComm over the default group"""
+        if comm is None:
+            comm = (_comm.GlooComm() if (dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'gloo')
+                    else _comm.LocalComm())
+        self.comm = comm
+        self.world = comm.world
         unused = set(unused or [])
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and n not in unused]
         named.reverse()
@@ -126,14 +133,13 @@ class GradReducer:
         self.fused = fused
         self.ready_order = []           # parameters in the order their gradients became ready in the last backward
         self._seen = set()
+        self.generation = 0             # bumped whenever the flat buffers are re-assigned (optim.FusedAdamW checks it)
         for n, p in named:
             p.register_post_accumulate_grad_hook(self._hook)     # gradients that arrive through autograd
         self._assign([p for n, p in named])
         self.active = False
         self.reduce_now = True
         self.ctx = None
-        # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) sums and the buckets are divided afterwards
-        self.avg = self.world > 1 and dist.get_backend(group) == 'nccl'
 
     def _assign(self, params):
         """bucket `params` in the given order: flat fp32 buffers of ~cap elements, every .grad a view into its bucket"""
@@ -160,6 +166,7 @@ class GradReducer:
                     p._ltu_hook = self._hook
             self.flat.append(flat)
         self.pending = [0] * len(self.buckets)
+        self.generation += 1
 
     def rebucket(self):
         """Re-assign the buckets in the order in which the gradients became ready during the last backward (as DDP does after its
@@ -167,7 +174,8 @@ class GradReducer:
         stages and the bottleneck transformer are registered early in the decoder but finish late in backward, so buckets in
         registration order all complete near the end of the step and nothing overlaps.  Call between steps, after one backward
         with hooks armed (`prepare`), before building optimizers / step graphs on top of the buffers (a GraphedStep notices moved
-        gradient storage and captures again).  Every rank records the same order (it depends on the autograd graph only)."""
+        gradient storage and captures again; an optimizer built on the old buffers refuses to step: `generation` changed).  Every
+        rank records the same order (it depends on the autograd graph only)."""
         if not self.ready_order:
             raise RuntimeError('rebucket() needs one backward pass with armed hooks first')
         seen = set(self.ready_order)
@@ -175,12 +183,7 @@ class GradReducer:
         self._assign(list(self.ready_order) + rest)
 
     def _all_reduce(self, flat):
-        return dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-    def _finish_bucket(self, flat, handle):
-        handle.wait()
-        if not self.avg:
-            flat.div_(self.world)
+        return self.comm.allreduce_avg(flat)
 
     def zero_grad(self):
         for f in self.flat:
@@ -211,8 +214,8 @@ class GradReducer:
         """all-reduce every bucket now (after a graph replay that did not capture the collectives)"""
         if self.world > 1:
             hs = [self._all_reduce(f) for f in self.flat]
-            for f, h in zip(self.flat, hs):
-                self._finish_bucket(f, h)
+            for h in hs:
+                h.wait()
 
     def finish(self):
         (self.ctx or ops.current()).flush_deferred()      # safety net for callers that ran backward without train_step
@@ -223,7 +226,7 @@ class GradReducer:
                 if bi not in launched:
                     self.handles.append((bi, self._all_reduce(self.flat[bi])))
             for bi, h in self.handles:
-                self._finish_bucket(self.flat[bi], h)
+                h.wait()
         self.handles = []
 
 
@@ -234,8 +237,8 @@ class GraphedStep:
 
     * The batch lives in static device buffers (`copy_` new data in); dropout masks stay fresh across replays because the
       kernels mix a device-resident step counter, advanced inside the graph, into their seeds.
-    * all-reduce: `overlap='graph'` (default) captures the bucket collectives inside the graph - RCCL kernels on the process
-      group's stream become side branches forked where a bucket's last gradient is produced and joined at the end of the step,
+    * all-reduce: `overlap='graph'` (default) captures the bucket collectives inside the graph - RCCL kernels on the
+      communicator's stream become side branches forked where a bucket's last gradient is produced and joined at the end of the step,
       i.e. overlapped with the rest of backward exactly as in the eager hook path.  `overlap='after'` issues them after the
       replay (fully exposed; kept as the fallback if a runtime refuses to capture collectives).  LTU_GRAPH_ALLREDUCE overrides.
     * accumulation (utils/utils_3D_embed_full.py:85-91, `step_times` micro-steps per optimizer step): `step(x, y, micro=j)`
@@ -303,19 +306,12 @@ class GraphedStep:
                 for _ in range(self.warmup):
                     self._body(True, True)
             torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        if dist.is_initialized():
-            if dist.get_world_size() > 1:
-                dist.barrier()             # no collective in flight while the stream is capturing
-                torch.cuda.synchronize(dev)
-            # The process group's watchdog thread polls the completion events of every eagerly issued collective (warm-up, the
-            # barrier above) until it has retired them, in a 100 ms loop.  Once the captured collectives have pulled the group's
-            # RCCL stream into the capture, such a poll fails with hipErrorCapturedEvent and the watchdog aborts the process
-            # (observed with ROCm 7.0 / torch 2.10).  All eager collectives are complete here, so give the watchdog a few loop
-            # periods to empty its list; nothing is enqueued during the capture itself (captured works are never handed to it).
-            time.sleep(0.5)
+        torch.cuda.synchronize(dev)          # every eager collective of the warm-up has completed on the communicator's stream
+        # Nothing else needs to happen before a capture that contains collectives: the communicator (comm.RcclComm) enqueues
+        # RCCL's kernels from this thread through a plain C call, so there is no watchdog or progress thread that could touch an
+        # event of the capturing streams (round 2's ProcessGroupNCCL path needed a sleep here and could still abort).
         graph = torch.cuda.CUDAGraph()
-        # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
+        # thread-local capture mode: other threads of the process (data loading, logging) may use the HIP runtime meanwhile
         kw = {} if (self.pool is None or os.environ.get('LTU_GRAPH_SHARE_POOL', '1') == '0') else {'pool': self.pool}
         with torch.cuda.graph(graph, capture_error_mode='thread_local', **kw):
             totals, named = self._body(zero, reduce)
@@ -328,6 +324,10 @@ class GraphedStep:
     def __call__(self, images=None, labels=None, micro=0):
         """replay micro-step `micro` (0 .. step_times-1) of an optimizer step on a new batch"""
         if self._signature() != self.sig:          # parameter / gradient storage moved since capture: the graph reads stale memory
+            if micro != 0:
+                # a re-capture runs warm-up steps that zero the buckets: the micro-steps already accumulated would be lost
+                raise RuntimeError('parameter / gradient storage moved in the middle of an accumulation cycle (micro > 0): '
+                                   're-home parameters (optimizers, rebucket) only between optimizer steps')
             self.graphs = {}
             self.pool = None
             self.ctx.arena.frozen = False
@@ -349,8 +349,8 @@ UNUSED_PARAMETERS = tuple(f'decode.bridge_list.4.transformer.pos_encoders.{n}.pr
                           for n in range(1, 8) for k in ('weight', 'bias'))
 
 
-def broadcast_parameters(model, src=0, group=None):
+def broadcast_parameters(model, comm=None, src=0):
     """one-time parameter sync from rank `src` (replaces DataParallel's per-step replicate)"""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if comm is not None and comm.world > 1:
         for p in model.parameters():
-            dist.broadcast(p.data, src, group=group)
+            comm.broadcast(p.data, src)

@@ -79,14 +79,18 @@ def _free_port():
 def _reducer_worker(rank, world, port, out):
     import torch.distributed as dist
     from lintransunet_amd.train import GradReducer, broadcast_parameters
+    from lintransunet_amd.comm import GlooComm
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    comm = GlooComm()                            # the communicator interface of the RCCL path, on CPU tensors (comm.py)
+    assert (comm.world, comm.rank) == (world, rank)
+    assert comm.max_float(float(rank)) == world - 1
     torch.manual_seed(rank)                      # different init per rank: broadcast must fix it
     net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
                               torch.nn.Linear(16, 1))
     unused = torch.nn.Linear(3, 3)               # registered, never used in forward (like pos_encoders.1..7)
     net.add_module('unused', unused)
-    broadcast_parameters(net)
-    red = GradReducer(net, bucket_mb=0.0005, unused=['unused.weight', 'unused.bias'])
+    broadcast_parameters(net, comm)
+    red = GradReducer(net, bucket_mb=0.0005, unused=['unused.weight', 'unused.bias'], comm=comm)
     assert len(red.buckets) >= 2
     g = torch.Generator().manual_seed(123)
     x = torch.randn(8, 6, generator=g)
