@@ -136,6 +136,11 @@ def parse_args(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured HIP graph')
     ap.add_argument('--allreduce', default=None, choices=['graph', 'after'],
                     help="gradient all-reduce of the graph-replayed step: captured inside the graph (overlapped, default) or after the replay")
+    ap.add_argument('--rehearse-comm', action='store_true',
+                    help='1 GPU only: run the step with a live 1-rank RCCL communicator and the collective path forced on (what every '
+                         'rank does at N > 1 minus the link time): prices the captured fork / join edges and RCCL launches')
+    ap.add_argument('--bucket-mb', type=float, default=32.0)
+    ap.add_argument('--tail-mb', type=float, default=0.0)
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU/gloo rehearsal of the launcher, rendezvous, barrier / max-over-ranks timing and the JSON line; no GPU, no model')
     return ap.parse_args(argv)
@@ -245,6 +250,8 @@ def main():
         # the C-ABI (lintransunet_amd/comm.py) - no ProcessGroupNCCL, hence no watchdog thread next to the graph captures
         dist.init_process_group('gloo')
         comm = C.RcclComm(dev, control=C.GlooComm())
+    elif args.rehearse_comm:
+        comm = C.RcclComm(dev)
 
     torch.manual_seed(1234)          # same initial weights on every rank (then broadcast for good measure)
     act = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -252,7 +259,8 @@ def main():
                                             1, args.classes, dropout=0.3, act_dtype=act).to(dev).train()
     train.broadcast_parameters(model, comm)
     torch.manual_seed(1234 + rank)   # dropout streams differ per rank
-    reducer = train.GradReducer(model, bucket_mb=16.0, unused=train.UNUSED_PARAMETERS, comm=comm)
+    reducer = train.GradReducer(model, bucket_mb=args.bucket_mb, unused=train.UNUSED_PARAMETERS, comm=comm, tail_mb=args.tail_mb,
+                                force_collectives=args.rehearse_comm and world == 1)
     size = (args.size,) * 3
     weights = train.get_dynamic_weight(1)[0]
     batches = [synthetic_batch(args.batch, size, 100 + 10 * rank + i, dev, args.classes) for i in range(2)]
@@ -336,18 +344,19 @@ def main():
     timer.calls = []
 
     launch = 'eager'
-    allreduce = 'hooks (overlapped with backward)' if world > 1 else 'none (1 rank)'
+    allreduce = 'hooks (overlapped with backward)' if (world > 1 or args.rehearse_comm) else 'none (1 rank)'
     step = eager_step
     if not args.no_graph:
         # ladder: collectives captured inside the step graph (overlapped) -> collectives after the replay -> eager launches.
         # A failed capture must not cost the measurement; every rung runs the same kernels.
-        modes = [args.allreduce] if args.allreduce else (['graph', 'after'] if world > 1 else ['graph'])
+        multi = world > 1 or args.rehearse_comm
+        modes = [args.allreduce] if args.allreduce else (['graph', 'after'] if multi else ['graph'])
         for mode in modes:
             try:
                 graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer, specs=specs, overlap=mode)
                 step = lambda i: graphed(*batches[i % 2])
                 launch = 'hip-graph replay'
-                if world > 1:
+                if multi:
                     allreduce = ('captured in the step graph (side branches, overlapped with backward)' if mode == 'graph'
                                  else 'after the replay (exposed)')
                 break

@@ -17,8 +17,10 @@
   the CPU stand-in of the two entry points in the world-size-2 tests (tests/test_host_cpu.py).
 * `LocalComm` - world size 1: nothing to exchange.
 """
+import contextlib
 import ctypes
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -98,6 +100,21 @@ class _StreamHandle:
         torch.cuda.current_stream().wait_stream(self.stream)
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner to stdout (file descriptor 1) when rank 0 creates its first communicator; a benchmark's
+    stdout carries exactly one JSON line, so the banner is sent to stderr instead"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def _librccl_path():
     return os.environ.get('LTU_LIBRCCL') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
 
@@ -117,7 +134,7 @@ class RcclComm:
             _lib.call('ltu_comm_unique_id', uid.data_ptr())
         self.control.broadcast(uid, 0)
         h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _stdout_to_stderr():
             _lib.call('ltu_comm_init', ctypes.byref(h), uid.data_ptr(), self.world, self.rank)
             self.stream = torch.cuda.Stream(device=self.device)
         self.handle = h

@@ -118,18 +118,26 @@ class GradReducer:
     With gradient accumulation only the last micro-step reduces (`prepare(reduce=False)` otherwise).
     """
 
-    def __init__(self, model, bucket_mb=16.0, unused=None, comm=None, fused=True):
+    def __init__(self, model, bucket_mb=32.0, unused=None, comm=None, fused=True, tail_mb=0.0, force_collectives=False):
         """comm: a communicator of lintransunet_amd.comm (RcclComm on the GPU, GlooComm on CPU tensors); None = LocalComm, or -
         when torch.distributed is initialised with a gloo group - a GlooComm over the default group"""
         if comm is None:
             comm = (_comm.GlooComm() if (dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'gloo')
                     else _comm.LocalComm())
         self.comm = comm
-        self.world = comm.world
+        # force_collectives: take the multi-rank code path (bucket plan, hooks, collectives) on a 1-rank communicator - the one-GPU
+        # rehearsal of what every rank does at N > 1 (tools/check_dist_graph.py, bench.py --rehearse-comm)
+        self.world = max(comm.world, 2) if force_collectives else comm.world
         unused = set(unused or [])
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and n not in unused]
         named.reverse()
         self.cap = int(bucket_mb * 1024 * 1024 / 4)
+        # The gradients that become ready last (the encoder's first layers) close their bucket at the very end of backward, so that
+        # bucket's all-reduce is exposed whatever its size; `tail_mb` > 0 gives the last parameters a bucket of their own (a
+        # latency-sized collective) so that the bulk of the former last bucket starts earlier.  Off by default: on ROCm 7.0 a
+        # captured fork costs 0 - 0.6 ms depending on WHERE in the step graph it lands (profiles/r03_bucket_sweep.txt: 32 MB
+        # buckets = 3 forks are free, the extra fork of a tail bucket costs 0.55 ms - more than the ~0.2 ms it would hide).
+        self.tail_cap = int(tail_mb * 1024 * 1024 / 4)
         self.fused = fused
         self.ready_order = []           # parameters in the order their gradients became ready in the last backward
         self._seen = set()
@@ -152,6 +160,13 @@ class GradReducer:
                 cur, cur_n = [], 0
         if cur:
             self.buckets.append(cur)
+        if self.tail_cap > 0 and self.buckets and self.world > 1:
+            last, tail, n = self.buckets[-1], [], 0
+            while len(last) > 1 and n + last[-1].numel() <= self.tail_cap:
+                n += last[-1].numel()
+                tail.insert(0, last.pop())
+            if tail:
+                self.buckets.append(tail)
         self.flat, self.handles = [], []
         self.bucket_of = {}
         for bi, plist in enumerate(self.buckets):
@@ -207,7 +222,8 @@ class GradReducer:
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.reduce_now:
-            self.ctx.flush_deferred()       # pending second-stage reductions may still owe this bucket their sums
+            if os.environ.get('LTU_NO_HOOK_FLUSH') != '1':
+                self.ctx.flush_deferred()       # pending second-stage reductions may still owe this bucket their sums
             self.handles.append((bi, self._all_reduce(self.flat[bi])))
 
     def reduce_all(self):

@@ -28,11 +28,17 @@ def build(with_comm=True):
     torch.manual_seed(5)
     m = get_model_dict('MaskTransUnet')([8, 8, 8, 16, 32], [20, 12, 9, 10, 6], [False, True, True, True, True], 1, 2,
                                         dropout=0.0, act_dtype=DT).to(dev).train()
-    red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS, comm=comm if with_comm else None)
+    red = train.GradReducer(m, bucket_mb=0.25, tail_mb=0.01, unused=train.UNUSED_PARAMETERS, comm=comm if with_comm else None,
+                            force_collectives=with_comm)
     if with_comm:
         train.broadcast_parameters(m, comm)
-        red.world = 2           # force the collective path
     return m, red
+
+
+def grads_of(m):
+    """the whole gradient in registration order as one vector (bucket plans differ between the runs; single tensors whose gradient
+    is mathematically zero - conv biases in front of InstanceNorm, the key bias - hold only rounding noise)"""
+    return [torch.cat([p.grad.detach().flatten() for p in m.parameters() if p.grad is not None]).clone()]
 
 
 x = seedgen.seeded_volume((2, 1, 32, 32, 32), 1).to(dev)
@@ -55,7 +61,7 @@ for mode in ('graph', 'after', 'none'):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20 * 1e3
     per = (comm.calls - n0) / 23
-    results[mode] = [f.clone() for f in red.flat]
+    results[mode] = grads_of(m)
     print(f'{mode:6s}: {len(red.flat)} buckets, collectives enqueued while building (warm-up + capture) {built}, per replay {per:.1f}, '
           f'{dt:.3f} ms/step, loss {sum(t.item() for t in totals):.6f}', flush=True)
     if mode == 'graph':
@@ -67,7 +73,7 @@ m, red = build()
 red.zero_grad()
 train.train_step(m, x, lab, w, reducer=red)
 torch.cuda.synchronize()
-results['eager'] = [f.clone() for f in red.flat]
+results['eager'] = grads_of(m)
 # buckets in gradient-ready order, then the captured step again: same gradients (summed over all parameters)
 tot_before = sum(f.double().sum().item() for f in red.flat)
 names = {id(p): n for n, p in m.named_parameters()}
@@ -80,7 +86,7 @@ tot_after = sum(f.double().sum().item() for f in red.flat)
 assert abs(tot_after - tot_before) <= 1e-3 * abs(tot_before) + 1e-6, (tot_before, tot_after)
 for mode in ('after', 'eager', 'none'):
     worst = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(results['graph'], results[mode]))
-    print(f'gradients graph vs {mode}: worst bucket rel-L2 {worst:.2e}')
+    print(f'gradients graph vs {mode}: whole-gradient rel-L2 {worst:.2e}')
     assert worst < (5e-2 if DT == torch.bfloat16 else 1e-4)
 # accumulation: 2 micro-steps, collectives only inside the last one's graph
 m, red = build()
@@ -88,9 +94,9 @@ step = train.GraphedStep(m, x, lab, w, red, step_times=2, overlap='graph')
 for j in range(2):
     step(x, lab, micro=j)
 torch.cuda.synchronize()
-acc = [f.clone() for f in red.flat]
+acc = grads_of(m)
 worst = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(acc, results['graph']))
-print(f'2 accumulated half-weight micro-steps vs one step: worst bucket rel-L2 {worst:.2e}; graphs {sorted(step.graphs)}')
+print(f'2 accumulated half-weight micro-steps vs one step: whole-gradient rel-L2 {worst:.2e}; graphs {sorted(step.graphs)}')
 assert worst < (5e-2 if DT == torch.bfloat16 else 1e-4)
 # storage that moves in the middle of an accumulation cycle must be refused (a re-capture would zero the accumulated buckets)
 from lintransunet_amd import optim
