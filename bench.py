@@ -133,6 +133,7 @@ def parse_args(argv=None):
     ap.add_argument('--classes', type=int, default=2, choices=[2, 3],
                     help='model outputs: 2 = single-class pancreas (BASELINE configs 2/3), 3 = multi-class path (config 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-families', action='store_true', help='skip the per-family timing table of the roofline object')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured HIP graph')
     ap.add_argument('--allreduce', default=None, choices=['graph', 'after'],
                     help="gradient all-reduce of the graph-replayed step: captured inside the graph (overlapped, default) or after the replay")
@@ -337,6 +338,13 @@ def main():
     timer.on = False
     reducer.rebucket()                        # buckets in gradient-ready order (recorded by the eager step): each bucket's all-reduce
                                               # starts while backward still produces the next one
+    # per-family device time of the step (tools/family_timer.py): the C-ABI calls that go into the captured step graph are logged,
+    # then each family's launches are replayed alone from a graph of their own between one HIP event pair
+    families, ft = None, None
+    if not args.no_families and not args.no_graph:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from family_timer import FamilyTimer
+        ft = FamilyTimer()
     for c in timer.calls:
         chain_buffers(*c[1].shape)            # allocate / prepare outside the timed replay
     ms_lin, n_lin = timer.measure(replay)
@@ -353,7 +361,14 @@ def main():
         modes = [args.allreduce] if args.allreduce else (['graph', 'after'] if multi else ['graph'])
         for mode in modes:
             try:
-                graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer, specs=specs, overlap=mode)
+                if ft is not None:
+                    ft.calls.clear()
+                    ft.attach()
+                try:
+                    graphed = train.GraphedStep(model, batches[0][0], batches[0][1], weights, reducer, specs=specs, overlap=mode)
+                finally:
+                    if ft is not None:
+                        ft.detach()
                 step = lambda i: graphed(*batches[i % 2])
                 launch = 'hip-graph replay'
                 if multi:
@@ -365,6 +380,8 @@ def main():
                       file=sys.stderr)
                 torch.cuda.synchronize()
 
+    if ft is not None and ft.calls and launch == 'hip-graph replay':
+        families = ft.table(ft.measure(), args.size, args.batch)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -411,7 +428,10 @@ def main():
                          'timing': 'one HIP event pair around a graph replay of exactly these launches',
                          # the whole step against SURVEY 8d's mixed roofline (convs at the MFMA peak + everything else at the HBM peak)
                          'step_roofline_ms': roof_ms * args.batch if roof_ms else None,
-                         'step_frac': (roof_ms * args.batch / ms_step) if roof_ms else None},
+                         'step_frac': (roof_ms * args.batch / ms_step) if roof_ms else None,
+                         # every op family of the step, replayed alone (graph of exactly its launches, one HIP event pair), against the
+                         # algorithmic work SURVEY 8d assigns it (fwd + bwd = 3 x forward) and the peak that bounds it
+                         'families': families},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(size)

@@ -344,6 +344,67 @@ __global__ void __launch_bounds__(1024) linattn_kv_combine(const float* __restri
   }
 }
 
+// The same merge as ONE launch (two dependent 5 us launches were pure latency at every level): grid (8, B*H), block 256.  Workgroup w
+// produces accT rows j = 4w .. 4w+3 (128 elements) from ALL nsplit partials; every workgroup recomputes the 32 column maxima and
+// sums itself (2 x nsplit x 128 B from L2) and keeps the nsplit x 32 rescale factors exp(m_s - m) in LDS.
+__global__ void __launch_bounds__(256) linattn_kv_combine1(const float* __restrict__ part, int nsplit, float* __restrict__ stats,
+                                                           float* __restrict__ ctx, int H) {
+  extern __shared__ __attribute__((aligned(16))) float fs[];       // [nsplit][32]
+  __shared__ float red[8][32];
+  __shared__ float4 red4[7][32];
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const float* p0 = part + ((long long)b * nsplit * H + h) * PART_STRIDE;
+  const long long sstride = (long long)H * PART_STRIDE;
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float m = -INFINITY;
+#pragma unroll 8
+  for (int s = grp; s < nsplit; s += 8) m = fmaxf(m, p0[s * sstride + l]);
+  red[grp][l] = m;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) m = fmaxf(m, red[q][l]);
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll 8
+  for (int s = grp; s < nsplit; s += 8) {
+    const float f = __expf(p0[s * sstride + l] - m);
+    fs[s * 32 + l] = f;
+    ss += p0[s * sstride + 32 + l] * f;
+  }
+  red[grp][l] = ss;
+  __syncthreads();                             // also: every factor is in LDS
+  ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ss += red[q][l];          // same order in every thread and workgroup: one value per column
+  // accT slice: thread (grp, l) takes the float4 at element e0 = 128 w + 4 l of splits grp, grp + 8, ...; its 4 columns are 4 (l & 7) ..
+  const int e0 = blockIdx.x * 128 + l * 4, c0 = e0 & 31;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int s = grp; s < nsplit; s += 8) {
+    const float4 v = *reinterpret_cast<const float4*>(p0 + s * sstride + 64 + e0);
+    const float4 f = *reinterpret_cast<const float4*>(fs + s * 32 + c0);
+    a.x += v.x * f.x; a.y += v.y * f.y; a.z += v.z * f.z; a.w += v.w * f.w;
+  }
+  if (grp > 0) red4[grp - 1][l] = a;
+  // column sums of this thread's 4 columns (threads with l < 8 of group 0 hold all 32 between them after the exchange below)
+  __shared__ float scol[32];
+  if (grp == 0) scol[l] = ss;
+  __syncthreads();
+  if (grp != 0) return;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float4 v = red4[q][l];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int j = e0 >> 5;                        // accT[j][c0 .. c0+3] -> ctx[c][j] / colsum[c]
+  float* o = ctx + (long long)bh * 1024 + j;
+  o[c0 * 32] = a.x / scol[c0]; o[(c0 + 1) * 32] = a.y / scol[c0 + 1]; o[(c0 + 2) * 32] = a.z / scol[c0 + 2]; o[(c0 + 3) * 32] = a.w / scol[c0 + 3];
+  if (blockIdx.x == 0) {
+    stats[bh * 64 + l] = m;
+    stats[bh * 64 + 32 + l] = ss;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ phase B
 // grid (ceil(N/tokb), B), block 2D; each block handles tokb tokens in tiles of 32.
 // out [B*N][d];  qstat [B*N][H][2] = (row max, 1/(rowsum*sqrt(32)))
@@ -944,7 +1005,9 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
       // two-level merge of the split partials (level-1 results live behind the level-0 partials in part_ws)
       const int group = KVC_GROUP, ngroups = (nsplit + group - 1) / group;
       float* part2 = part_ws + (size_t)B * nsplit * H * PART_STRIDE;
-      if (ngroups > 1) {
+      if (nsplit * 32 * sizeof(float) <= 48 * 1024 && !ltu_knob("LTU_LA_TWO_LEVEL", 0)) {
+        hipLaunchKernelGGL(linattn_kv_combine1, dim3(8, B * H), dim3(256), (size_t)nsplit * 32 * sizeof(float), st, part_ws, nsplit, colstats, ctx, H);
+      } else if (ngroups > 1) {
         hipLaunchKernelGGL(linattn_kv_combine, dim3(ngroups, B * H), dim3(1024), 0, st, part_ws, nsplit, group, part2, colstats, ctx, H, 0);
         hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part2, ngroups, ngroups, nullptr, colstats, ctx, H, 1);
       } else {

@@ -452,8 +452,10 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
   }
 }
 
-template <int D, int UMODE>
-__global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_bwd_kernel(const TailBwdArgs ta) {
+// WPS: waves per SIMD the register allocator has to fit (d = 128: 4 = four workgroups per CU at a 128-register budget, which spills
+// 9 registers; 3 = 168 registers, no spills, three workgroups per CU.  d = 256 runs 512-thread workgroups, two per CU: 4)
+template <int D, int UMODE, int WPS>
+__global__ void __launch_bounds__(D >= 256 ? 512 : 256, WPS) tail_bwd_kernel(const TailBwdArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
   constexpr int NT1 = D / 32, NT2 = 2 * D / 32;
@@ -586,9 +588,11 @@ extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)s, ta);
   };
   if (d == 256) {
-    if (u_mode) launch(&tail_bwd_kernel<256, 1>, 512); else launch(&tail_bwd_kernel<256, 0>, 512);
+    if (u_mode) launch(&tail_bwd_kernel<256, 1, 4>, 512); else launch(&tail_bwd_kernel<256, 0, 4>, 512);
+  } else if (ltu_knob("LTU_TAIL_BWD_WPS", 4) == 3) {
+    if (u_mode) launch(&tail_bwd_kernel<128, 1, 3>, 256); else launch(&tail_bwd_kernel<128, 0, 3>, 256);
   } else {
-    if (u_mode) launch(&tail_bwd_kernel<128, 1>, 256); else launch(&tail_bwd_kernel<128, 0>, 256);
+    if (u_mode) launch(&tail_bwd_kernel<128, 1, 4>, 256); else launch(&tail_bwd_kernel<128, 0, 4>, 256);
   }
   return ltu_check_launch();
 }

@@ -1,12 +1,15 @@
 #!/bin/bash
-# usage: sweep_env.sh VAR v1 v2 ... -- PATTERN   : rocprof kernel-time total of the bench step and of kernels matching PATTERN per value
-VAR=$1; shift
-VALS=()
-while [ "$1" != "--" ]; do VALS+=("$1"); shift; done
-shift
-PAT=$1
-for v in "${VALS[@]}"; do
-  export $VAR=$v
-  bash tools/profile_bench.sh > /dev/null 2>&1
-  echo "$VAR=$v: $(head -1 gpurun_out/prof_bench_stats.txt | cut -d' ' -f1-3)  match=$(grep -E "$PAT" gpurun_out/prof_bench_stats.txt | awk '{s+=$1} END {print s}') ms"
+# one box, one sitting: the default bench under runtime environment variables that change how HIP graphs dispatch kernels
+run() { env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; L=sys.stdin.read().splitlines(); d=json.loads([l for l in L if l.startswith(chr(123))][0]); print('$*', round(d['ms_per_step'], 3), flush=True)"; }
+for rep in 1 2; do
+  run A=0
+  run DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
+  run DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+  run HIP_FORCE_DEV_KERNARG=1
+  run HIP_FORCE_DEV_KERNARG=0
+  run GPU_MAX_HW_QUEUES=1
+  run GPU_MAX_HW_QUEUES=2
+  run GPU_MAX_HW_QUEUES=8
+  run HSA_NO_SCRATCH_RECLAIM=1
+  run DEBUG_HIP_GRAPH_DOT_PRINT=0 AMD_DIRECT_DISPATCH=1
 done
