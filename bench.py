@@ -280,9 +280,11 @@ def main():
     def tail_bytes(ctx, a, x, *rest):
         # forward: reads q (the q third of the qkv rows: the attention's phase B runs inside the kernel), x; writes a, z1, t1, z2, y
         # (d wide) and u, h (2d wide); backward: reads dy, dy2, z2, z1, u; writes dr2, dr1, dz1, da, du; weights (8 d^2 forward +
-        # 8 d^2 backward, bf16) are read once per launch from HBM
+        # 8 d^2 backward, bf16) are read once per launch from HBM.  A launch that also forms the next layer's q|k|v projection
+        # (round 3) writes 3 M d more and reads 3 d^2 more weights
         M, d = x.shape
-        return float((11 + 13) * M * d + 16 * d * d) * 2.0
+        nxt = len(rest) > 16 and rest[-1] is not None
+        return float((11 + 13 + (3 if nxt else 0)) * M * d + (16 + (3 if nxt else 0)) * d * d) * 2.0
     ops._LayerTail.forward = staticmethod(timer.wrap(ops._LayerTail.forward, tail_bytes, 'tail'))
     chain_cache = {}
 
@@ -301,7 +303,8 @@ def main():
             nblk = _lib.load().ltu_layer_tail_blocks(M)
             chain_cache[(M, d)] = dict(
                 a=bf(M, d), x=bf(M, d), dy=bf(M, d), dy2=bf(M, d), w=[fragw(d, d, 8), fragw(2 * d, d, 8), fragw(d, 2 * d, 8)],
-                qkv=bf(M, 3 * d), ctx=torch.randn(2 * (d // 32), 32, 32, device=dev) * 0.05, qstat=torch.empty(M, d // 32, 2, device=dev),
+                qkv=bf(M, 3 * d), ctx=torch.randn(args.batch * (d // 32), 32, 32, device=dev) * 0.05, qstat=torch.empty(M, d // 32, 2, device=dev),
+                wq=torch.cat([fragw(d, d, 8) for _ in range(3)]), qkv_next=torch.empty(M, 3 * d, device=dev, dtype=torch.bfloat16),
                 wt=[fragw(d, 2 * d, 9), fragw(2 * d, d, 9), fragw(d, d, 9)], bias=torch.zeros(2 * d, device=dev),
                 gamma=torch.ones(d, device=dev), md=[torch.empty(M, d, device=dev, dtype=torch.bfloat16) for _ in range(8)],
                 m2d=[torch.empty(M, 2 * d, device=dev, dtype=torch.bfloat16) for _ in range(3)],
@@ -311,13 +314,16 @@ def main():
     def replay(c):
         M, d = c[2].shape                  # x [M, d] (c[1] is a [M, d] or, with the fused attention phase B, qkv [M, 3d])
         fused = c[1].shape[1] == 3 * d
+        nxt = len(c) > 19 and c[-1] is not None        # the launch also forms the next layer's q|k|v projection
         q = chain_buffers(M, d)
         z1, t1, z2, y, dr2, dr1, dz1, da = q['md']
         u, h, du = q['m2d']
         _lib.call('ltu_layer_tail_fwd', _p(q['a']), _p(q['x']), _p(q['w'][0]), _p(q['w'][1]), _p(q['w'][2]), _p(q['bias']), _p(q['bias']),
                   _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(q['gamma']), _p(q['bias']), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y),
                   _p(q['stat'][0]), _p(q['stat'][1]), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, _p(q['qkv']) if fused else 0,
-                  _p(q['ctx']) if fused else 0, _p(q['qstat']) if fused else 0, M // 2 if fused else 0, 1, _s())
+                  _p(q['ctx']) if fused else 0, _p(q['qstat']) if fused else 0, M // args.batch if fused else 0,
+                  _p(q['wq']) if nxt else 0, _p(q['bias']) if nxt else 0, _p(q['bias']) if nxt else 0, _p(q['bias']) if nxt else 0,
+                  _p(q['qkv_next']) if nxt else 0, 1, _s())
         _lib.call('ltu_layer_tail_bwd', _p(q['dy']), _p(q['dy2']), _p(z2), _p(z1), _p(u), _p(q['stat'][1]), _p(q['stat'][0]), _p(q['gamma']),
                   _p(q['gamma']), _p(q['wt'][0]), _p(q['wt'][1]), _p(q['wt'][2]), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(q['lnws'][0]),
                   _p(q['lnws'][1]), M, d, 0.3, 11, 12, 13, 0, 1, 1, _s())
@@ -420,7 +426,7 @@ def main():
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights' + (', 3 labels (multi-class losses)' if args.classes == 3 else ''), 'global_batch': args.batch * world,
                        'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch, 'allreduce': allreduce},
-            'roofline': {'bound': 'hbm', 'kernel': 'tail_fwd_kernel + tail_bwd_kernel (row-block chain kernels: post-attention half of every transformer layer, forward and backward)',
+            'roofline': {'bound': 'hbm', 'kernel': 'tail_fwd_kernel + tail_bwd_kernel (row-block chain kernels: post-attention half of every transformer layer - with the next layer\'s q|k|v projection where the layers are adjacent - forward and backward)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),
                          'algorithmic_bytes_per_launch': timer.work / max(n_lin, 1), 'traffic': traffic,

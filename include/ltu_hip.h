@@ -106,12 +106,16 @@ int ltu_linear_gelu_fwd(const void* a, int lda, const void* w, const float* bias
  * qkv != NULL fuses phase B of the linear attention in front of the chain (trans_block.py:41-67 after the context has been
  * formed): the block's q rows are read from qkv [M][3d], `ctx` [B*H][32][32] is the merged context of ltu_linattn_ctx,
  * ntok = tokens per sample (a multiple of 32); `a` is then an OUTPUT ([M][d], the attention output the out-projection weight
- * gradient needs) and qstat [M][H][2] receives the row statistics ltu_linattn_bwd expects.  qkv == NULL: `a` is the input. */
+ * gradient needs) and qstat [M][H][2] receives the row statistics ltu_linattn_bwd expects.  qkv == NULL: `a` is the input.
+ * With qkv_next != NULL the q | k | v projection of the NEXT layer (model/trans_block.py:156-158, which follows :210 of this layer
+ * with nothing in between) is formed from the block's y rows before they leave LDS: qkv_next [M][3d] = y cat(Wq, Wk, Wv)^T + cat(b);
+ * wq_next = the three [d][d] weights of that layer in fragment order, back to back (ltu_weight_prep kind 8 each), bq0..2 their biases. */
 int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void* w1, const void* w2, const float* bo,
                        const float* b1, const float* b2, const float* g1, const float* be1, const float* g2, const float* be2,
                        void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1, float* stat2, long long M, int d,
                        float eps, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int u_mode,
-                       const void* qkv, const float* ctx, float* qstat, int ntok, int dtype, ltu_stream_t s);
+                       const void* qkv, const float* ctx, float* qstat, int ntok, const void* wq_next, const float* bq0,
+                       const float* bq1, const float* bq2, void* qkv_next, int dtype, ltu_stream_t s);
 
 /* The backward of the same chain as ONE launch: LayerNorm 2 backward, data gradients through linear2 / GELU + dropout / linear1,
  * LayerNorm 1 backward (on dt1 + dz2), data gradient through the out projection.  dy2 (nullable): second gradient of y, summed on

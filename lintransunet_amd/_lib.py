@@ -39,7 +39,7 @@ SIGNATURES = {
     'ltu_wgrad_ws_floats': [L, I, I],
     'ltu_upconv_wgrad_ws_floats': [L, I, I],
     'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
-    'ltu_layer_tail_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, U, U, U, P, I, P, P, P, I, I, P],
+    'ltu_layer_tail_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, U, U, U, P, I, P, P, P, I, P, P, P, P, P, I, P],
     'ltu_layer_tail_blocks': [L],
     'ltu_layer_tail_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, U, U, P, I, I, P],
     'ltu_reduce_batch': [P, I, P],

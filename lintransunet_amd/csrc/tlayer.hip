@@ -56,6 +56,12 @@ struct TailArgs {
   uint16_t* a_out;
   float* qstat;           // [M][H][2] = (row max, 1 / (row sum * sqrt(32)))
   int ntok;               // tokens per sample (a multiple of 32: a row block never straddles samples)
+  // fused q|k|v projection of the NEXT layer (QKV kernels): qkv_next [M][3d] = y Wqkv^T + b, Wqkv = cat(Wq, Wk, Wv) of the next layer
+  // in fragment order ([3d][d], kind 8); nothing but per-token ops lies between LayerNorm 2 and that projection
+  // (model/trans_block.py:156-158 follows :210 of the previous layer)
+  const uint16_t* wq;
+  const float* bq[3];
+  uint16_t* qkv_next;
   int u_mode;
   int dbg;                // ablation (tools/bench_tail.py): 2 = no GELU / dropout arithmetic, 4 = u and h are not stored
 };
@@ -153,7 +159,7 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
   }
 }
 
-template <int D, bool ATTN>
+template <int D, bool ATTN, bool QKV>
 __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const TailArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;          // padded rows: +16 bytes rotates the banks from row to row
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
@@ -166,7 +172,8 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   uint16_t* HB = TB + TL_ROWS * LD;                   // [32][LDH]  x (stage 0-2), then h
   float* PB = reinterpret_cast<float*>(HB + TL_ROWS * LDH);   // bo[D] b1[2D] b2[D] g1[D] be1[D] g2[D] be2[D]: no parameter is loaded
                                                               // from global memory behind a store (see tl_issue)
-  float* QS = PB + 8 * D;                                     // ATTN: [32][H][2] row statistics of the block
+  constexpr int NPAR = QKV ? 11 * D : 8 * D;                  // QKV: + the next layer's q | k | v biases [3D]
+  float* QS = PB + NPAR;                                      // ATTN: [32][H][2] row statistics of the block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
@@ -183,6 +190,12 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
     const float* src = e < D ? ta.bo + e : e < 3 * D ? ta.b1 + (e - D) : e < 4 * D ? ta.b2 + (e - 3 * D) : e < 5 * D ? ta.g1 + (e - 4 * D)
                        : e < 6 * D ? ta.be1 + (e - 5 * D) : e < 7 * D ? ta.g2 + (e - 6 * D) : ta.be2 + (e - 7 * D);
     *reinterpret_cast<float4*>(PB + e) = *reinterpret_cast<const float4*>(src);
+    if constexpr (QKV) {
+      if (e < 3 * D) {
+        const float* sq = e < D ? ta.bq[0] + e : e < 2 * D ? ta.bq[1] + (e - D) : ta.bq[2] + (e - 2 * D);
+        *reinterpret_cast<float4*>(PB + 8 * D + e) = *reinterpret_cast<const float4*>(sq);
+      }
+    }
   }
   for (int i = tid; i < TL_ROWS * (D / 8); i += NTHR) {
     const int r = i / (D / 8), c = (i % (D / 8)) * 8;
@@ -332,8 +345,36 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
     *reinterpret_cast<uint2*>(TB + li * LD + n) = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
   }
   __syncthreads();
-  // stage 5: z2 = t1 + drop(f), y = LN2(z2)
-  tl_layernorm<D, true, false>(TB, XA, nullptr, nullptr, LD, g2, be2, ta.z2, ta.y, ta.stat2, row0, ta.M, ta.eps, dc2, tid);
+  // stage 5: z2 = t1 + drop(f), y = LN2(z2); QKV: y also replaces t1 in XA (a lane overwrites exactly the quad it has just read)
+  if constexpr (QKV) tl_issue<KS1>(ta.wq, wave, lane, q1);   // first q|k|v tile: in flight across the LayerNorm stage
+  tl_layernorm<D, true, QKV>(TB, XA, nullptr, XA, LD, g2, be2, ta.z2, ta.y, ta.stat2, row0, ta.M, ta.eps, dc2, tid);
+  if constexpr (QKV) {
+    // stage 6: the next layer's q | k | v projection of the block: three column tiles per wave (wave, wave + NW, wave + 2 NW of the
+    // 3D / 32), staged in the TB | HB region ([32][3D + 16]: both are free now) and stored in whole rows
+    constexpr int LDQ = 3 * D + 16;
+    static_assert(TL_ROWS * LDQ == TL_ROWS * (LD + LDH), "the q|k|v staging tile is exactly TB + HB");
+    uint16_t* QB = TB;
+    const float* bq = PB + 8 * D;
+    __syncthreads();                       // y complete in XA, TB (linear2 result) consumed
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int ct = wave + t * NW;
+      tl_run<KS1>(ta.wq, ct, XA, LD, lane, q1, acc);
+      if (t < 2) tl_issue<KS1>(ta.wq, wave + (t + 1) * NW, lane, q1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = ct * 32 + 8 * q + 4 * lh;
+        const float4 b = *reinterpret_cast<const float4*>(bq + n);
+        *reinterpret_cast<uint2*>(QB + li * LDQ + n) = pack_quad(acc[4 * q] + b.x, acc[4 * q + 1] + b.y, acc[4 * q + 2] + b.z, acc[4 * q + 3] + b.w);
+      }
+    }
+    __syncthreads();
+    constexpr int CPRQ = 3 * D / 8;
+    for (int i = tid; i < TL_ROWS * CPRQ; i += NTHR) {
+      const int r = i / CPRQ, c = (i % CPRQ) * 8;
+      if (row0 + r < ta.M) *reinterpret_cast<uint4*>(ta.qkv_next + (row0 + r) * (3 * D) + c) = *reinterpret_cast<const uint4*>(QB + r * LDQ + c);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward chain
@@ -602,11 +643,13 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
                                   const float* be2, void* z1, void* t1, void* u, void* h, void* z2, void* y, float* stat1,
                                   float* stat2, long long M, int d, float eps, float p, uint64_t seed1, uint64_t seedg,
                                   uint64_t seed2, const uint64_t* step, int u_mode, const void* qkv, const float* ctx, float* qstat,
-                                  int ntok, int dtype, ltu_stream_t s) {
+                                  int ntok, const void* wq_next, const float* bq0, const float* bq1, const float* bq2,
+                                  void* qkv_next, int dtype, ltu_stream_t s) {
   if (dtype != LTU_BF16) return LTU_E_DTYPE;
   if (d != 128 && d != 256) return LTU_E_SHAPE;
   if (u_mode != 0 && u_mode != 1) return LTU_E_ARG;
   if (qkv != nullptr && (ctx == nullptr || qstat == nullptr || ntok <= 0 || ntok % TL_ROWS || M % ntok)) return LTU_E_ARG;
+  if (qkv_next != nullptr && (wq_next == nullptr || bq0 == nullptr || bq1 == nullptr || bq2 == nullptr)) return LTU_E_ARG;
   if (M <= 0) return LTU_OK;
   TailArgs ta;
   ta.u_mode = u_mode;
@@ -618,8 +661,10 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   ta.stat1 = stat1; ta.stat2 = stat2;
   ta.M = M; ta.eps = eps; ta.p = p; ta.seed1 = seed1; ta.seedg = seedg; ta.seed2 = seed2; ta.step = step;
   ta.dbg = ltu_knob("LTU_TAIL_DBG", 0);
+  ta.wq = (const uint16_t*)wq_next; ta.bq[0] = bq0; ta.bq[1] = bq1; ta.bq[2] = bq2; ta.qkv_next = (uint16_t*)qkv_next;
+  const bool qn = qkv_next != nullptr;
   const unsigned blocks = cdiv(M, TL_ROWS);
-  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)8 * d * sizeof(float) +
+  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)(qn ? 11 : 8) * d * sizeof(float) +
                      (qkv != nullptr ? (size_t)TL_ROWS * (d / 32) * 2 * sizeof(float) : 0);
   auto launch = [&](auto kern, unsigned threads) {
     static LtuDevOnce once;                // one latch per kernel instantiation
@@ -627,9 +672,11 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)s, ta);
   };
   if (d == 256) {
-    if (qkv != nullptr) launch(&tail_fwd_kernel<256, true>, 512); else launch(&tail_fwd_kernel<256, false>, 512);
+    if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<256, true, true>, 512); else launch(&tail_fwd_kernel<256, true, false>, 512); }
+    else { if (qn) launch(&tail_fwd_kernel<256, false, true>, 512); else launch(&tail_fwd_kernel<256, false, false>, 512); }
   } else {
-    if (qkv != nullptr) launch(&tail_fwd_kernel<128, true>, 256); else launch(&tail_fwd_kernel<128, false>, 256);
+    if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<128, true, true>, 256); else launch(&tail_fwd_kernel<128, true, false>, 256); }
+    else { if (qn) launch(&tail_fwd_kernel<128, false, true>, 256); else launch(&tail_fwd_kernel<128, false, false>, 256); }
   }
   return ltu_check_launch();
 }

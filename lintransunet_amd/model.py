@@ -127,11 +127,14 @@ class _WeightStore:
         for i, w in enumerate(weights):
             self.recs.append((w, wt, 1, N, K, N * len(weights), i * N))
         fr = frT = None
-        if frag and self.dtype == torch.bfloat16 and N % 32 == 0 and K % 32 == 0 and len(weights) == 1:
-            fr = torch.empty(N * K, device=self.device, dtype=self.dtype)      # MFMA fragment order (kind 8) ...
-            frT = torch.empty(N * K, device=self.device, dtype=self.dtype)     # ... and of the transpose (kind 9)
-            self.recs.append((weights[0], fr, 8, N, K, 0, 0))
-            self.recs.append((weights[0], frT, 9, N, K, 0, 0))
+        if frag and self.dtype == torch.bfloat16 and N % 32 == 0 and K % 32 == 0:
+            nw = len(weights)
+            fr = torch.empty(nw * N * K, device=self.device, dtype=self.dtype)      # MFMA fragment order (kind 8): column tiles of
+            for i, w in enumerate(weights):                                          # cat(W) = the weights' tiles back to back
+                self.recs.append((w, fr[i * N * K:(i + 1) * N * K], 8, N, K, 0, 0))
+            if nw == 1:
+                frT = torch.empty(N * K, device=self.device, dtype=self.dtype)      # ... and of the transpose (kind 9)
+                self.recs.append((weights[0], frT, 9, N, K, 0, 0))
         self.lin[key] = ops.LinPrep(fw, wt, group, fr, frT)
 
     def finalize(self):
@@ -269,7 +272,7 @@ class MaskTransUnet(nn.Module):
             for lay in tr.layers:
                 lin = lay.self_attn.linears
                 # weight gradients of a layer's projections go out as one group, launched by the qkv backward (the layer's last)
-                st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight], group='flush')
+                st.add_linear((id(lay), 'qkv'), [lin[0].weight, lin[1].weight, lin[2].weight], group='flush', frag=True)
                 st.add_linear((id(lay), 'o'), [lin[3].weight], group='collect', frag=True)
                 st.add_linear((id(lay), 'f1'), [lay.linear1.weight], group='collect', frag=True)
                 st.add_linear((id(lay), 'f2'), [lay.linear2.weight], group='collect', frag=True)
@@ -284,28 +287,41 @@ class MaskTransUnet(nn.Module):
         y = ops.conv3d(x, conv.weight, conv.bias, stride=stride, x1=x1, ups=ups, prep=self._store.conv[id(conv)])
         return ops.instnorm_act(y, res=res, act=ops.ACT_LRELU, p=p, seed=seeds.next() if p > 0 else 0, fork=fork, res_dup=res_dup)
 
-    def _layer(self, lay, t, tres, B, N, d, p, seeds, last):
+    def _chain_ok(self, lay, B, N, d):
+        """the row-block chain kernels (csrc/tlayer.hip) serve this layer"""
+        po = self._store.lin[(id(lay), 'o')]
+        return (po is not None and po.frag is not None and d in (128, 256) and 64 <= B * N <= ops.TAIL_MAX_TOKENS and ops.USE_LAYER_TAIL)
+
+    def _layer(self, lay, t, tres, B, N, d, p, seeds, last, qkv=None, nxt=None):
         """post-norm transformer layer on tokens t [B*N, d] (model/trans_block.py:148-166, 203-211).  `t` feeds the
-        projections, `tres` (same values) the residual: two autograd edges whose gradients the LayerNorm backward sums."""
+        projections, `tres` (same values) the residual: two autograd edges whose gradients the LayerNorm backward sums.
+        qkv: this layer's fused q|k|v projection, already formed by the previous layer's chain kernel (then t is None);
+        nxt: the next layer, whose q|k|v projection this layer's chain kernel forms.  Returns (t, tres, qkv_next)."""
         lin = lay.self_attn.linears
         wl = self._store.lin
-        if ops.WGRAD_FLUSH_PER_LAYER:
-            t = ops.wgrad_flush_point(t)     # the qkv data gradient is the last backward op of a layer
-        qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
-                         prep=wl[(id(lay), 'qkv')])
+        if qkv is None:
+            if ops.WGRAD_FLUSH_PER_LAYER:
+                t = ops.wgrad_flush_point(t)     # the qkv data gradient is the last backward op of a layer
+            qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
+                             prep=wl[(id(lay), 'qkv')])
         po, p1, p2 = wl[(id(lay), 'o')], wl[(id(lay), 'f1')], wl[(id(lay), 'f2')]
-        if (po is not None and po.frag is not None and d in (128, 256) and B * N <= ops.TAIL_MAX_TOKENS and B * N >= 64
-                and ops.USE_LAYER_TAIL):
+        if self._chain_ok(lay, B, N, d):
             # the rest of the layer as one launch (csrc/tlayer.hip); with N a multiple of the kernel's 32-row blocks the
             # attention's phase B runs inside it too (the chain kernel reads its q rows and applies the merged context)
             s1, sg, s2 = ((seeds.next(), seeds.next(), seeds.next()) if p > 0 else (0, 0, 0))
             fuse = ops.FUSE_ATTN_APPLY and N % 32 == 0 and qkv.dtype == torch.bfloat16
             a = qkv if fuse else ops.linear_attention(qkv, B, N, d)
+            nx = None
+            if nxt is not None:
+                nl = nxt.self_attn.linears
+                nx = ([nl[0].weight, nl[1].weight, nl[2].weight], [nl[0].bias, nl[1].bias, nl[2].bias], wl[(id(nxt), 'qkv')])
             out = ops.layer_tail(a, tres, (lin[3].weight, lin[3].bias, lay.linear1.weight, lay.linear1.bias, lay.linear2.weight,
                                            lay.linear2.bias, lay.layer_norm1.weight, lay.layer_norm1.bias, lay.layer_norm2.weight,
-                                           lay.layer_norm2.bias), (po, p1, p2), 1e-6, p, (s1, sg, s2), fork=not last,
-                                 attn=(B, N) if fuse else None)
-            return out if not last else (out, out)
+                                           lay.layer_norm2.bias), (po, p1, p2), 1e-6, p, (s1, sg, s2), fork=not last and nx is None,
+                                 attn=(B, N) if fuse else None, nxt=nx)
+            if nx is not None:
+                return None, out[0], out[1]
+            return (out, out, None) if last else (out[0], out[1], None)
         a = ops.linear_attention(qkv, B, N, d)
         a = ops.linear(a, [lin[3].weight], [lin[3].bias], prep=wl[(id(lay), 'o')])
         t, tres = ops.res_layernorm(tres, a, lay.layer_norm1.weight, lay.layer_norm1.bias, 1e-6, p, seeds.next() if p > 0 else 0,
@@ -314,7 +330,7 @@ class MaskTransUnet(nn.Module):
         f = ops.linear(f, [lay.linear2.weight], [lay.linear2.bias], prep=wl[(id(lay), 'f2')])
         out = ops.res_layernorm(tres, f, lay.layer_norm2.weight, lay.layer_norm2.bias, 1e-6, p, seeds.next() if p > 0 else 0,
                                 fork=not last)
-        return out if not last else (out, out)
+        return (out, out, None) if last else (out[0], out[1], None)
 
     def _token_transformer(self, layers, pos, x, p, seeds, x_res=None):
         """8 layers over the voxels of x [B,H,W,D,d]; positional conv after layer 0.  Token order does not
@@ -325,13 +341,21 @@ class MaskTransUnet(nn.Module):
         x = ops.wgrad_flush_point(x)         # backward: the transformer's weight gradients go out as one branch from here
         t = x.reshape(B * N, d)
         tres = t if x_res is None else x_res.reshape(B * N, d)
+        qkv = None
         for n, lay in enumerate(layers):
+            # layer n's chain kernel also forms layer n + 1's q|k|v projection whenever nothing lies between the two layers (the
+            # positional conv follows layer 0) and both run the chain kernels
+            nxt = None
+            if (ops.FUSE_NEXT_QKV and 1 <= n < len(layers) - 1 and x.dtype == torch.bfloat16 and self._chain_ok(lay, B, N, d)
+                    and ops.FUSE_QKV_MIN_TOKENS <= B * N <= ops.FUSE_QKV_MAX_TOKENS
+                    and self._store.lin[(id(layers[n + 1]), 'qkv')].frag is not None and not ops.WGRAD_FLUSH_PER_LAYER):
+                nxt = layers[n + 1]
             # the positional conv after layer 0 consumes a single tensor; so does whatever follows the last layer
-            t, tres = self._layer(lay, t, tres, B, N, d, p, seeds, last=(n == 0 or n == len(layers) - 1))
+            t, tres, qkv = self._layer(lay, t, tres, B, N, d, p, seeds, last=(n == 0 or n == len(layers) - 1), qkv=qkv, nxt=nxt)
             if n == 0:
                 g, g_res = ops.pos_conv(t.view(B, H, W, D, d), pos.proj.weight, pos.proj.bias, p, seeds.next() if p > 0 else 0, fork=2)
                 t, tres = g.view(B * N, d), g_res.view(B * N, d)
-        return t.view(B, H, W, D, d)
+        return tres.view(B, H, W, D, d)
 
     def _roi_bridge(self, br, skip, mask, roi_size, p, seeds):
         """model/Unet_3Dblock.py:717-755"""

@@ -964,6 +964,9 @@ def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):
 
 
 FUSE_ATTN_APPLY = True      # phase B of the linear attention inside the forward chain kernel (tests flip it to compare)
+FUSE_NEXT_QKV = _os.environ.get('LTU_NO_FUSE_QKV', '') == ''      # the next layer's q|k|v projection at the end of the forward chain kernel
+FUSE_QKV_MAX_TOKENS = int(_os.environ.get('LTU_FUSE_QKV_MAX_TOKENS', '50000'))      # measured: pays at the d = 256 levels (-0.05 ms), costs as much at 114 816 x 128
+FUSE_QKV_MIN_TOKENS = int(_os.environ.get('LTU_FUSE_QKV_MIN_TOKENS', '0'))
 
 
 class _LayerTail(torch.autograd.Function):
@@ -971,7 +974,8 @@ class _LayerTail(torch.autograd.Function):
     y = LN2(t1 + drop(W2 drop(gelu(W1 t1)))),  t1 = LN1(x + drop(Wo a)).  Backward: the op-by-op kernels on the saved tensors."""
 
     @staticmethod
-    def forward(ctx, a, x, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, preps, eps, p, seeds, fork, attn):
+    def forward(ctx, a, x, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, preps, eps, p, seeds, fork, attn, nq0=None, nq1=None, nq2=None,
+                nb0=None, nb1=None, nb2=None, nprep=None):
         lc = ctx.lc = current()
         _chk(a, 'a'); _chk(x, 'x')
         M, d = x.shape
@@ -993,32 +997,58 @@ class _LayerTail(torch.autograd.Function):
         z1, t1, z2, y = (torch.empty((M, d), device=dev, dtype=dt) for _ in range(4))
         u, h = (torch.empty((M, 2 * d), device=dev, dtype=dt) for _ in range(2))
         stat1, stat2 = (torch.empty((M, 2), device=dev, dtype=torch.float32) for _ in range(2))
+        # the NEXT layer's q | k | v projection inside this launch (nprep: its LinPrep with the fragment-ordered cat(Wq, Wk, Wv))
+        qkv_next = torch.empty((M, 3 * d), device=dev, dtype=dt) if nprep is not None else None
         # u_mode 1: the kernel leaves dropout_mask * gelu'(u) in `u` - all the backward chain kernel needs of it; the op-by-op
         # backward (no transposed fragments, or switched off) wants the pre-activation itself
         u_mode = 1 if (USE_LAYER_TAIL_BWD and po.fragT is not None and p1.fragT is not None and p2.fragT is not None) else 0
         _lib.call('ltu_layer_tail_fwd', _p(a), _p(x), _p(po.frag), _p(p1.frag), _p(p2.frag), _p(bo), _p(b1), _p(b2), _p(g1), _p(be1),
                   _p(g2), _p(be2), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(stat1), _p(stat2), M, d, float(eps), float(p),
-                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), u_mode, _p(qkv), _p(cx), _p(qstat), attn[1] if attn else 0, _dt(a), _s())
-        ctx.save_for_backward(a, z1, stat1, t1, u, h, z2, stat2)
+                  seeds[0], seeds[1], seeds[2], lc.step_ptr(), u_mode, _p(qkv), _p(cx), _p(qstat), attn[1] if attn else 0,
+                  _p(nprep.frag) if nprep is not None else 0, _p(nb0), _p(nb1), _p(nb2), _p(qkv_next), _dt(a), _s())
+        ctx.save_for_backward(a, z1, stat1, t1, u, h, z2, stat2, y if nprep is not None else None)
         ctx.params = (wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
         ctx.cfg = (preps, p, seeds)
         ctx.u_mode = u_mode
         ctx.attn = None if attn is None else (attn, qkv, cx, colstats, qstat)
+        ctx.nxt = None if nprep is None else ((nq0, nq1, nq2), (nb0, nb1, nb2), nprep)
+        if nprep is not None:
+            return y, qkv_next              # y has one consumer left (the next layer's residual): no second port
         return (y, y.view_as(y)) if fork else y
 
     @staticmethod
     def backward(ctx, g, g2=None):
         lc = ctx.lc
-        a, z1, stat1, t1, u, h, z2, stat2 = ctx.saved_tensors
+        a, z1, stat1, t1, u, h, z2, stat2, y = ctx.saved_tensors
         wo, bo, w1, b1, w2, b2, gm1, be1, gm2, be2 = ctx.params
         (po, p1, p2), p, seeds = ctx.cfg
+        M, d = a.shape
+        dev, dt = a.device, _dt(a)
+        nxt_grads = (None,) * 7
+        if ctx.nxt is not None:
+            # second output = the next layer's qkv: its gradient g2 = dqkv goes through that projection here - the data gradient
+            # becomes the second gradient of y, the weight gradient closes the next layer's group (its last backward op)
+            (nws, nbs, nprep), gq = ctx.nxt, g2
+            g2 = None
+            if gq is not None:
+                gq = gq.contiguous()
+                g2 = torch.empty((M, d), device=dev, dtype=a.dtype)
+                _lib.call('ltu_linear_fwd', _p(gq), 3 * d, _ptr_array([nprep.wt]), 1, _ptr_array([None]), _p(g2), d, M, d, 3 * d, 0, dt, _s())
+                gw = [_grad_buf(w) for w in nws]
+                gb = [_grad_buf(b) for b in nbs]
+                dws, dbs = [t for t, _ in gw], [t for t, _ in gb]
+                if GROUP_WGRAD and lc.wg_branch is None and all(f for _, f in gw) and all(f for _, f in gb):
+                    lc.wgrad_group_push(gq, y, dws, dbs, M, 3 * d, d, True)
+                else:
+                    _lib.call('ltu_linear_wgrad', _p(gq), 3 * d, _p(y), d, _ptr_array(dws), _ptr_array(dbs), 3, M, 3 * d, d,
+                              _p(_wgrad_ws(M, 3 * d, d, y)), 0, dt, _s())
+                nxt_grads = tuple(_grad_done(w, t, f) for w, (t, f) in zip(nws, gw)) + \
+                    tuple(_grad_done(b, t, f) for b, (t, f) in zip(nbs, gb)) + (None,)
         if g is None:
             g, g2 = g2, None
         g = g.contiguous()
         if g2 is not None:
             g2 = g2.contiguous()
-        M, d = a.shape
-        dev, dt = a.device, _dt(a)
 
         def ln_bwd(gy, gy2, z, stat, gamma, beta, seed):
             dz = torch.empty_like(z)
@@ -1066,7 +1096,7 @@ class _LayerTail(torch.autograd.Function):
             (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)
             (dw1,), (db1,) = _wgrad_now_or_group(lc, du, t1, [w1], [b1], M, 2 * d, d)
             (dwo,), (dbo,) = _wgrad_now_or_group(lc, dr1, a, [wo], [bo], M, d, d)
-            return _LayerTail._attn_bwd(ctx, da), dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None, None
+            return (_LayerTail._attn_bwd(ctx, da), dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None, None) + (nxt_grads if ctx.nxt is not None else ())
         dz2, dr2, dgm2, dbe2 = ln_bwd(g, g2, z2, stat2, gm2, be2, seeds[2])
         dh = dgrad(dr2, p2, w2, d, 2 * d)
         (dw2,), (db2,) = _wgrad_now_or_group(lc, dr2, h, [w2], [b2], M, d, 2 * d)
@@ -1077,7 +1107,7 @@ class _LayerTail(torch.autograd.Function):
         dz1, dr1, dgm1, dbe1 = ln_bwd(dt1, dz2, z1, stat1, gm1, be1, seeds[0])
         da = dgrad(dr1, po, wo, d, d)
         (dwo,), (dbo,) = _wgrad_now_or_group(lc, dr1, a, [wo], [bo], M, d, d)
-        return _LayerTail._attn_bwd(ctx, da), dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None, None
+        return (_LayerTail._attn_bwd(ctx, da), dz1, dwo, dbo, dw1, db1, dw2, db2, dgm1, dbe1, dgm2, dbe2, None, None, None, None, None, None) + (nxt_grads if ctx.nxt is not None else ())
 
     @staticmethod
     def _attn_bwd(ctx, da):
@@ -1096,11 +1126,16 @@ class _LayerTail(torch.autograd.Function):
         return dqkv
 
 
-def layer_tail(a, x, lay_params, preps, eps, p, seeds, fork, attn=None):
+def layer_tail(a, x, lay_params, preps, eps, p, seeds, fork, attn=None, nxt=None):
     """a: attention output [M,d], x: layer input [M,d]; lay_params = (Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2);
     preps = LinPrep of (out, linear1, linear2) with fragment-ordered operands; seeds = dropout sites (LN1, GELU, LN2).
     attn = (B, N): `a` is the fused q|k|v projection [M, 3d] instead and the linear attention runs in front of the chain (its
-    phase B inside the chain kernel); the gradient returned for `a` is then dqkv."""
+    phase B inside the chain kernel); the gradient returned for `a` is then dqkv.
+    nxt = ([Wq, Wk, Wv], [bq, bk, bv], LinPrep with .frag) of the NEXT layer: its q|k|v projection runs at the end of this launch
+    and the call returns (y, qkv_next)."""
+    if nxt is not None:
+        (q0, q1, q2), (c0, c1, c2), nprep = nxt
+        return _LayerTail.apply(a, x, *lay_params, preps, eps, p, tuple(seeds), fork, attn, q0, q1, q2, c0, c1, c2, nprep)
     return _LayerTail.apply(a, x, *lay_params, preps, eps, p, tuple(seeds), fork, attn)
 
 

@@ -566,8 +566,9 @@ def test_attn_layer_golden(ops, golden_dir):
         class _S:
             lin = type('D', (dict,), {'__getitem__': lambda self, k: None})()
         _store = _S()
+        _chain_ok = lambda self, *a: False
     xt = x.view(B * N, d)
-    y, _ = MaskTransUnet._layer(_NoStore(), lay, xt, xt, B, N, d, 0.0, _SeedStream(0), last=True)
+    y, _, _ = MaskTransUnet._layer(_NoStore(), lay, xt, xt, B, N, d, 0.0, _SeedStream(0), last=True)
     y.backward(go.view(B * N, d))
     assert rel_err(y.view(B, N, d), torch.from_numpy(Gd['out'])) < 1e-4
     assert rel_err(x.grad, torch.from_numpy(Gd['dx'])) < 5e-4

@@ -33,7 +33,7 @@ def run(M, d):
     u, h = (torch.empty(M, 2 * d, device='cuda', dtype=torch.bfloat16) for _ in range(2))
     s1, s2 = torch.empty(M, 2, device='cuda'), torch.empty(M, 2, device='cuda')
     tail = lambda: _lib.call('ltu_layer_tail_fwd', _p(a), _p(x), _p(fo), _p(f1), _p(f2), _p(bo), _p(b1), _p(b2), _p(g), _p(be), _p(g),
-                             _p(be), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(s1), _p(s2), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, 0, 0, 0, 0, 1, _s())
+                             _p(be), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(s1), _p(s2), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, _s())
     wob, w1b, w2b = wo.bfloat16(), w1.bfloat16(), w2.bfloat16()
     o, f = torch.empty(M, d, device='cuda', dtype=torch.bfloat16), torch.empty(M, d, device='cuda', dtype=torch.bfloat16)
     pa = ops._ptr_array
