@@ -495,7 +495,7 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
 
 // WPS: waves per SIMD the register allocator has to fit (d = 128: 4 = four workgroups per CU at a 128-register budget, which spills
 // 9 registers; 3 = 168 registers, no spills, three workgroups per CU.  d = 256 runs 512-thread workgroups, two per CU: 4)
-template <int D, int UMODE, int WPS>
+template <int D, int UMODE, int WPS, bool PRE_U>
 __global__ void __launch_bounds__(D >= 256 ? 512 : 256, WPS) tail_bwd_kernel(const TailBwdArgs ta) {
   constexpr int LD = D + 8, LDH = 2 * D + 8;
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
@@ -521,14 +521,17 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, WPS) tail_bwd_kernel(con
   tl_layernorm_bwd<D, NTHR, false, false, true, false>(nullptr, nullptr, ta.dy, ta.dy2, ta.z2, ta.stat2, ta.g2, ZB, nullptr, RB, ta.dr2,
                                                       ta.lnws2, red, LD, row0, ta.M, dc2, tid);
   tl_issue<KS1>(ta.w2t, wave, lane, q1);
-  // the thread's 16-byte chunks of the pre-activations u for stage 1b (row-contiguous): in flight across stage 1a
+  // the thread's 16-byte chunks of the pre-activations u for stage 1b (row-contiguous): in flight across stage 1a (d = 128; at
+  // d = 256, where the budget is 128 registers, holding them costs 16 registers = spills: they are fetched in stage 1b instead)
   constexpr int CPR2 = 2 * D / 8, NCH2 = TL_ROWS * CPR2 / NTHR;
-  uint4 uch[NCH2];
+  uint4 uch[PRE_U ? NCH2 : 1];
+  if constexpr (PRE_U) {
 #pragma unroll
-  for (int j = 0; j < NCH2; ++j) {
-    const int i = tid + j * NTHR, r = i / CPR2, c = (i % CPR2) * 8;
-    uch[j] = make_uint4(0u, 0u, 0u, 0u);
-    if (row0 + r < ta.M) uch[j] = *reinterpret_cast<const uint4*>(ta.u + (row0 + r) * (2 * D) + c);
+    for (int j = 0; j < NCH2; ++j) {
+      const int i = tid + j * NTHR, r = i / CPR2, c = (i % CPR2) * 8;
+      uch[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (row0 + r < ta.M) uch[j] = *reinterpret_cast<const uint4*>(ta.u + (row0 + r) * (2 * D) + c);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
@@ -554,7 +557,10 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, WPS) tail_bwd_kernel(con
     const long long rw = row0 + r;
     const uint4 dv = *reinterpret_cast<const uint4*>(UB + r * LDH + c);
     const float4 d0 = unpack_quad(make_uint2(dv.x, dv.y)), d1 = unpack_quad(make_uint2(dv.z, dv.w));
-    const float4 u0 = unpack_quad(make_uint2(uch[j].x, uch[j].y)), u1 = unpack_quad(make_uint2(uch[j].z, uch[j].w));
+    uint4 uv;
+    if constexpr (PRE_U) uv = uch[j];
+    else uv = rw < ta.M ? *reinterpret_cast<const uint4*>(ta.u + rw * (2 * D) + c) : make_uint4(0u, 0u, 0u, 0u);
+    const float4 u0 = unpack_quad(make_uint2(uv.x, uv.y)), u1 = unpack_quad(make_uint2(uv.z, uv.w));
     uint2 a0, a1;
     if constexpr (UMODE == 1) {         // the forward kernel left mask * gelu'(u)
       a0 = pack_quad(d0.x * u0.x, d0.y * u0.y, d0.z * u0.z, d0.w * u0.w);
@@ -629,11 +635,14 @@ extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)s, ta);
   };
   if (d == 256) {
-    if (u_mode) launch(&tail_bwd_kernel<256, 1, 4>, 512); else launch(&tail_bwd_kernel<256, 0, 4>, 512);
+    if (ltu_knob("LTU_TAIL_BWD_PREU", 0)) { if (u_mode) launch(&tail_bwd_kernel<256, 1, 4, true>, 512); else launch(&tail_bwd_kernel<256, 0, 4, true>, 512); }
+    else { if (u_mode) launch(&tail_bwd_kernel<256, 1, 4, false>, 512); else launch(&tail_bwd_kernel<256, 0, 4, false>, 512); }
   } else if (ltu_knob("LTU_TAIL_BWD_WPS", 4) == 3) {
-    if (u_mode) launch(&tail_bwd_kernel<128, 1, 3>, 256); else launch(&tail_bwd_kernel<128, 0, 3>, 256);
+    if (u_mode) launch(&tail_bwd_kernel<128, 1, 3, true>, 256); else launch(&tail_bwd_kernel<128, 0, 3, true>, 256);
+  } else if (ltu_knob("LTU_TAIL_BWD_PREU", 0) == 0) {
+    if (u_mode) launch(&tail_bwd_kernel<128, 1, 4, false>, 256); else launch(&tail_bwd_kernel<128, 0, 4, false>, 256);
   } else {
-    if (u_mode) launch(&tail_bwd_kernel<128, 1, 4>, 256); else launch(&tail_bwd_kernel<128, 0, 4>, 256);
+    if (u_mode) launch(&tail_bwd_kernel<128, 1, 4, true>, 256); else launch(&tail_bwd_kernel<128, 0, 4, true>, 256);
   }
   return ltu_check_launch();
 }

@@ -22,7 +22,7 @@ def run():
     torch.manual_seed(1234)
     model = get_model_dict('MaskTransUnet')([16, 32, 64, 128, 256], [100, 65, 40, 25, 10], [False, True, True, True, True], 1, 2,
                                             dropout=0.3, act_dtype=torch.bfloat16).to(dev).train()
-    reducer = train.GradReducer(model, bucket_mb=16.0, unused=train.UNUSED_PARAMETERS)
+    reducer = train.GradReducer(model, unused=train.UNUSED_PARAMETERS)
     weights = train.get_dynamic_weight(1)[0]
     x, lab = data.synthetic_patches(2, (128, 128, 128), 100, dev)
     for i in range(2 + STEPS):

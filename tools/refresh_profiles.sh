@@ -2,17 +2,21 @@
 # regenerates the files kept under profiles/ for the current round (run from the repo root on the GPU box; outputs land in
 # gpurun_out/ and are copied into profiles/ by hand afterwards):  bash tools/refresh_profiles.sh r02
 set -e
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 python3 bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 bash tools/profile_bench.sh
 {
-  echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3   (MI355X; the trace holds 2 eager steps, 2 capture warm-ups, 13 replays of the step graph and 6 replays of the 64-launch chain-kernel timing graph; per-step figures divide by 18, so the chain kernels read a few per cent high; summary of the rocpd database by tools/prof_summary.py)"
+  echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3   (MI355X; the trace holds 2 eager steps, 2 capture warm-ups, 13 replays of the step graph, 6 replays of the 64-launch chain-kernel timing graph and 6 replays of each family graph of the roofline table; per-step figures divide by 18, so everything reads high by the replayed families - the one-step trace ${R}_step_trace.txt is exact; summary of the rocpd database by tools/prof_summary.py)"
   cat gpurun_out/prof_bench_stats.txt
 } > gpurun_out/${R}_bench_kernel_stats.txt
 cp gpurun_out/prof_bench_stats.csv gpurun_out/${R}_bench_kernel_stats.csv
-bash tools/pmc_step.sh
-cp gpurun_out/r02_pmc_step.json gpurun_out/${R}_pmc_step.json 2>/dev/null || true
+DB=$(find /tmp/prof_bench -name '*.db' | head -1)
+{
+  echo "one replayed step of the same trace (tools/trace_step.py): launches, busy time vs span, per-kernel sums"
+  python3 tools/trace_step.py "$DB"
+} > gpurun_out/${R}_step_trace.txt
+bash tools/pmc_step.sh ${R}
 bash tools/pmc_valu.sh
 cp gpurun_out/pmc_valu.txt gpurun_out/${R}_pmc_valu.txt
 {
