@@ -1,0 +1,105 @@
+"""The data-parallel path on ONE GPU: a live 1-rank RCCL communicator driven through the C-ABI (lintransunet_amd/comm.py ->
+csrc/comm.hip: ltu_comm_load / _unique_id / _init / _allreduce_avg / _broadcast / _destroy), i.e. what every rank does at N > 1
+minus the links.  RCCL's kernels launch and are captured; the mean over one rank is the identity, so gradients must come out
+unchanged - eagerly, from autograd hooks, and replayed from a step graph with the collectives captured as side branches."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import net as O_net          # noqa: E402
+from oracle import seedgen               # noqa: E402
+from oracle import step as O_step        # noqa: E402
+
+DEV = 'cuda'
+SMALL = dict(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
+
+
+@pytest.fixture(scope='module')
+def comm():
+    from lintransunet_amd import comm as C
+    c = C.RcclComm(torch.device('cuda', 0))
+    yield c
+    c.close()
+
+
+def test_allreduce_and_broadcast_one_rank(comm):
+    assert (comm.world, comm.rank) == (1, 0)
+    x = torch.randn(1 << 20, device=DEV)
+    ref = x.clone()
+    n0 = comm.calls
+    comm.allreduce_avg(x).wait()
+    comm.broadcast(x, 0)
+    torch.cuda.synchronize()
+    assert comm.calls == n0 + 1 and torch.equal(x, ref)
+    from lintransunet_amd import _lib
+    with pytest.raises(_lib.LtuError):
+        comm.allreduce_avg(x.cpu())                      # no silent staging through the host
+    with pytest.raises(_lib.LtuError):
+        comm.allreduce_avg(x.bfloat16())
+
+
+def test_captured_allreduce_replays(comm):
+    """the collective is a plain enqueue on the communicator's stream: fork / join are stream dependencies, so a capture takes it
+    as a side branch and replays it"""
+    x = torch.zeros(1 << 16, device=DEV)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x.add_(1.0)
+        comm.allreduce_avg(x).wait()
+    torch.cuda.synchronize()
+    x.zero_()
+    g = torch.cuda.CUDAGraph()
+    n0 = comm.calls
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        x.add_(1.0)
+        comm.allreduce_avg(x).wait()
+        x.mul_(2.0)
+    assert comm.calls == n0 + 1
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    assert comm.calls == n0 + 1                          # nothing is re-issued from the host
+    assert torch.equal(x, torch.full_like(x, 62.0))      # ((((0+1)*2+1)*2+1)*2+1)*2+1)*2
+
+
+def test_graphed_step_with_captured_collectives_matches_plain_step(comm):
+    from lintransunet_amd import train
+    from lintransunet_amd.model import get_model_dict
+    cfg = O_net.NetConfig(**SMALL)
+    x = seedgen.seeded_volume((2, 1, 32, 32, 32), 1).to(DEV)
+    lab = seedgen.seeded_label((2, 1, 32, 32, 32), 2).to(DEV)
+    w = O_step.dynamic_weights(0)
+
+    def build(c):
+        m = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, 2, dropout=0.0,
+                                            act_dtype=torch.bfloat16)      # the bf16 path has no atomics: runs are bit-reproducible
+        m.load_state_dict(seedgen.seeded_params(O_net.param_shapes(cfg), 100), strict=True)
+        m = m.to(DEV).train()
+        red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS, comm=c, force_collectives=c is not None)
+        return m, red
+
+    def whole(m):
+        return torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    m0, r0 = build(None)
+    r0.zero_grad()
+    train.train_step(m0, x, lab, w, reducer=r0)
+    torch.cuda.synchronize()
+    ref = whole(m0)
+    m1, r1 = build(comm)
+    assert len(r1.flat) >= 3 and r1.world == 2
+    n0 = comm.calls
+    step = train.GraphedStep(m1, x, lab, w, r1, overlap='graph')
+    built = comm.calls - n0
+    assert built >= 3 * len(r1.flat)                     # two warm-up steps and the capture each enqueue every bucket once
+    for _ in range(3):
+        step(x, lab)
+    torch.cuda.synchronize()
+    assert comm.calls - n0 == built                      # replays re-issue nothing
+    err = ((whole(m1) - ref).norm() / ref.norm()).item()
+    assert err <= 1e-6, err
+    # eager hook path and after-replay path through the same communicator
+    r1.zero_grad()
+    train.train_step(m1, x, lab, w, reducer=r1)
+    torch.cuda.synchronize()
+    assert ((whole(m1) - ref).norm() / ref.norm()).item() <= 1e-6

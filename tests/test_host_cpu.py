@@ -193,3 +193,23 @@ def test_bench_parent_does_not_import_torch_before_launch():
     assert not re.search(r'^import torch|^from torch', head, flags=re.M)
     body = src[src.index('def main():'):]
     assert body.index('self_launch(args)') < body.index('import torch')
+
+
+def test_comm_surface_without_gpu():
+    """LocalComm is a no-op communicator; the RCCL entry points refuse to work before ltu_comm_load (no compute, no GPU)"""
+    import ctypes
+    from lintransunet_amd import _lib
+    from lintransunet_amd import comm as C
+    c = C.LocalComm()
+    t = torch.ones(4)
+    c.allreduce_avg(t).wait()
+    c.broadcast(t)
+    c.barrier()
+    assert c.max_float(2.5) == 2.5 and torch.equal(t, torch.ones(4))
+    lib = _lib.load()
+    assert lib.ltu_comm_load(None) == -4                       # LTU_E_ARG
+    assert lib.ltu_comm_load(b'/nonexistent/librccl.so') == -100        # LTU_E_COMM: not loadable
+    buf = (ctypes.c_char * 128)()
+    assert lib.ltu_comm_unique_id(ctypes.addressof(buf)) == -100        # not loaded
+    with pytest.raises(RuntimeError):
+        C.GlooComm()                                           # needs an initialised gloo group
