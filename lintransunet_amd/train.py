@@ -216,9 +216,15 @@ class GradReducer:
     def _hook(self, p):
         if not self.active:
             return
-        if p not in self._seen:
-            self._seen.add(p)
-            self.ready_order.append(p)
+        # Each parameter counts ONCE per backward.  A fused parameter reports twice: from its weight-gradient op (`_ltu_hook`, when
+        # the kernels that write the bucket have been enqueued) and from autograd's post-accumulate hook, which PyTorch also fires
+        # when the op returned no gradient for it.  Counting both closed every bucket when half of its gradients were in
+        # (found in round 3 by tools/rehearse_two_ranks.py, the first run with two real ranks: a 1-rank rehearsal cannot see an
+        # all-reduce that comes too early).
+        if p in self._seen:
+            return
+        self._seen.add(p)
+        self.ready_order.append(p)
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.reduce_now:

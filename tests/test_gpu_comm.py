@@ -103,3 +103,77 @@ def test_graphed_step_with_captured_collectives_matches_plain_step(comm):
     train.train_step(m1, x, lab, w, reducer=r1)
     torch.cuda.synchronize()
     assert ((whole(m1) - ref).norm() / ref.norm()).item() <= 1e-6
+
+
+def test_collectives_see_complete_buckets():
+    """WHERE a bucket's collective is issued (eagerly from the gradient hooks, or as a captured side branch): a stand-in communicator
+    snapshots the bucket on its own stream at that point; after the step every snapshot must equal the final bucket, i.e. no gradient
+    of the bucket was written after its all-reduce was forked.  (Round 3: with every fused parameter counted twice the buckets closed
+    half-way - invisible to a 1-rank all-reduce, which is the identity.)"""
+    from lintransunet_amd import train
+    from lintransunet_amd.model import get_model_dict
+
+    class SnapshotComm:
+        world, rank = 2, 0
+
+        def __init__(self):
+            self.stream = torch.cuda.Stream()
+            self.snaps = {}
+
+        def allreduce_avg(self, flat):
+            self.stream.wait_stream(torch.cuda.current_stream())
+            snap = self.snaps.setdefault(flat.data_ptr(), torch.empty_like(flat))
+            with torch.cuda.stream(self.stream):
+                snap.copy_(flat)
+            stream = self.stream
+
+            class H:
+                def wait(self):
+                    torch.cuda.current_stream().wait_stream(stream)
+            return H()
+
+        def broadcast(self, t, src=0):
+            pass
+    cfg = O_net.NetConfig(**SMALL)
+    x = seedgen.seeded_volume((2, 1, 32, 32, 32), 1).to(DEV)
+    lab = seedgen.seeded_label((2, 1, 32, 32, 32), 2).to(DEV)
+    w = O_step.dynamic_weights(0)
+    m = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, 2, dropout=0.0, act_dtype=torch.bfloat16)
+    m.load_state_dict(seedgen.seeded_params(O_net.param_shapes(cfg), 100), strict=True)
+    m = m.to(DEV).train()
+    comm = SnapshotComm()
+    red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS, comm=comm)
+    assert len(red.flat) >= 5
+
+    def check(tag):
+        torch.cuda.synchronize()
+        for bi, f in enumerate(red.flat):
+            assert f.abs().sum().item() > 0
+            assert torch.equal(comm.snaps[f.data_ptr()], f), f'{tag}: bucket {bi} was reduced before its last gradient arrived'
+        assert all(v == 0 for v in red.pending), red.pending          # every parameter counted exactly once
+    red.zero_grad()
+    train.train_step(m, x, lab, w, reducer=red)                        # eager hooks
+    check('hooks')
+    red.rebucket()                                                     # gradient-ready order, as bench.py uses it
+    comm.snaps.clear()
+    red.zero_grad()
+    train.train_step(m, x, lab, w, reducer=red)
+    check('hooks, ready order')
+    comm.snaps.clear()
+    step = train.GraphedStep(m, x, lab, w, red, overlap='graph')      # captured side branches
+    for _ in range(2):
+        for s in comm.snaps.values():
+            s.zero_()
+        step(x, lab)
+        check('captured')
+
+
+def test_two_ranks_on_one_gpu_average_to_the_full_batch_gradient():
+    """tools/rehearse_two_ranks.py: two real data-parallel processes on this GPU (the gradient exchange staged through gloo by a
+    test communicator, RCCL refuses two ranks on one device): ranks end up with identical gradients, and their mean equals the
+    gradient of the full batch of four on one process - for the hook path, the graph + after-replay path and accumulation"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rehearse_two_ranks.py')], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'ok' in r.stdout.splitlines()[-1]

@@ -1,0 +1,133 @@
+"""Two data-parallel ranks end to end on ONE GPU (RCCL refuses two ranks on one device, tools/try_two_ranks_one_gpu.py, so the
+gradient exchange of this rehearsal is a TEST communicator that stages the buckets through the host and gloo; everything else is the
+product path: rendezvous, parameter broadcast, per-rank patches, HIP kernels, gradient hooks in ready order, re-bucketing,
+GraphedStep with the collectives after the replay, accumulation).  Checks the property the data-parallel design rests on
+(SURVEY 8e): every op of the network is per-sample, so mean over ranks of the per-rank gradients == gradient of the full batch.
+
+    python tools/rehearse_two_ranks.py          (parent: spawns rank 0 / 1 on device 0, then compares with a 1-process full-batch run)
+"""
+import os, socket, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'gpurun_out')
+SMALL = dict(num_layers=[8, 8, 8, 16, 32], roi_size_list=[20, 12, 9, 10, 6])
+
+
+def setup(batch, seed0):
+    import torch
+    from lintransunet_amd.model import get_model_dict
+    from oracle import net as O_net, seedgen
+    cfg = O_net.NetConfig(**SMALL)
+    m = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, 2, dropout=0.0, act_dtype=torch.bfloat16)
+    m.load_state_dict(seedgen.seeded_params(O_net.param_shapes(cfg), seed0), strict=True)
+    return m.to('cuda').train()
+
+
+def patches(indices):
+    import torch
+    from oracle import seedgen
+    xs = [seedgen.seeded_volume((1, 1, 32, 32, 32), 500 + i) for i in indices]
+    ls = [seedgen.seeded_label((1, 1, 32, 32, 32), 600 + i) for i in indices]
+    return torch.cat(xs).cuda(), torch.cat(ls).cuda()
+
+
+def whole(m):
+    import torch
+    return torch.cat([p.grad.flatten().float() for p in m.parameters() if p.grad is not None]).cpu()
+
+
+def rank_main():
+    import torch, torch.distributed as dist
+    from lintransunet_amd import train, comm as C
+    from oracle import step as O_step
+    rank = int(os.environ['RANK'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    gloo = C.GlooComm()
+
+    class StagedComm:                       # test-only: GPU bucket -> host -> gloo -> GPU (the product path uses RcclComm)
+        world, rank = gloo.world, gloo.rank
+
+        def allreduce_avg(self, flat):
+            torch.cuda.current_stream().synchronize()
+            h = flat.cpu()
+            gloo.allreduce_avg(h).wait()
+            flat.copy_(h)
+            return C._Done()
+
+        def broadcast(self, t, src=0):
+            h = t.cpu()
+            gloo.broadcast(h, src)
+            t.copy_(h)
+
+        barrier, max_float = gloo.barrier, gloo.max_float
+    comm = StagedComm()
+    m = setup(2, 100 + rank)                # different initial weights per rank: the broadcast must fix that
+    train.broadcast_parameters(m, comm)
+    red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS, comm=comm)
+    assert red.world == 2
+    x, lab = patches([2 * rank, 2 * rank + 1])          # this rank's two patches of the global batch of four
+    w = O_step.dynamic_weights(0)
+    red.zero_grad()
+    train.train_step(m, x, lab, w, reducer=red)         # eager, collectives from the gradient hooks
+    torch.cuda.synchronize()
+    g_hooks = whole(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    per_param = {names[id(p)]: (bi, p.grad.detach().float().cpu().clone()) for bi, b in enumerate(red.buckets) for p in b}
+    red.rebucket()
+    step = train.GraphedStep(m, x, lab, w, red, overlap='after')       # replay + collectives after it
+    step(x, lab)
+    torch.cuda.synchronize()
+    g_graph = whole(m)
+    # accumulation: two micro-steps of one patch each (losses / 2), reduced on the last only
+    step2 = train.GraphedStep(m, x[:1], lab[:1], w, red, step_times=2, overlap='after')
+    for j in range(2):
+        step2(x[j:j + 1], lab[j:j + 1], micro=j)
+    torch.cuda.synchronize()
+    g_acc = whole(m)
+    torch.save({'hooks': g_hooks, 'graph': g_graph, 'acc': g_acc, 'per_param': per_param, 'w0': next(m.parameters()).detach().float().cpu()},
+               os.path.join(OUT, f'two_ranks_{rank}.pt'))
+    tmax = comm.max_float(float(rank))
+    assert tmax == 1.0
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def parent():
+    import torch
+    os.makedirs(OUT, exist_ok=True)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, __file__, 'rank'], env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                                                                          MASTER_PORT=str(port))) for r in range(2)]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [0, 0], rcs
+    from lintransunet_amd import train
+    from oracle import step as O_step
+    r0, r1 = (torch.load(os.path.join(OUT, f'two_ranks_{r}.pt')) for r in range(2))
+    assert torch.equal(r0['w0'], r1['w0'])                                  # broadcast made the ranks identical
+    for k in ('hooks', 'graph', 'acc'):
+        if not torch.equal(r0[k], r1[k]):
+            print(f'{k}: ranks differ, rel-L2 {((r0[k] - r1[k]).norm() / r0[k].norm()).item():.2e}')
+            if k == 'hooks':
+                for n, (bi, g0) in r0['per_param'].items():
+                    g1 = r1['per_param'][n][1]
+                    if not torch.equal(g0, g1):
+                        print(f'   bucket {bi} {n}: rel diff {((g0 - g1).norm() / g0.norm().clamp_min(1e-30)).item():.2e}')
+    for k in ('hooks', 'graph', 'acc'):
+        assert torch.equal(r0[k], r1[k]), k                                  # an all-reduced gradient is the same on every rank
+    m = setup(4, 100)                                                         # rank 0's weights
+    red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS)
+    x, lab = patches([0, 1, 2, 3])
+    red.zero_grad()
+    train.train_step(m, x, lab, O_step.dynamic_weights(0), reducer=red)
+    torch.cuda.synchronize()
+    ref = whole(m)
+    for k in ('hooks', 'graph', 'acc'):
+        err = ((r0[k] - ref).norm() / ref.norm()).item()
+        print(f'mean over 2 ranks ({k:5s}) vs full batch of 4 on one process: whole-gradient rel-L2 {err:.2e}')
+        assert err <= 2e-2, (k, err)           # bf16 storage: batch 2 vs batch 4 launches differ in reduction splits only
+    print('ok')
+
+
+if __name__ == '__main__':
+    rank_main() if len(sys.argv) > 1 and sys.argv[1] == 'rank' else parent()
