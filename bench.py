@@ -135,13 +135,14 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-families', action='store_true', help='skip the per-family timing table of the roofline object')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured HIP graph')
-    ap.add_argument('--allreduce', default=None, choices=['graph', 'after'],
-                    help="gradient all-reduce of the graph-replayed step: captured inside the graph (overlapped, default) or after the replay")
+    ap.add_argument('--allreduce', default=None, choices=['segments', 'graph', 'after'],
+                    help="gradient all-reduce of the graph-replayed step: between linear graph segments (overlapped, default), captured as "
+                         "side branches of one graph, or after the replay")
     ap.add_argument('--rehearse-comm', action='store_true',
                     help='1 GPU only: run the step with a live 1-rank RCCL communicator and the collective path forced on (what every '
                          'rank does at N > 1 minus the link time): prices the captured fork / join edges and RCCL launches')
     ap.add_argument('--bucket-mb', type=float, default=32.0)
-    ap.add_argument('--tail-mb', type=float, default=0.0)
+    ap.add_argument('--tail-mb', type=float, default=0.5)
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU/gloo rehearsal of the launcher, rendezvous, barrier / max-over-ranks timing and the JSON line; no GPU, no model')
     return ap.parse_args(argv)
@@ -364,7 +365,7 @@ def main():
         # ladder: collectives captured inside the step graph (overlapped) -> collectives after the replay -> eager launches.
         # A failed capture must not cost the measurement; every rung runs the same kernels.
         multi = world > 1 or args.rehearse_comm
-        modes = [args.allreduce] if args.allreduce else (['graph', 'after'] if multi else ['graph'])
+        modes = [args.allreduce] if args.allreduce else (['segments', 'graph', 'after'] if multi else ['graph'])
         for mode in modes:
             try:
                 if ft is not None:
@@ -378,8 +379,9 @@ def main():
                 step = lambda i: graphed(*batches[i % 2])
                 launch = 'hip-graph replay'
                 if multi:
-                    allreduce = ('captured in the step graph (side branches, overlapped with backward)' if mode == 'graph'
-                                 else 'after the replay (exposed)')
+                    allreduce = {'segments': 'eager RCCL calls between linear graph segments cut where a bucket closes (overlapped with backward)',
+                                 'graph': 'captured in the step graph (side branches, overlapped with backward)',
+                                 'after': 'after the replay (exposed)'}[mode]
                 break
             except Exception as e:
                 print(f'[bench] rank {rank}: HIP-graph capture with all-reduce mode {mode!r} failed ({type(e).__name__}: {e})',

@@ -118,7 +118,7 @@ class GradReducer:
     With gradient accumulation only the last micro-step reduces (`prepare(reduce=False)` otherwise).
     """
 
-    def __init__(self, model, bucket_mb=32.0, unused=None, comm=None, fused=True, tail_mb=0.0, force_collectives=False):
+    def __init__(self, model, bucket_mb=32.0, unused=None, comm=None, fused=True, tail_mb=0.5, force_collectives=False):
         """comm: a communicator of lintransunet_amd.comm (RcclComm on the GPU, GlooComm on CPU tensors); None = LocalComm, or -
         when torch.distributed is initialised with a gloo group - a GlooComm over the default group"""
         if comm is None:
@@ -133,10 +133,10 @@ class GradReducer:
         named.reverse()
         self.cap = int(bucket_mb * 1024 * 1024 / 4)
         # The gradients that become ready last (the encoder's first layers) close their bucket at the very end of backward, so that
-        # bucket's all-reduce is exposed whatever its size; `tail_mb` > 0 gives the last parameters a bucket of their own (a
-        # latency-sized collective) so that the bulk of the former last bucket starts earlier.  Off by default: on ROCm 7.0 a
-        # captured fork costs 0 - 0.6 ms depending on WHERE in the step graph it lands (profiles/r03_bucket_sweep.txt: 32 MB
-        # buckets = 3 forks are free, the extra fork of a tail bucket costs 0.55 ms - more than the ~0.2 ms it would hide).
+        # bucket's all-reduce is exposed whatever its size: the last `tail_mb` of parameters get a bucket of their own (a
+        # latency-sized collective) and the bulk of the former last bucket starts its all-reduce earlier.  With the step replayed
+        # as linear graph segments (GraphedStep overlap='segments') an extra bucket costs nothing measurable; as a side branch of
+        # ONE graph it cost +0.2 ms (profiles/r03_bucket_sweep.txt).
         self.tail_cap = int(tail_mb * 1024 * 1024 / 4)
         self.fused = fused
         self.ready_order = []           # parameters in the order their gradients became ready in the last backward
@@ -148,6 +148,8 @@ class GradReducer:
         self.active = False
         self.reduce_now = True
         self.ctx = None
+        self.on_bucket = None           # GraphedStep(overlap='segments'): called instead of issuing a completed bucket's collective
+        self.cut, self.cut_rest = [], []
 
     def _assign(self, params):
         """bucket `params` in the given order: flat fp32 buffers of ~cap elements, every .grad a view into its bucket"""
@@ -208,6 +210,7 @@ class GradReducer:
         """arm the hooks for one backward; reduce=False (a non-final accumulation micro-step) only accumulates"""
         self.pending = [len(b) for b in self.buckets]
         self.handles = []
+        self.cut, self.cut_rest = [], []
         self.active = True
         self.ready_order, self._seen = [], set()
         self.reduce_now = bool(reduce) and self.world > 1
@@ -228,9 +231,12 @@ class GradReducer:
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.reduce_now:
-            if os.environ.get('LTU_NO_HOOK_FLUSH') != '1':
-                self.ctx.flush_deferred()       # pending second-stage reductions may still owe this bucket their sums
-            self.handles.append((bi, self._all_reduce(self.flat[bi])))
+            self.ctx.flush_deferred()       # pending second-stage reductions may still owe this bucket their sums
+            if self.on_bucket is not None:
+                self.cut.append(bi)
+                self.on_bucket(bi)
+            else:
+                self.handles.append((bi, self._all_reduce(self.flat[bi])))
 
     def reduce_all(self):
         """all-reduce every bucket now (after a graph replay that did not capture the collectives)"""
@@ -243,9 +249,12 @@ class GradReducer:
         (self.ctx or ops.current()).flush_deferred()      # safety net for callers that ran backward without train_step
         self.active = False
         if self.reduce_now:
-            launched = {bi for bi, _ in self.handles}
-            for bi in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
-                if bi not in launched:
+            launched = {bi for bi, _ in self.handles} | set(self.cut)
+            rest = [bi for bi in range(len(self.buckets)) if bi not in launched]       # buckets holding a parameter that got no gradient
+            if self.on_bucket is not None:
+                self.cut_rest = rest                  # the caller reduces them after its last segment
+            else:
+                for bi in rest:
                     self.handles.append((bi, self._all_reduce(self.flat[bi])))
             for bi, h in self.handles:
                 h.wait()
@@ -259,10 +268,13 @@ class GraphedStep:
 
     * The batch lives in static device buffers (`copy_` new data in); dropout masks stay fresh across replays because the
       kernels mix a device-resident step counter, advanced inside the graph, into their seeds.
-    * all-reduce: `overlap='graph'` (default) captures the bucket collectives inside the graph - RCCL kernels on the
-      communicator's stream become side branches forked where a bucket's last gradient is produced and joined at the end of the step,
-      i.e. overlapped with the rest of backward exactly as in the eager hook path.  `overlap='after'` issues them after the
-      replay (fully exposed; kept as the fallback if a runtime refuses to capture collectives).  LTU_GRAPH_ALLREDUCE overrides.
+    * all-reduce, three ways (LTU_GRAPH_ALLREDUCE overrides):
+      `overlap='segments'` cuts the capture where a bucket's last gradient has been enqueued: the step becomes K + 1 LINEAR graphs
+      (K buckets) replayed back to back on the compute stream, and after segment k the bucket's collective is issued eagerly on the
+      communicator's stream - it runs beside the next segments exactly as in the eager hook path, and no graph contains a fork
+      (on ROCm 7.0 a fork inside a replayed graph costs 0.15 - 1 ms, profiles/r03_bucket_sweep.txt; a linear graph costs nothing);
+      `overlap='graph'` captures the collectives inside ONE graph as side branches (forked where a bucket closes, joined at the end);
+      `overlap='after'` issues them after the replay (fully exposed; the fallback if the other two cannot be captured).
     * accumulation (utils/utils_3D_embed_full.py:85-91, `step_times` micro-steps per optimizer step): `step(x, y, micro=j)`
       zeroes the buckets only for j == 0 and reduces only for j == step_times - 1; each (zero, reduce) combination in use is its
       own captured graph (they share one memory pool).
@@ -280,9 +292,9 @@ class GraphedStep:
         dev = images.device
         self.dev = dev
         self.x, self.lab = images.clone(), labels.clone()
-        self.overlap = overlap or os.environ.get('LTU_GRAPH_ALLREDUCE', 'graph')
-        if self.overlap not in ('graph', 'after'):
-            raise ValueError("overlap must be 'graph' or 'after'")
+        self.overlap = overlap or os.environ.get('LTU_GRAPH_ALLREDUCE', 'segments')
+        if self.overlap not in ('segments', 'graph', 'after'):
+            raise ValueError("overlap must be 'segments', 'graph' or 'after'")
         self.ctx = ops.Context()
         self.counter = torch.zeros(1, device=dev, dtype=torch.int64)
         self.ctx.set_step_counter(self.counter)
@@ -309,7 +321,7 @@ class GraphedStep:
         try:
             return train_step(self.model, self.x, self.lab, self.weights, step_times=self.step_times, specs=self.specs,
                               reducer=self.reducer, ctx=self.ctx, level_scale=self.level_scale,
-                              reduce=reduce and self.overlap == 'graph')
+                              reduce=reduce and self.overlap in ('graph', 'segments'))
         finally:
             self.ctx.wgrad_branch_install(None)
 
@@ -332,16 +344,61 @@ class GraphedStep:
         # Nothing else needs to happen before a capture that contains collectives: the communicator (comm.RcclComm) enqueues
         # RCCL's kernels from this thread through a plain C call, so there is no watchdog or progress thread that could touch an
         # event of the capturing streams (round 2's ProcessGroupNCCL path needed a sleep here and could still abort).
-        graph = torch.cuda.CUDAGraph()
-        # thread-local capture mode: other threads of the process (data loading, logging) may use the HIP runtime meanwhile
-        kw = {} if (self.pool is None or os.environ.get('LTU_GRAPH_SHARE_POOL', '1') == '0') else {'pool': self.pool}
-        with torch.cuda.graph(graph, capture_error_mode='thread_local', **kw):
-            totals, named = self._body(zero, reduce)
-        if self.pool is None:
-            self.pool = graph.pool()
-        self.ctx.freeze()                  # the graph holds addresses inside the scratch arena
-        self.graphs[key] = (graph, totals, named)
+        if self.overlap == 'segments' and reduce and self.reducer.world > 1:
+            segs, totals, named, rest = self._capture_segments(zero, reduce)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            # thread-local capture mode: other threads of the process (data loading, logging) may use the HIP runtime meanwhile
+            kw = {} if (self.pool is None or os.environ.get('LTU_GRAPH_SHARE_POOL', '1') == '0') else {'pool': self.pool}
+            with torch.cuda.graph(graph, capture_error_mode='thread_local', **kw):
+                totals, named = self._body(zero, reduce)
+            if self.pool is None:
+                self.pool = graph.pool()
+            segs, rest = [(graph, None)], []
+        self.ctx.freeze()                  # the graphs hold addresses inside the scratch arena
+        self.graphs[key] = (segs, totals, named, rest)
         self.sig = self._signature()
+
+    def _capture_segments(self, zero, reduce):
+        """the step as a chain of linear graphs, cut at every point where a gradient bucket is complete (see the class docstring).
+        The cut happens inside the reducer's hook, i.e. on autograd's thread in the middle of backward: the capture there is ended
+        and the next one begun on the same stream and memory pool (relaxed capture mode: begin and end may come from different
+        threads; nothing else of this process touches the GPU meanwhile)."""
+        import gc
+        dev, red = self.dev, self.reducer
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        gc.collect()
+        torch.cuda.empty_cache()
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        segs, cur = [], [None]
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=self.pool, capture_error_mode='relaxed')
+
+        def cut(bi):
+            cur[0].capture_end()
+            segs.append((cur[0], bi))
+            begin()
+        with torch.cuda.stream(stream):
+            begin()
+            red.on_bucket = cut
+            try:
+                totals, named = self._body(zero, reduce)
+            except BaseException:
+                try:                       # leave the stream out of capture mode before the error travels on
+                    cur[0].capture_end()
+                except Exception:
+                    pass
+                raise
+            finally:
+                red.on_bucket = None
+            cur[0].capture_end()
+            segs.append((cur[0], None))
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        return segs, totals, named, list(red.cut_rest)
 
     def __call__(self, images=None, labels=None, micro=0):
         """replay micro-step `micro` (0 .. step_times-1) of an optimizer step on a new batch"""
@@ -359,8 +416,16 @@ class GraphedStep:
         if images is not None:
             self.x.copy_(images, non_blocking=True)
             self.lab.copy_(labels, non_blocking=True)
-        graph, totals, named = self.graphs[key]
-        graph.replay()
+        segs, totals, named, rest = self.graphs[key]
+        handles = []
+        for graph, bi in segs:
+            graph.replay()
+            if bi is not None:             # this segment completed bucket bi: its all-reduce runs beside the next segments
+                handles.append(self.reducer._all_reduce(self.reducer.flat[bi]))
+        for bi in rest:
+            handles.append(self.reducer._all_reduce(self.reducer.flat[bi]))
+        for h in handles:
+            h.wait()
         if key[1] and self.overlap == 'after':
             self.reducer.reduce_all()
         self.totals, self.named = totals, named

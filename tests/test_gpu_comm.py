@@ -98,6 +98,14 @@ def test_graphed_step_with_captured_collectives_matches_plain_step(comm):
     assert comm.calls - n0 == built                      # replays re-issue nothing
     err = ((whole(m1) - ref).norm() / ref.norm()).item()
     assert err <= 1e-6, err
+    # the same step as linear segments with eager collectives in between
+    seg = train.GraphedStep(m1, x, lab, w, r1, overlap='segments')
+    n1 = comm.calls
+    for _ in range(2):
+        seg(x, lab)
+    torch.cuda.synchronize()
+    assert comm.calls - n1 == 2 * len(r1.flat)
+    assert ((whole(m1) - ref).norm() / ref.norm()).item() <= 1e-6
     # eager hook path and after-replay path through the same communicator
     r1.zero_grad()
     train.train_step(m1, x, lab, w, reducer=r1)
@@ -159,13 +167,16 @@ def test_collectives_see_complete_buckets():
     red.zero_grad()
     train.train_step(m, x, lab, w, reducer=red)
     check('hooks, ready order')
-    comm.snaps.clear()
-    step = train.GraphedStep(m, x, lab, w, red, overlap='graph')      # captured side branches
-    for _ in range(2):
-        for s in comm.snaps.values():
-            s.zero_()
-        step(x, lab)
-        check('captured')
+    for mode in ('graph', 'segments'):                                 # captured side branches; linear segments + eager collectives
+        comm.snaps.clear()
+        step = train.GraphedStep(m, x, lab, w, red, overlap=mode)
+        if mode == 'segments':
+            assert len(step.graphs[(True, True)][0]) == len(red.flat) + 1 or len(step.graphs[(True, True)][0]) == len(red.flat)
+        for _ in range(2):
+            for s in comm.snaps.values():
+                s.zero_()
+            step(x, lab)
+            check(mode)
 
 
 def test_two_ranks_on_one_gpu_average_to_the_full_batch_gradient():

@@ -1,5 +1,6 @@
 """Rehearsal of bench.py's multi-GPU code path on ONE GPU with a live 1-rank RCCL communicator driven through the C-ABI
 (lintransunet_amd/comm.py: RcclComm -> ltu_comm_init / ltu_comm_allreduce_avg; what every rank does at N > 1):
+  0. GraphedStep(overlap='segments'): the step as linear graph segments cut where a bucket closes, collectives issued eagerly between them;
   1. GraphedStep(overlap='graph'): the bucket all-reduces are CAPTURED inside the step graph (side branches on the communicator's
      stream, forked where a bucket's last gradient is produced);
   2. GraphedStep(overlap='after'): the collectives are issued after the replay (`reduce_all`);
@@ -45,7 +46,7 @@ x = seedgen.seeded_volume((2, 1, 32, 32, 32), 1).to(dev)
 lab = seedgen.seeded_label((2, 1, 32, 32, 32), 2).to(dev)
 w = O_step.dynamic_weights(0)
 results = {}
-for mode in ('graph', 'after', 'none'):
+for mode in ('segments', 'graph', 'after', 'none'):
     m, red = build(mode != 'none')
     n0 = comm.calls
     step = train.GraphedStep(m, x, lab, w, red, overlap='after' if mode == 'none' else mode)
@@ -67,6 +68,8 @@ for mode in ('graph', 'after', 'none'):
     if mode == 'graph':
         assert per == 0, 'captured collectives must not be re-issued from the host'
         assert built >= 3 * len(red.flat)
+    elif mode == 'segments':
+        assert per == len(red.flat) and len(step.graphs[(True, True)][0]) >= 2        # eager collectives between linear segments
     elif mode == 'after':
         assert per == len(red.flat)
 m, red = build()
@@ -84,7 +87,7 @@ step(x, lab)
 torch.cuda.synchronize()
 tot_after = sum(f.double().sum().item() for f in red.flat)
 assert abs(tot_after - tot_before) <= 1e-3 * abs(tot_before) + 1e-6, (tot_before, tot_after)
-for mode in ('after', 'eager', 'none'):
+for mode in ('segments', 'after', 'eager', 'none'):
     worst = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(results['graph'], results[mode]))
     print(f'gradients graph vs {mode}: whole-gradient rel-L2 {worst:.2e}')
     assert worst < (5e-2 if DT == torch.bfloat16 else 1e-4)
