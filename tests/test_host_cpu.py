@@ -238,7 +238,7 @@ def test_reducer_counts_each_parameter_once():
             pass
     net = torch.nn.Sequential(*[torch.nn.Linear(4, 4) for _ in range(6)])
     comm = FakeComm()
-    red = GradReducer(net, bucket_mb=0.0001, comm=comm)          # 40 floats per bucket: two layers each
+    red = GradReducer(net, bucket_mb=0.0001, comm=comm, tail_mb=0.0)          # 40 floats per bucket: two layers each
     assert len(red.buckets) == 3
     reported = set()
     red.zero_grad()
@@ -250,6 +250,7 @@ def test_reducer_counts_each_parameter_once():
             red._hook(p)              # ... and the post-accumulate hook
     red.finish()
     assert len(comm.log) == 3
+    assert all(v == 0 for v in red.pending)
     for (ptr, seen), b, flat in zip(comm.log, red.buckets, red.flat):
         assert ptr == flat.data_ptr() and all(id(p) in seen for p in b)
     # the real thing: a custom Function that writes the gradient itself and returns None still triggers the post-accumulate hook
