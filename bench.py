@@ -141,6 +141,9 @@ def parse_args(argv=None):
     ap.add_argument('--rehearse-comm', action='store_true',
                     help='1 GPU only: run the step with a live 1-rank RCCL communicator and the collective path forced on (what every '
                          'rank does at N > 1 minus the link time): prices the captured fork / join edges and RCCL launches')
+    ap.add_argument('--test-comm', default=None, choices=['staged'],
+                    help='rehearsal only: several ranks on ONE GPU with the gradient exchange staged through the host and gloo (RCCL refuses '
+                         'two ranks per device); exercises launcher, rendezvous, broadcast, hooks, segments and the JSON line - not a measurement')
     ap.add_argument('--bucket-mb', type=float, default=32.0)
     ap.add_argument('--tail-mb', type=float, default=0.5)
     ap.add_argument('--dry-run', action='store_true',
@@ -192,6 +195,13 @@ def self_launch(args):
     return rc
 
 
+def quiet_stdout():
+    """gloo and RCCL print connection / version banners to stdout (file descriptor 1) from C++; the benchmark's stdout carries exactly
+    ONE JSON line, so they are sent to stderr while the process group and the communicator come up"""
+    from lintransunet_amd.comm import _stdout_to_stderr
+    return _stdout_to_stderr()
+
+
 def dry_run(args, rank, world):
     """the multi-process plumbing of main() on the CPU: gloo rendezvous, barrier-bracketed timed region, MAX over ranks, one line"""
     import torch
@@ -199,7 +209,9 @@ def dry_run(args, rank, world):
     if os.environ.get('LTU_BENCH_FAIL_RANK') == str(rank):       # test hook: a rank that dies before the rendezvous
         raise RuntimeError('simulated rank failure')
     if world > 1:
-        dist.init_process_group('gloo')
+        with quiet_stdout():
+            dist.init_process_group('gloo')
+            dist.barrier()
     buf = torch.zeros(1 << 16)
     for _ in range(args.warmup):
         if world > 1:
@@ -240,6 +252,8 @@ def main():
         print(f'[bench] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: using {world} ranks', file=sys.stderr)
     if args.dry_run:
         return dry_run(args, rank, world)
+    if args.test_comm:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     from lintransunet_amd.model import get_model_dict
@@ -250,8 +264,10 @@ def main():
     if world > 1:
         # host control plane (unique id, barriers, max over ranks): gloo on 127.0.0.1; gradient exchange: direct RCCL calls behind
         # the C-ABI (lintransunet_amd/comm.py) - no ProcessGroupNCCL, hence no watchdog thread next to the graph captures
-        dist.init_process_group('gloo')
-        comm = C.RcclComm(dev, control=C.GlooComm())
+        with quiet_stdout():
+            dist.init_process_group('gloo')
+            dist.barrier()                  # gloo connects lazily: its banner comes with the first collective
+            comm = C.HostStagedComm(C.GlooComm()) if args.test_comm else C.RcclComm(dev, control=C.GlooComm())
     elif args.rehearse_comm:
         comm = C.RcclComm(dev)
 
@@ -427,7 +443,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights' + (', 3 labels (multi-class losses)' if args.classes == 3 else ''), 'global_batch': args.batch * world,
-                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch, 'allreduce': allreduce},
+                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch,
+                       'allreduce': allreduce + (' [REHEARSAL: host-staged test communicator, ranks share one GPU - not a measurement]' if args.test_comm else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'tail_fwd_kernel + tail_bwd_kernel (row-block chain kernels: post-attention half of every transformer layer - with the next layer\'s q|k|v projection where the layers are adjacent - forward and backward)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': n_lin, 'avg_launch_ms': ms_lin / max(n_lin, 1),

@@ -92,6 +92,39 @@ class GlooComm:
         pass
 
 
+class HostStagedComm:
+    """TEST communicator: a GPU bucket travels host -> gloo -> host -> GPU.  It exists for rehearsals of the multi-rank code paths
+    with several processes on ONE GPU, where RCCL refuses a second rank per device (tools/rehearse_two_ranks.py,
+    `bench.py --test-comm staged`); it synchronises the stream and is never selected by the product path."""
+
+    def __init__(self, control):
+        self.control = control
+        self.world, self.rank = control.world, control.rank
+        self.calls = 0
+
+    def allreduce_avg(self, flat):
+        torch.cuda.current_stream().synchronize()
+        h = flat.cpu()
+        self.control.allreduce_avg(h).wait()
+        flat.copy_(h)
+        self.calls += 1
+        return _Done()
+
+    def broadcast(self, t, src=0):
+        h = t.cpu()
+        self.control.broadcast(h, src)
+        t.copy_(h)
+
+    def barrier(self):
+        self.control.barrier()
+
+    def max_float(self, x):
+        return self.control.max_float(x)
+
+    def close(self):
+        pass
+
+
 class _StreamHandle:
     def __init__(self, stream):
         self.stream = stream

@@ -365,6 +365,7 @@ class GraphedStep:
         and the next one begun on the same stream and memory pool (relaxed capture mode: begin and end may come from different
         threads; nothing else of this process touches the GPU meanwhile)."""
         import gc
+        import warnings
         dev, red = self.dev, self.reducer
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
@@ -378,8 +379,13 @@ class GraphedStep:
             cur[0] = torch.cuda.CUDAGraph()
             cur[0].capture_begin(pool=self.pool, capture_error_mode='relaxed')
 
+        def end():
+            with warnings.catch_warnings():          # a segment may be empty (two buckets closing at the same point, or nothing
+                warnings.simplefilter('ignore')      # left after the last one): torch warns about empty graphs
+                cur[0].capture_end()
+
         def cut(bi):
-            cur[0].capture_end()
+            end()
             segs.append((cur[0], bi))
             begin()
         with torch.cuda.stream(stream):
@@ -395,7 +401,7 @@ class GraphedStep:
                 raise
             finally:
                 red.on_bucket = None
-            cur[0].capture_end()
+            end()
             segs.append((cur[0], None))
         torch.cuda.current_stream(dev).wait_stream(stream)
         return segs, totals, named, list(red.cut_rest)

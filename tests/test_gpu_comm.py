@@ -188,3 +188,20 @@ def test_two_ranks_on_one_gpu_average_to_the_full_batch_gradient():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rehearse_two_ranks.py')], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'ok' in r.stdout.splitlines()[-1]
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --test-comm staged`: the driver-facing multi-GPU flow (self-launch, gloo rendezvous, parameter
+    broadcast, gradient hooks, re-bucketing, the step as graph segments with the collectives between them, barrier / max-over-ranks
+    timing, ONE JSON line from rank 0) with two processes sharing this GPU and the exchange staged through the host"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--test-comm', 'staged', '--size', '32', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-families'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
+    assert out['config']['launch'] == 'hip-graph replay' and 'segments' in out['config']['allreduce']

@@ -175,6 +175,7 @@ def test_bench_self_launch_dry_run_world2():
     assert r.returncode == 0, r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout          # nothing else on stdout (gloo's connection banner goes to stderr)
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
     assert out['config']['parallelism'] == 'dp2'

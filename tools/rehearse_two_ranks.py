@@ -45,23 +45,7 @@ def rank_main():
     dist.init_process_group('gloo')
     gloo = C.GlooComm()
 
-    class StagedComm:                       # test-only: GPU bucket -> host -> gloo -> GPU (the product path uses RcclComm)
-        world, rank = gloo.world, gloo.rank
-
-        def allreduce_avg(self, flat):
-            torch.cuda.current_stream().synchronize()
-            h = flat.cpu()
-            gloo.allreduce_avg(h).wait()
-            flat.copy_(h)
-            return C._Done()
-
-        def broadcast(self, t, src=0):
-            h = t.cpu()
-            gloo.broadcast(h, src)
-            t.copy_(h)
-
-        barrier, max_float = gloo.barrier, gloo.max_float
-    comm = StagedComm()
+    comm = C.HostStagedComm(gloo)           # test-only: GPU bucket -> host -> gloo -> GPU (the product path uses RcclComm)
     m = setup(2, 100 + rank)                # different initial weights per rank: the broadcast must fix that
     train.broadcast_parameters(m, comm)
     red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS, comm=comm)
