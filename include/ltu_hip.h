@@ -49,6 +49,15 @@ int ltu_config_set(const char* name, int value, int clear);
  * multiple of 64.  Exists because the permlane-swap builtins of hipcc 7.2 miscompile (tests/test_gpu_ops.py keeps the inline-asm
  * replacement honest on the hardware). */
 int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, int n, int G, ltu_stream_t s);
+/* Self-test and price of an in-launch "last arriver" fold against the two-stage form the step uses (per-workgroup partial rows + a
+ * second small launch): nwg workgroups with uneven load (workgroup i sums 1 + (7 i mod skew) chunks of rows_per_chunk rows of x
+ * [rows][n], n <= 256) publish one partial row each; mode 0 folds them with a second launch, mode 1 inside the launch (write-through
+ * partials, agent-scope ticket, one acquire by the last arriver: the guide's hand-off recipe R1).  Both fold in the same fixed
+ * order, so `out` [n] must be bit-identical.  part: nwg * n floats (pre-read by every workgroup: an L1-warm consumer), counter: one
+ * zeroed word (left zero by the last arriver), sink: nwg floats (never written for finite data).  tests/test_gpu_ops.py runs 10^4
+ * launches of it in one process; tools/bench_last_arriver.py times both forms. */
+int ltu_selftest_last_arriver(const float* x, float* part, float* out, unsigned* counter, float* sink, int nwg, int n,
+                              int rows_per_chunk, int skew, int mode, ltu_stream_t s);
 
 /* ---- window embedding: model/Unet_3Dblock.py:123-136 ------------------------------------------
  * x f32 [B,1,H,W,D] (reference layout) -> y T [B,H/2,W/2,D,8]; channel kh*2+kw, channels 4..7 = 0

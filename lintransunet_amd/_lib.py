@@ -30,6 +30,7 @@ SIGNATURES = {
     'ltu_version': [],
     'ltu_config_set': [ctypes.c_char_p, I, I],
     'ltu_selftest_group_reduce': [P, P, P, I, I, P],
+    'ltu_selftest_last_arriver': [P, P, P, P, P, I, I, I, I, I, P],
     'ltu_window_embed': [P, P, I, I, I, I, I, P],
     'ltu_pack_conv_weight': [P, P, P, I, I, I, I, I, P],
     'ltu_unpack_conv_wgrad': [P, P, I, I, I, P],

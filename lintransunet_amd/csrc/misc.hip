@@ -32,6 +32,74 @@ extern "C" int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, 
   return ltu_check_launch();
 }
 
+// ---- last-arriver fold: self-test and price of the in-launch second stage (finding 15) -----------------------
+// The step folds ~100 sets of per-workgroup partial sums with a second small launch each.  The alternative keeps the fold inside
+// the producing launch: every workgroup publishes its partial row, takes a ticket, and the workgroup whose ticket is the last
+// one folds all rows.  The hand-off follows the guide's recipe R1 (cdna_hip_programming.md, Guideline 16): payload stored
+// write-through (sc1), every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to the
+// agent-scope counter; the last arriver issues ONE agent-scope acquire (its L1 may hold stale copies of the partial lines),
+// waits for the invalidate, meets its other waves at a barrier, then reads with plain loads in a FIXED order (bit-reproducible).
+// The self-test makes the consumer's L1 warm on purpose (every workgroup pre-reads the partial lines of the previous launch
+// before it works) and the load uneven (workgroup i sums 1 + (7 i mod skew) row chunks).  mode 0: two-stage reference (this
+// launch writes partials, ltu_selftest_fold sums them); mode 1: last-arriver fold inside the launch.
+typedef __attribute__((address_space(1))) unsigned int gu32_t;
+__global__ void __launch_bounds__(256) selftest_partials_kernel(const float* __restrict__ x, float* __restrict__ part, float* __restrict__ out,
+                                                                unsigned* counter, float* __restrict__ sink, int n, int rows_per_chunk,
+                                                                int skew, int mode) {
+  __shared__ int s_last;
+  const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+  // L1-warm consumer: plain loads of the partial rows as the PREVIOUS launch left them (every workgroup: any of them may be last)
+  float warm = 0.f;
+  for (int i = tid; i < nwg * n; i += 256 * 8) warm += part[i];
+  // uneven work: chunks [c0, c0 + cnt) of x, column t summed by thread t
+  const int cnt = 1 + (7 * wg) % skew;
+  long long c0 = 0;
+  for (int i = 0; i < wg; ++i) c0 += 1 + (7 * i) % skew;
+  float acc = 0.f;
+  if (tid < n)
+    for (long long r = c0 * rows_per_chunk; r < (c0 + cnt) * rows_per_chunk; ++r) acc += x[r * n + tid];
+  if (warm == 12345.678f) sink[wg] = warm;                   // keeps the pre-reads alive, never true for the test data
+  if (mode == 0) {
+    if (tid < n) part[(long long)wg * n + tid] = acc;
+    return;
+  }
+  if (tid < n) __hip_atomic_store(part + (long long)wg * n + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == (unsigned)nwg - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drops this CU's stale L1 lines
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // holds the barrier below until the invalidate has completed
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid < n) {
+    float v = 0.f;
+    for (int i = 0; i < nwg; ++i) v += part[(long long)i * n + tid];      // fixed order: the same bits as the two-stage fold
+    out[tid] = v;
+  }
+  if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+}
+__global__ void __launch_bounds__(256) selftest_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int nwg, int n) {
+  const int tid = threadIdx.x;
+  if (tid >= n) return;
+  float v = 0.f;
+  for (int i = 0; i < nwg; ++i) v += part[(long long)i * n + tid];
+  out[tid] = v;
+}
+// x: [sum_i (1 + 7 i mod skew)] * rows_per_chunk rows of n <= 256 floats; part: nwg * n floats; counter: one zeroed word (mode 1)
+extern "C" int ltu_selftest_last_arriver(const float* x, float* part, float* out, unsigned* counter, float* sink, int nwg, int n,
+                                         int rows_per_chunk, int skew, int mode, ltu_stream_t s) {
+  if (nwg <= 0 || n <= 0 || n > 256 || rows_per_chunk <= 0 || skew <= 0 || (mode != 0 && mode != 1)) return LTU_E_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(selftest_partials_kernel, dim3(nwg), dim3(256), 0, st, x, part, out, counter, sink, n, rows_per_chunk, skew, mode);
+  if (mode == 0) hipLaunchKernelGGL(selftest_fold_kernel, dim3(1), dim3(256), 0, st, part, out, nwg, n);
+  return ltu_check_launch();
+}
+
 // ---- knob overrides (ltu_config_set): a small table under a mutex; see common.h ------------------------------------------
 namespace {
 struct KnobOverride { char name[40]; int value; };

@@ -813,3 +813,37 @@ def test_group_reduce_selftest(G):
     ref_m = x.view(-1, G).max(1, keepdim=True).values.expand(-1, G).reshape(-1)
     assert torch.allclose(s, ref_s, rtol=1e-5, atol=1e-5)
     assert torch.equal(m, ref_m)
+
+
+@pytest.mark.parametrize('nwg,n,skew', [(512, 128, 5), (1024, 32, 3), (256, 256, 7), (777, 64, 4)])
+def test_last_arriver_reduce(nwg, n, skew):
+    """the in-launch 'last arriver' fold (csrc/misc.hip: write-through partial rows, agent-scope ticket, one acquire by the last
+    workgroup - the guide's hand-off recipe R1) against the two-stage fold the step uses: uneven per-workgroup load, an L1-warm
+    consumer (every workgroup pre-reads the previous launch's partial rows), 2-4 workgroups per CU, 10^4 launches in ONE process on
+    alternating data, every output word compared bit for bit.  (VERDICT round 2, item 6.  The reducer is correct here; it is still
+    not used in the step because it does not pay: tools/bench_last_arriver.py, DESIGN.md section 5 finding 15.)"""
+    from lintransunet_amd import _lib
+    from lintransunet_amd.ops import _p, _s
+    rpc = 4
+    rows = sum(1 + (7 * i) % skew for i in range(nwg)) * rpc
+    g = G(77)
+    xs = [torch.randn(rows, n, generator=g).to(DEV) * (1 + k) for k in range(2)]
+    part = torch.zeros(nwg * n, device=DEV)
+    sink = torch.zeros(nwg, device=DEV)
+    counter = torch.zeros(1, device=DEV, dtype=torch.int32)
+    refs = []
+    for x in xs:                                         # two-stage reference
+        out = torch.empty(n, device=DEV)
+        _lib.call('ltu_selftest_last_arriver', _p(x), _p(part), _p(out), _p(counter), _p(sink), nwg, n, rpc, skew, 0, _s())
+        refs.append(out)
+        # and the plain sum, to make sure the reference itself means something
+        assert torch.allclose(out.cpu(), x.double().sum(0).float().cpu(), rtol=1e-3, atol=1e-2)
+    assert not torch.equal(refs[0], refs[1])
+    out = torch.empty(n, device=DEV)
+    bad = torch.zeros((), device=DEV, dtype=torch.int64)
+    for k in range(10000):
+        _lib.call('ltu_selftest_last_arriver', _p(xs[k & 1]), _p(part), _p(out), _p(counter), _p(sink), nwg, n, rpc, skew, 1, _s())
+        bad += (out != refs[k & 1]).sum()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f'{int(bad.item())} stale / wrong output words in 10^4 launches'
+    assert int(counter.item()) == 0 and float(sink.abs().sum().item()) == 0.0
