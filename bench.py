@@ -7,7 +7,8 @@
 
 One process per GPU, weak scaling (2 patches per GPU, BASELINE.json config 3): every rank draws its own
 synthetic patches, gradients are all-reduced (mean) over RCCL in buckets overlapped with backward (direct RCCL calls behind the
-C-ABI, captured as side branches of the step's HIP graph; the host control plane - rendezvous, barriers, max over ranks - is gloo).  A "step" is one inner training step of
+C-ABI, issued between the linear graph segments the step is replayed as; the host control plane - rendezvous, barriers, max over
+ranks - is gloo).  A "step" is one inner training step of
 utils/utils_3D_embed_full.py:55-86 (dropout 0.3 as in training, no optimizer step, inputs resident in HBM).
 Rank 0 prints ONE JSON line.
 
@@ -378,7 +379,8 @@ def main():
     allreduce = 'hooks (overlapped with backward)' if (world > 1 or args.rehearse_comm) else 'none (1 rank)'
     step = eager_step
     if not args.no_graph:
-        # ladder: collectives captured inside the step graph (overlapped) -> collectives after the replay -> eager launches.
+        # ladder: step as linear graph segments with the collectives between them (overlapped) -> collectives captured as side branches of
+        # one graph -> collectives after the replay -> eager launches.
         # A failed capture must not cost the measurement; every rung runs the same kernels.
         multi = world > 1 or args.rehearse_comm
         modes = [args.allreduce] if args.allreduce else (['segments', 'graph', 'after'] if multi else ['graph'])

@@ -109,11 +109,10 @@ class GradReducer:
 
     Parameters are bucketed in reverse registration order (decoder tail first = the order in which
     backward produces gradients).  Each parameter's `.grad` is a view into its bucket's flat buffer; a
-    post-accumulate hook counts arrivals and launches `all_reduce(async_op=True)` when a bucket is full, so the
-    collective of one bucket runs while backward produces the next.  Inside a captured step (GraphedStep) the same
-    calls are captured: each bucket's RCCL kernel becomes a side branch of the HIP graph, forked where the bucket's
-    last gradient is produced and joined at the end of the step (comm.RcclComm: the RCCL kernel is enqueued on the
-    communicator's stream by a plain C call; no process-group thread takes part).
+    hook counts arrivals (each parameter once) and issues the bucket's all-reduce when it is full, so the collective of one bucket
+    runs while backward produces the next (comm.RcclComm: the RCCL kernel is enqueued on the communicator's stream by a plain C
+    call; no process-group thread takes part).  GraphedStep replays the step as linear graph segments cut at exactly those points
+    and issues the collectives between them (or captures them as side branches of one graph, or issues them after the replay).
     Parameters that never receive a gradient (the 14 unused pos_encoders tensors) are left out.
     With gradient accumulation only the last micro-step reduces (`prepare(reduce=False)` otherwise).
     """
