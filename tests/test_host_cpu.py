@@ -272,3 +272,44 @@ def test_reducer_counts_each_parameter_once():
     w.register_post_accumulate_grad_hook(lambda p: calls.append('post_accumulate'))
     F.apply(torch.ones(3, requires_grad=True), w).sum().backward()
     assert calls in (['op', 'post_accumulate'], ['op'])          # torch 2.10: both - the behaviour the reducer has to be robust against
+
+
+def test_reducer_tail_bucket_plan():
+    """multi-rank bucket plan: buckets of ~bucket_mb in the given order, and the last `tail_mb` of parameters (the gradients that
+    arrive last) in a latency-sized bucket of their own; every parameter exactly once, order preserved, also after rebucket()"""
+    from lintransunet_amd.train import GradReducer
+
+    class FakeComm:
+        world, rank = 2, 0
+
+        def allreduce_avg(self, flat):
+            class H:
+                def wait(self):
+                    pass
+            return H()
+    net = torch.nn.Sequential(*[torch.nn.Linear(16, 16) for _ in range(8)])          # 8 x (256 + 16) parameters
+    red = GradReducer(net, bucket_mb=1024 * 4 / 2 ** 20, tail_mb=300 * 4 / 2 ** 20, comm=FakeComm())      # 1 024-float buckets, 300-float tail
+    order = [p for _, p in reversed(list(net.named_parameters()))]
+    flat_order = [p for b in red.buckets for p in b]
+    assert len(flat_order) == len(order) and all(a is b for a, b in zip(flat_order, order))
+    sizes = [sum(p.numel() for p in b) for b in red.buckets]
+    assert sizes[-1] <= 300 and len(red.buckets[-1]) >= 1 and all(s >= 1024 for s in sizes[:-2])
+    assert sum(sizes) == sum(p.numel() for p in net.parameters())
+    for b, f in zip(red.buckets, red.flat):
+        assert f.numel() == sum(p.numel() for p in b)
+        assert all(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for p in b)
+    # a 1-rank reducer keeps the plain plan (no tail bucket)
+    red1 = GradReducer(torch.nn.Sequential(*[torch.nn.Linear(16, 16) for _ in range(8)]), bucket_mb=1024 * 4 / 2 ** 20, tail_mb=300 * 4 / 2 ** 20)
+    assert sum(p.numel() for p in red1.buckets[-1]) > 300
+    # ready order recorded by a backward, then re-bucketing keeps the invariants and bumps the generation
+    gen = red.generation
+    red.zero_grad()
+    red.prepare()
+    x = torch.randn(4, 16)
+    net(x).sum().backward()
+    red.finish()
+    assert all(v == 0 for v in red.pending)
+    red.rebucket()
+    assert red.generation == gen + 1
+    assert sorted(id(p) for b in red.buckets for p in b) == sorted(id(p) for p in net.parameters())
+    assert red.buckets[0][0] is net[7].bias or red.buckets[0][0] is net[7].weight          # the last layer's gradients arrive first
