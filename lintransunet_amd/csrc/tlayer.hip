@@ -75,24 +75,24 @@ __device__ __forceinline__ tl_bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_c
 // gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued after a store cannot be waited for without also
 // waiting for the store's acknowledgement - and drained by tl_run.  Every step is fenced with sched_barrier: left alone, hipcc
 // sinks each weight load next to its MFMA (one load in flight per wave, an L2 round trip per MFMA).
-template <int KS>
+template <int KS, int QD = TL_QDEPTH>
 struct TlQueue {
-  static constexpr int U = KS < TL_QDEPTH ? KS : TL_QDEPTH;
+  static constexpr int U = KS < QD ? KS : QD;
   uint4 q[U];
 };
 
-template <int KS>
-__device__ __forceinline__ void tl_issue(const uint16_t* __restrict__ W, int ct, int lane, TlQueue<KS>& wq) {
+template <int KS, int QD = TL_QDEPTH>
+__device__ __forceinline__ void tl_issue(const uint16_t* __restrict__ W, int ct, int lane, TlQueue<KS, QD>& wq) {
   const uint4* wp = reinterpret_cast<const uint4*>(W) + (size_t)ct * KS * 64 + lane;
 #pragma unroll
-  for (int i = 0; i < TlQueue<KS>::U; ++i) wq.q[i] = wp[(size_t)i * 64];
+  for (int i = 0; i < TlQueue<KS, QD>::U; ++i) wq.q[i] = wp[(size_t)i * 64];
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int KS>
-__device__ __forceinline__ void tl_run(const uint16_t* __restrict__ W, int ct, const uint16_t* Xl, int LDX, int lane, TlQueue<KS>& wq,
+template <int KS, int QD = TL_QDEPTH>
+__device__ __forceinline__ void tl_run(const uint16_t* __restrict__ W, int ct, const uint16_t* Xl, int LDX, int lane, TlQueue<KS, QD>& wq,
                                        f32x16& acc) {
-  constexpr int U = TlQueue<KS>::U;
+  constexpr int U = TlQueue<KS, QD>::U;
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -159,8 +159,17 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
   }
 }
 
-template <int D, bool ATTN, bool QKV>
-__global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const TailArgs ta) {
+// OCC = waves per SIMD the kernel is built for.  5 (d = 128 only, no q|k|v stage): the "slim" layout - TB shares HB's memory (the
+// out-projection result is dead before u is written; the linear2 result is written after a barrier behind the last read of h), the
+// residual rows x are read from global memory in LayerNorm 1 instead of waiting in LDS, and the weight queue is 6 deep: 30.7 KB of
+// LDS and <= 96 registers = five workgroups per CU instead of four.  Measured (round 3): 91-93 us either way at 114 816 x 128 and
+// +0.07 ms per step - the kernel is instruction-issue-bound, a fifth wave per SIMD has nothing to hide.  Kept behind
+// LTU_TAIL_FWD_OCC=5, off by default.
+template <int D, bool ATTN, bool QKV, int OCC>
+__global__ void __launch_bounds__(D >= 256 ? 512 : 256, OCC) tail_fwd_kernel(const TailArgs ta) {
+  constexpr bool SLIM = OCC >= 5;
+  constexpr int QD = SLIM ? 6 : TL_QDEPTH;
+  static_assert(!SLIM || (D == 128 && !QKV), "the slim layout exists for d = 128 without the fused q|k|v stage");
   constexpr int LD = D + 8, LDH = 2 * D + 8;          // padded rows: +16 bytes rotates the banks from row to row
   constexpr int NW = D >= 256 ? 8 : 4, NTHR = NW * 64;
   constexpr int NT1 = D / 32, NT2 = 2 * D / 32;       // column tiles of the d-wide and the 2d-wide stages
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* XA = smem;                                // [32][LD]   a, later t1
   uint16_t* TB = XA + TL_ROWS * LD;                   // [32][LD]   out-projection result, later linear2 result
-  uint16_t* HB = TB + TL_ROWS * LD;                   // [32][LDH]  x (stage 0-2), then h
+  uint16_t* HB = SLIM ? TB : TB + TL_ROWS * LD;       // [32][LDH]  x (stage 0-2), then h
   float* PB = reinterpret_cast<float*>(HB + TL_ROWS * LDH);   // bo[D] b1[2D] b2[D] g1[D] be1[D] g2[D] be2[D]: no parameter is loaded
                                                               // from global memory behind a store (see tl_issue)
   constexpr int NPAR = QKV ? 11 * D : 8 * D;                  // QKV: + the next layer's q | k | v biases [3D]
@@ -182,8 +191,8 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   // stage 0: the wave's out-projection weights first (they do not depend on the rows), then the block's rows of the attention
   // output -> XA and of the residual input -> HB (free until stage 3: loading it in stage 2 would expose one more global round
   // trip per workgroup), and the parameters -> PB
-  TlQueue<KS1> q1;
-  tl_issue<KS1>(ta.wo, wave, lane, q1);
+  TlQueue<KS1, QD> q1;
+  tl_issue<KS1, QD>(ta.wo, wave, lane, q1);
   {
     static_assert(8 * D == 4 * NTHR, "one float4 of parameters per thread");
     const int e = tid * 4;
@@ -203,10 +212,10 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
     if (row0 + r < ta.M) {
       if constexpr (ATTN) v = *reinterpret_cast<const uint4*>(ta.qkv + (row0 + r) * (3 * D) + c);      // the q third of the row
       else v = *reinterpret_cast<const uint4*>(ta.a + (row0 + r) * D + c);
-      xv = *reinterpret_cast<const uint4*>(ta.x + (row0 + r) * D + c);
+      if constexpr (!SLIM) xv = *reinterpret_cast<const uint4*>(ta.x + (row0 + r) * D + c);
     }
     *reinterpret_cast<uint4*>(XA + r * LD + c) = v;
-    *reinterpret_cast<uint4*>(HB + r * LD + c) = xv;
+    if constexpr (!SLIM) *reinterpret_cast<uint4*>(HB + r * LD + c) = xv;
   }
   if constexpr (ATTN) {
     // Phase B of the linear attention (linattn.hip: linattn_apply_rows) on the block's q rows, wave = head: row softmax over the
@@ -267,8 +276,8 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
 
   // stage 1: out projection -> TB (bf16)
   f32x16 acc;
-  tl_run<KS1>(ta.wo, wave, XA, LD, lane, q1, acc);
-  tl_issue<KS1>(ta.w1, wave, lane, q1);               // first linear1 tile: in flight across the LayerNorm stage
+  tl_run<KS1, QD>(ta.wo, wave, XA, LD, lane, q1, acc);
+  tl_issue<KS1, QD>(ta.w1, wave, lane, q1);           // first linear1 tile: in flight across the LayerNorm stage
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n = wave * 32 + 8 * q + 4 * lh;
@@ -277,16 +286,16 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   }
   __syncthreads();
   // stage 2: z1 = x + drop(o), t1 = LN1(z1) -> XA (the attention rows are no longer needed)
-  tl_layernorm<D, true, true>(TB, HB, nullptr, XA, LD, g1, be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
+  tl_layernorm<D, !SLIM, true>(TB, HB, ta.x, XA, LD, g1, be1, ta.z1, ta.t1, ta.stat1, row0, ta.M, ta.eps, dc1, tid);
   __syncthreads();
   // stage 3a: u = t1 W1^T + b1 -> HB (bf16); the wave's tiles are wave and wave + NW
-  TlQueue<KS2> q2;
+  TlQueue<KS2, QD> q2;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wave + t * NW;
-    tl_run<KS1>(ta.w1, ct, XA, LD, lane, q1, acc);
-    if (t == 0) tl_issue<KS1>(ta.w1, wave + NW, lane, q1);
-    else tl_issue<KS2>(ta.w2, wave, lane, q2);        // linear2 operands: requested before any store of stage 3b
+    tl_run<KS1, QD>(ta.w1, ct, XA, LD, lane, q1, acc);
+    if (t == 0) tl_issue<KS1, QD>(ta.w1, wave + NW, lane, q1);
+    else tl_issue<KS2, QD>(ta.w2, wave, lane, q2);    // linear2 operands: requested before any store of stage 3b
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = ct * 32 + 8 * q + 4 * lh;
@@ -337,7 +346,8 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   }
   __syncthreads();
   // stage 4: linear2 -> TB
-  tl_run<KS2>(ta.w2, wave, HB, LDH, lane, q2, acc);
+  tl_run<KS2, QD>(ta.w2, wave, HB, LDH, lane, q2, acc);
+  if constexpr (SLIM) __syncthreads();                // TB is HB's memory: every wave has read its h fragments
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n = wave * 32 + 8 * q + 4 * lh;
@@ -346,7 +356,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
   }
   __syncthreads();
   // stage 5: z2 = t1 + drop(f), y = LN2(z2); QKV: y also replaces t1 in XA (a lane overwrites exactly the quad it has just read)
-  if constexpr (QKV) tl_issue<KS1>(ta.wq, wave, lane, q1);   // first q|k|v tile: in flight across the LayerNorm stage
+  if constexpr (QKV) tl_issue<KS1, QD>(ta.wq, wave, lane, q1);   // first q|k|v tile: in flight across the LayerNorm stage
   tl_layernorm<D, true, QKV>(TB, XA, nullptr, XA, LD, g2, be2, ta.z2, ta.y, ta.stat2, row0, ta.M, ta.eps, dc2, tid);
   if constexpr (QKV) {
     // stage 6: the next layer's q | k | v projection of the block: three column tiles per wave (wave, wave + NW, wave + 2 NW of the
@@ -359,8 +369,8 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, 4) tail_fwd_kernel(const
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int ct = wave + t * NW;
-      tl_run<KS1>(ta.wq, ct, XA, LD, lane, q1, acc);
-      if (t < 2) tl_issue<KS1>(ta.wq, wave + (t + 1) * NW, lane, q1);
+      tl_run<KS1, QD>(ta.wq, ct, XA, LD, lane, q1, acc);
+      if (t < 2) tl_issue<KS1, QD>(ta.wq, wave + (t + 1) * NW, lane, q1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = ct * 32 + 8 * q + 4 * lh;
@@ -672,8 +682,9 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   ta.dbg = ltu_knob("LTU_TAIL_DBG", 0);
   ta.wq = (const uint16_t*)wq_next; ta.bq[0] = bq0; ta.bq[1] = bq1; ta.bq[2] = bq2; ta.qkv_next = (uint16_t*)qkv_next;
   const bool qn = qkv_next != nullptr;
+  const bool slim = d == 128 && !qn && ltu_knob("LTU_TAIL_FWD_OCC", 4) >= 5;
   const unsigned blocks = cdiv(M, TL_ROWS);
-  const size_t lds = (size_t)TL_ROWS * (2 * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)(qn ? 11 : 8) * d * sizeof(float) +
+  const size_t lds = (size_t)TL_ROWS * ((slim ? 1 : 2) * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)(qn ? 11 : 8) * d * sizeof(float) +
                      (qkv != nullptr ? (size_t)TL_ROWS * (d / 32) * 2 * sizeof(float) : 0);
   auto launch = [&](auto kern, unsigned threads) {
     static LtuDevOnce once;                // one latch per kernel instantiation
@@ -681,11 +692,13 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)s, ta);
   };
   if (d == 256) {
-    if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<256, true, true>, 512); else launch(&tail_fwd_kernel<256, true, false>, 512); }
-    else { if (qn) launch(&tail_fwd_kernel<256, false, true>, 512); else launch(&tail_fwd_kernel<256, false, false>, 512); }
+    if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<256, true, true, 4>, 512); else launch(&tail_fwd_kernel<256, true, false, 4>, 512); }
+    else { if (qn) launch(&tail_fwd_kernel<256, false, true, 4>, 512); else launch(&tail_fwd_kernel<256, false, false, 4>, 512); }
+  } else if (slim) {
+    if (qkv != nullptr) launch(&tail_fwd_kernel<128, true, false, 5>, 256); else launch(&tail_fwd_kernel<128, false, false, 5>, 256);
   } else {
-    if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<128, true, true>, 256); else launch(&tail_fwd_kernel<128, true, false>, 256); }
-    else { if (qn) launch(&tail_fwd_kernel<128, false, true>, 256); else launch(&tail_fwd_kernel<128, false, false>, 256); }
+    if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<128, true, true, 4>, 256); else launch(&tail_fwd_kernel<128, true, false, 4>, 256); }
+    else { if (qn) launch(&tail_fwd_kernel<128, false, true, 4>, 256); else launch(&tail_fwd_kernel<128, false, false, 4>, 256); }
   }
   return ltu_check_launch();
 }
