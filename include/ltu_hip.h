@@ -161,9 +161,11 @@ int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* cons
 /* Several of the above in ONE launch + ONE fold: the weight / bias gradients of the four projections of a transformer layer
  * (model/trans_block.py:144,156,166,187,189: q,k,v as one job with nw = 3, out, linear1, linear2).  Together they offer 8-32
  * output tiles, so a few row splits per tile fill the chip and the fp32 partial tiles shrink 4x against four separate calls.
+ * The host side may also hand in the jobs of SEVERAL layers of one transformer at once (small levels, where a layer's group is
+ * launch-latency-bound): all jobs of a group share one split count, so they should have the same M.
  * jobs: host array (<= LTU_WGRAD_GROUP_MAX); ws: ltu_linear_wgrad_group_ws_floats() floats (0 = this group is not handled:
  * use ltu_linear_wgrad per job; bf16 storage, N and K multiples of 128, M a multiple of 32 and >= 1024). */
-#define LTU_WGRAD_GROUP_MAX 8
+#define LTU_WGRAD_GROUP_MAX 32
 typedef struct ltu_wgrad_job {
   const void* grad;    /* g [M][ldg] */
   const void* a;       /* a [M][lda] */

@@ -25,6 +25,9 @@ class WgradJob(ctypes.Structure):
                 ('ldg', c_int), ('lda', c_int), ('nw', c_int), ('M', c_int), ('N', c_int), ('K', c_int)]
 
 
+WGRAD_GROUP_MAX = 32      # LTU_WGRAD_GROUP_MAX of include/ltu_hip.h
+
+
 # name -> argument types (return type is always int).  Mirrors include/ltu_hip.h one to one.
 SIGNATURES = {
     'ltu_version': [],

@@ -187,13 +187,19 @@ __global__ void __launch_bounds__(256) wgrad_group_ring_bf16_kernel(const WGroup
   // round-robin over the 8 XCDs) they share one XCD and its L2, and they are adjacent in dispatch order: the three column tiles
   // of the q,k,v gradient read the same rows of X, the two row tiles of the linear2 gradient the same rows of G.  Placement
   // affects speed only.  id = ((split / 8) * tiles + tile) * 8 + split % 8.
-  const int s_lo = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
-  const int tg = q % ga.tiles, split = (q / ga.tiles) * 8 + s_lo;
-  if (split >= ga.nsplit) return;
+  // With fewer than 8 splits (many jobs: the layers of a small level flushed together) that mapping would launch mostly empty
+  // workgroups; then id = tile * nsplit + split.
+  int tg, split;
+  if (ga.nsplit >= 8) {
+    const int s_lo = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    tg = q % ga.tiles; split = (q / ga.tiles) * 8 + s_lo;
+    if (split >= ga.nsplit) return;
+  } else {
+    tg = (int)blockIdx.x / ga.nsplit; split = (int)blockIdx.x - tg * ga.nsplit;
+  }
   int ji = 0;
-#pragma unroll
-  for (int t = 1; t < LTU_WGRAD_GROUP_MAX; ++t)
-    if (t < ga.njobs && tg >= ga.j[t].tile_begin) ji = t;
+  for (int t = 1; t < ga.njobs; ++t)
+    if (tg >= ga.j[t].tile_begin) ji = t;
   const WGroupJob& jb = ga.j[ji];
   const int t = tg - jb.tile_begin;
   const int nb = t / jb.nk, kb = t - nb * jb.nk;
@@ -521,9 +527,8 @@ struct WFoldArgs {
 __global__ void __launch_bounds__(256) wgroup_fold_kernel(const WFoldArgs fa) {
   __shared__ float4 red[3][64];
   int ji = 0;
-#pragma unroll
-  for (int t = 1; t < LTU_WGRAD_GROUP_MAX; ++t)
-    if (t < fa.njobs && (int)blockIdx.x >= fa.j[t].blk_begin) ji = t;
+  for (int t = 1; t < fa.njobs; ++t)
+    if ((int)blockIdx.x >= fa.j[t].blk_begin) ji = t;
   const WFoldJob& jb = fa.j[ji];
   const int local = (int)blockIdx.x - jb.blk_begin;
   const int nper = jb.N / jb.nseg;
@@ -657,7 +662,7 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_ring_bf16_kernel<TN_RING>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               smem_bytes);
   }
-  blocks = ((ga.nsplit + 7) / 8) * ga.tiles * 8;
+  blocks = ga.nsplit >= 8 ? ((ga.nsplit + 7) / 8) * ga.tiles * 8 : ga.nsplit * ga.tiles;
   hipLaunchKernelGGL((wgrad_group_ring_bf16_kernel<TN_RING>), dim3(blocks), dim3(256), smem_bytes, st, ga);
   hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fa);
   return ltu_check_launch();

@@ -109,7 +109,8 @@ class Context:
         self.wg_branch = None       # {'side': torch.cuda.Stream, 'jobs': [(fn, tensors)]}
         self.norm_ws_by_dev = {}
         self.ones = {}
-        self.wg_group = []          # pending projection weight gradients of the current transformer layer (see wgrad_group_push)
+        self.wg_group = []          # pending projection weight gradients of the current transformer layer(s) (see wgrad_group_push)
+        self.wg_bytes = self.wg_layers = 0
 
     def one(self, device):
         """a cached fp32 scalar 1 (the seed gradient of each level loss: no fill launch per level and step)"""
@@ -160,16 +161,27 @@ class Context:
     # weight-gradient jobs in here during the layer's backward; the layer's last one (qkv) flushes them as ONE launch + ONE fold
     # (ltu_linear_wgrad_group).  Only gradients that live in a reducer's flat buffer take part (nothing reads those before
     # flush_deferred, which also flushes a group left open).
+    # At the small levels one layer's group is launch-latency-bound (2 048 tokens: 10 us + a 6 us fold for 13 MB of operands), so
+    # the groups of consecutive layers of ONE transformer are kept back and launched together while their operands still fit
+    # the last-level cache (WGRAD_DEFER_MB; the transformer's flush point, a closing gradient bucket and the end of backward
+    # launch whatever is pending).
     def wgrad_group_push(self, g, x, dws, dbs, M, N, K, flush):
+        if self.wg_group and self.wg_group[0][4] != M:
+            self.wgrad_group_flush()                  # another transformer: a group shares one row split
         self.wg_group.append((g, x, dws, dbs, M, N, K))
-        if flush or len(self.wg_group) >= 8:
+        self.wg_bytes += 2 * M * (N + K)
+        if len(self.wg_group) >= _lib.WGRAD_GROUP_MAX or (
+                flush and (self.wg_bytes + self.wg_bytes // max(1, self.wg_layers + 1) > WGRAD_DEFER_MB * (1 << 20)
+                           or len(self.wg_group) + 4 > _lib.WGRAD_GROUP_MAX)):
             self.wgrad_group_flush()
+        elif flush:
+            self.wg_layers += 1
 
     def wgrad_group_flush(self):
         jobs = self.wg_group
         if not jobs:
             return
-        self.wg_group = []
+        self.wg_group, self.wg_bytes, self.wg_layers = [], 0, 0
         arr = (_lib.WgradJob * len(jobs))()
         for r, (g, x, dws, dbs, M, N, K) in zip(arr, jobs):
             r.grad, r.a, r.ldg, r.lda, r.nw, r.M, r.N, r.K = g.data_ptr(), x.data_ptr(), N, K, len(dws), M, N, K
@@ -314,6 +326,7 @@ def _w_transposed(ws, rows, cols, dtype):
 DEFER_WGRAD = False
 GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_linear_wgrad_group)
 import os as _os
+WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '128'))     # operand bytes of the layers' weight-gradient groups launched together
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
 
 
@@ -332,12 +345,13 @@ class _WgradFlushPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        ctx.lc.wgrad_group_flush()
         ctx.lc.wgrad_branch_flush()
         return g
 
 
 def wgrad_flush_point(x):
-    return _WgradFlushPoint.apply(x) if (current().wg_branch is not None and x.requires_grad) else x
+    return _WgradFlushPoint.apply(x) if ((current().wg_branch is not None or WGRAD_DEFER_MB > 0) and x.requires_grad) else x
 
 
 def _wgrad_ws(M, N, K, like):
