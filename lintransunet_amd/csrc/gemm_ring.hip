@@ -49,7 +49,7 @@ __device__ __forceinline__ void ring_sync() {
 template <int R>
 __device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ grad, int ldg, const uint16_t* __restrict__ x, int lda,
                                                 long long m_begin, long long m_end, int n_blk, int k_blk, float* __restrict__ pz,
-                                                float* __restrict__ bz, int kpad, uint16_t* smem) {
+                                                float* __restrict__ bz, int kpad, uint16_t* smem, bool accum = false) {
   constexpr int UNIT = 2 * 32 * 128;                                     // elements
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -133,6 +133,27 @@ __device__ __forceinline__ void wgrad_ring_tile(const uint16_t* __restrict__ gra
   }
 
   const int li = lane & 31, lh = lane >> 5;
+  if (accum) {
+    // the only split of its tile: the sums go straight into the gradient (pz / bz = the gradient block, bz nullable), no fold
+    if (k_blk == 0 && bz != nullptr) {
+      const float t = xhalf_combine<LtuAdd>(bsum);
+      if (lh == 0) bz[n_blk + (wm * 2 + wn) * 32 + li] += t;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k_blk + (wn * 2 + j) * 32 + li;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = pz[(long long)(n_blk + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * kpad + k];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pz[(long long)(n_blk + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * kpad + k] = old[r] + acc[i][j][r];
+      }
+    }
+    return;
+  }
   if (k_blk == 0) {
     const float t = xhalf_combine<LtuAdd>(bsum);
     if (lh == 0) bz[n_blk + (wm * 2 + wn) * 32 + li] = t;
@@ -173,13 +194,18 @@ struct WGroupJob {
   long long M;
   int ldg, lda, N, K, nk, rows, nsplit;
   int tile_begin;       // first tile of this job in the group's tile list; its tiles are ordered (n tile, k tile)
+  float* out[3];        // direct mode: the gradient blocks themselves
+  float* outb[3];
+  int nper;             // rows of one gradient block (N / nw)
 };
 struct WGroupArgs {
   WGroupJob j[LTU_WGRAD_GROUP_MAX];
   int njobs;
   int tiles;            // tiles of all jobs
   int nsplit;           // row splits (the same for every job)
+  int direct;           // nsplit == 1: every tile has one owner, which adds its sums to the gradient itself (no partials, no fold)
 };
+static_assert(sizeof(WGroupArgs) <= 4096, "kernel arguments");
 template <int R>
 __global__ void __launch_bounds__(256) wgrad_group_ring_bf16_kernel(const WGroupArgs ga) {
   extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
@@ -206,6 +232,16 @@ __global__ void __launch_bounds__(256) wgrad_group_ring_bf16_kernel(const WGroup
   const long long m_begin = (long long)split * jb.rows;
   long long m_end = m_begin + jb.rows;
   if (m_end > jb.M) m_end = jb.M;
+  if (ga.direct) {
+    const int seg = (nb * 128) / jb.nper;                   // a 128-row tile lies inside one block (nper % 128 == 0)
+    float* o = seg == 0 ? jb.out[0] : (seg == 1 ? jb.out[1] : jb.out[2]);
+    float* ob = seg == 0 ? jb.outb[0] : (seg == 1 ? jb.outb[1] : jb.outb[2]);
+    // the tile function indexes rows of cat(dW): rebase the block's pointers by its first row
+    o -= (long long)seg * jb.nper * jb.K;
+    if (ob != nullptr) ob -= seg * jb.nper;
+    wgrad_ring_tile<R>(jb.grad, jb.ldg, jb.x, jb.lda, m_begin, m_end, nb * 128, kb * 128, o, ob, jb.K, smem, true);
+    return;
+  }
   float* bpart = jb.part + (long long)jb.nsplit * jb.N * jb.K;
   wgrad_ring_tile<R>(jb.grad, jb.ldg, jb.x, jb.lda, m_begin, m_end, nb * 128, kb * 128, jb.part + (long long)split * jb.N * jb.K,
                      bpart + (long long)split * jb.N, jb.K, smem);
@@ -602,6 +638,9 @@ static void wgroup_geometry(const ltu_wgrad_job* jobs, int njobs, WGroupArgs& ga
   ga.njobs = njobs;
   ga.tiles = tiles;
   ga.nsplit = nsplit;
+  ga.direct = nsplit == 1 && !ltu_knob("LTU_WGROUP_NO_DIRECT", 0);
+  for (int i = 0; i < njobs && ga.direct; ++i)
+    if ((jobs[i].N / jobs[i].nw) % 128) ga.direct = 0;
   for (int i = 0; i < njobs; ++i) {
     WGroupJob& j = ga.j[i];
     const long long M = jobs[i].M;
@@ -615,6 +654,7 @@ static void wgroup_geometry(const ltu_wgrad_job* jobs, int njobs, WGroupArgs& ga
     part_off[i] = off;
     off += (long long)j.nsplit * j.N * ((long long)j.K + 1);
   }
+  if (ga.direct) off = 4;                    // no partial tiles (a non-zero size keeps "0 = not handled" of the C-ABI)
   *ws_floats = off;
 }
 static bool wgroup_ok(const ltu_wgrad_job* jobs, int njobs) {
@@ -649,6 +689,8 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
     j.part = ws + off[i];
     j.grad = reinterpret_cast<const uint16_t*>(jobs[i].grad);
     j.x = reinterpret_cast<const uint16_t*>(jobs[i].a);
+    j.nper = jobs[i].N / jobs[i].nw;
+    for (int s = 0; s < 3; ++s) { j.out[s] = s < jobs[i].nw ? jobs[i].dw[s] : nullptr; j.outb[s] = s < jobs[i].nw ? jobs[i].db[s] : nullptr; }
     WFoldJob& f = fa.j[i];
     f.part = j.part; f.nsplit = j.nsplit; f.N = j.N; f.K = j.K; f.nseg = jobs[i].nw;
     for (int s = 0; s < 3; ++s) { f.out[s] = s < jobs[i].nw ? jobs[i].dw[s] : nullptr; f.outb[s] = s < jobs[i].nw ? jobs[i].db[s] : nullptr; }
@@ -664,6 +706,6 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
   }
   blocks = ga.nsplit >= 8 ? ((ga.nsplit + 7) / 8) * ga.tiles * 8 : ga.nsplit * ga.tiles;
   hipLaunchKernelGGL((wgrad_group_ring_bf16_kernel<TN_RING>), dim3(blocks), dim3(256), smem_bytes, st, ga);
-  hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fa);
+  if (!ga.direct) hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fa);
   return ltu_check_launch();
 }

@@ -412,6 +412,33 @@ def test_linear_wgrad_group(ops, M, d):
         assert rel_err(dw, dw_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
 
 
+@pytest.mark.parametrize('M,d,layers', [(2048, 256, 8), (1024, 256, 8), (2048, 128, 8), (4320, 256, 2), (2048, 256, 3)])
+def test_linear_wgrad_group_of_layers(ops, M, d, layers):
+    """the groups of several layers of a small level as ONE launch (ops.Context.wgrad_group_push keeps them back): with 32 jobs
+    every tile has a single owner, which adds its sums to the gradient itself (no partial tiles, no fold); a bias gradient may be
+    absent"""
+    g = G(37)
+    bf = lambda t: t.bfloat16()
+    shapes = [(3 * d, d, 3), (d, d, 1), (2 * d, d, 1), (d, 2 * d, 1)]
+    lc = ops.Context()
+    want, bufs = [], []
+    for lay in range(layers):
+        for ji, (N, K, nw) in enumerate(shapes):
+            gr, x = bf(torch.randn(M, N, generator=g) * 0.1).to(DEV), bf(torch.randn(M, K, generator=g)).to(DEV)
+            dws = [torch.full((N // nw, K), 0.5, device=DEV) for _ in range(nw)]
+            dbs = [torch.full((N // nw,), -0.25, device=DEV) for _ in range(nw)]
+            lc.wgrad_group_push(gr, x, dws, dbs, M, N, K, ji == 3)
+            want.append((gr.float().t() @ x.float() + 0.5, gr.float().sum(0) - 0.25))
+            bufs.append((dws, dbs))
+        if lay < layers - 1 and 4 * (lay + 1) < 32:
+            assert len(lc.wg_group) == 4 * (lay + 1)        # kept back: these levels fit ops.WGRAD_DEFER_MB
+    lc.flush_deferred()
+    assert not lc.wg_group and lc.wg_bytes == 0
+    for (dw_ref, db_ref), (dws, dbs) in zip(want, bufs):
+        dw, db = torch.cat(dws, 0), torch.cat(dbs, 0)
+        assert rel_err(dw, dw_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
+
+
 # ---------------------------------------------------------------------------------------------- linear attention
 def _qkv_pack(q, k, v):
     B, h, N, dk = q.shape
