@@ -623,10 +623,17 @@ extern "C" int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, co
 // A workgroup walks 4x4x8 bricks of output voxels for one 128-byte channel chunk (64 bf16 / 32 fp32
 // channels): the 6x6x10 halo brick is staged in LDS once and the 27 taps are LDS reads at constant offsets (27x fewer
 // vector-memory requests than gathering from global, no per-tap address arithmetic).  A thread owns one channel quad and
-// every NV-th voxel of the brick; its 27 x 4 weights (or weight-gradient accumulators) stay in registers across bricks.
+// RUNS of 4 consecutive outputs along d: for each of the 9 (h, w) tap rows it reads the 6 halo values under the run once and
+// uses each of them for up to three taps - 54 LDS reads and unpacks per 4 outputs instead of 108 (one output at a time the
+// kernel was LDS-read- and unpack-bound at 0.09 of the HBM peak).  Its 27 x 4 weights (or weight-gradient accumulators) stay
+// in registers across bricks.  Halo rows have a d pitch of 11 voxels: the four runs a wave reads together (2 w x 2 d-halves)
+// then start on 128-byte rows of both parities, i.e. on both halves of the 64 LDS banks.
 //   MODE 0: y = mask * (x + conv(x) + bias)      MODE 1: dx = mask * (dy + conv_flipped(dy))
 //   MODE 2: dw[c][t] += sum g' x[v + off_t], db[c] += sum g'   (g' = mask * dy; block-level LDS reduction, then atomics)
 #define DWH_VOX 360
+#define DWH_PD 11           // d pitch of the LDS halo image (10 voxels + 1)
+#define DWH_ROWS (36 * DWH_PD)
+#define DWH_RUN 4
 // 16 bytes of T (4 floats / 8 bf16) plus the same of a second tensor: the backward modes take the gradients of two consumers
 // of the layer's output and sum them while staging (no stand-alone add pass)
 template <typename T>
@@ -648,7 +655,7 @@ __device__ __forceinline__ uint4 add16<bf16_t>(uint4 a, uint4 b) {
 }
 // x2 / g2 (nullable): second gradient tensors summed onto x (MODE 1) / g (MODE 2)
 template <typename T, int MODE>
-__global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ x, const T* __restrict__ x2, const T* __restrict__ g,
+__global__ void __launch_bounds__(256, 2) dwconv_halo_kernel(const T* __restrict__ x, const T* __restrict__ x2, const T* __restrict__ g,
                                                           const T* __restrict__ g2,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           T* __restrict__ y, float* __restrict__ dwt, float* __restrict__ db, int B,
@@ -656,9 +663,11 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
                                                           uint64_t seed, const uint64_t* step, float* __restrict__ part) {
   constexpr int CC = 128 / (int)sizeof(T);          // channels per chunk (one 128-byte LDS row per voxel)
   constexpr int QV = CC / 4;                        // channel quads per voxel
-  constexpr int NV = 256 / QV;                      // voxel slots
-  constexpr int NJ = 128 / NV;                      // outputs per thread and brick
-  __shared__ __attribute__((aligned(16))) T halo[DWH_VOX * CC];
+  constexpr int NV = 256 / QV;                      // run slots
+  constexpr int R = DWH_RUN, PD = DWH_PD;
+  constexpr int NJ = (128 / R) / NV;                // runs per thread and brick
+  static_assert(NJ >= 1 && NJ * NV * R == 128, "runs tile the brick");
+  __shared__ __attribute__((aligned(16))) T halo[DWH_ROWS * CC];
   __shared__ __attribute__((aligned(16))) T gl[MODE == 2 ? 128 * CC : 4];
   const int tid = threadIdx.x;
   const int cq = tid % QV, vs = tid / QV;
@@ -699,31 +708,68 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
     const int b = t / nbh;
     const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
     __syncthreads();                                // previous brick fully consumed
-    for (int idx = tid; idx < DWH_VOX * 8; idx += 256) {
-      const int hv = idx >> 3, part = idx & 7;      // 8 x 16 bytes per voxel row
-      const int hd = hv % 10, hw = (hv / 10) % 6, hh = hv / 60;
-      const int h = h0 - 1 + hh, ww = w0 - 1 + hw, d = d0 - 1 + hd;
-      const int cc = blockIdx.x * CC + part * (16 / (int)sizeof(T));
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W && (unsigned)d < (unsigned)D && cc < C) {
-        const long long off = ((((long long)b * H + h) * W + ww) * D + d) * C + cc;
-        v = *reinterpret_cast<const uint4*>(x + off);
-        if (MODE == 1 && x2 != nullptr) v = add16<T>(v, *reinterpret_cast<const uint4*>(x2 + off));
-      }
-      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(halo) + hv * 128 + part * 16) = v;
-    }
-    if (MODE == 2) {                                // the brick's output gradients: 128 voxels x 128 bytes
-      for (int idx = tid; idx < 128 * 8; idx += 256) {
-        const int ov = idx >> 3, part = idx & 7;
-        const int h = h0 + (ov >> 5), ww = w0 + ((ov >> 3) & 3), d = d0 + (ov & 7);
-        const int cc = blockIdx.x * CC + part * (16 / (int)sizeof(T));
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (h < H && ww < W && d < D && cc < C) {
-          const long long off = ((((long long)b * H + h) * W + ww) * D + d) * C + cc;
-          v = *reinterpret_cast<const uint4*>(g + off);
-          if (g2 != nullptr) v = add16<T>(v, *reinterpret_cast<const uint4*>(g2 + off));
+    // All of a thread's 16-byte pieces are requested before the first one is used, from clamped addresses (padding is selected
+    // to zero on the way to LDS): as a loop with a test around each load every piece was a memory round trip of its own - 12 in a
+    // row per brick, which is where this kernel's time went (0.7 TB/s).
+    {
+      constexpr int NH = (DWH_VOX * 8 + 255) / 256;
+      constexpr int EPP = 16 / (int)sizeof(T);      // elements per piece
+      constexpr int GP = MODE == 1 ? NH / 2 : NH;   // pieces per batch: two tensors (MODE 1) = two batches of 6 + 6 loads
+      static_assert(NH % GP == 0, "whole batches");
+      const bool two = MODE == 1 && x2 != nullptr;
+#pragma unroll
+      for (int p0 = 0; p0 < NH; p0 += GP) {
+        uint4 hv1[GP], hv2[MODE == 1 ? GP : 1];
+        unsigned inmask = 0;
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+          const int idx = tid + (p0 + q) * 256;
+          const int hv = idx >> 3, part = idx & 7;  // 8 x 16 bytes per voxel row
+          const int hd = hv % 10, hw = (hv / 10) % 6, hh = hv / 60;
+          const int h = h0 - 1 + hh, ww = w0 - 1 + hw, d = d0 - 1 + hd;
+          const int cc = blockIdx.x * CC + part * EPP;
+          const bool in = idx < DWH_VOX * 8 && (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W && (unsigned)d < (unsigned)D && cc < C;
+          const long long off = in ? ((((long long)b * H + h) * W + ww) * D + d) * C + cc : 0;
+          hv1[q] = *reinterpret_cast<const uint4*>(x + off);
+          if (MODE == 1 && two) hv2[q] = *reinterpret_cast<const uint4*>(x2 + off);
+          inmask |= in ? 1u << q : 0u;
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gl) + ov * 128 + part * 16) = v;
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+          const int idx = tid + (p0 + q) * 256;
+          if (idx < DWH_VOX * 8) {
+            const int hv = idx >> 3, part = idx & 7;
+            const int hd = hv % 10, hw = (hv / 10) % 6, hh = hv / 60;
+            uint4 v = hv1[q];
+            if (MODE == 1 && two) v = add16<T>(v, hv2[q]);
+            if (!((inmask >> q) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(halo) + ((hh * 6 + hw) * PD + hd) * 128 + part * 16) = v;
+          }
+        }
+      }
+      if (MODE == 2) {                              // the brick's output gradients: 128 voxels x 128 bytes
+        uint4 gv1[4], gv2[4];
+        unsigned gmask = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int idx = tid + p * 256;
+          const int ov = idx >> 3, part = idx & 7;
+          const int h = h0 + (ov >> 5), ww = w0 + ((ov >> 3) & 3), d = d0 + (ov & 7);
+          const int cc = blockIdx.x * CC + part * EPP;
+          const bool in = h < H && ww < W && d < D && cc < C;
+          const long long off = in ? ((((long long)b * H + h) * W + ww) * D + d) * C + cc : 0;
+          gv1[p] = *reinterpret_cast<const uint4*>(g + off);
+          if (g2 != nullptr) gv2[p] = *reinterpret_cast<const uint4*>(g2 + off);
+          gmask |= in ? 1u << p : 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int idx = tid + p * 256;
+          uint4 v = gv1[p];
+          if (g2 != nullptr) v = add16<T>(v, gv2[p]);
+          if (!((gmask >> p) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gl) + (idx >> 3) * 128 + (idx & 7) * 16) = v;
+        }
       }
     }
     __syncthreads();
@@ -731,32 +777,75 @@ __global__ void __launch_bounds__(256) dwconv_halo_kernel(const T* __restrict__ 
     const float4 m = dropmask4(dc, (uint64_t)(((long long)b * C + c) >> 2));
 #pragma unroll 1
     for (int j = 0; j < NJ; ++j) {
-      const int ov = vs + NV * j;
-      const int oh = ov >> 5, ow = (ov >> 3) & 3, od = ov & 7;
-      const int h = h0 + oh, ww = w0 + ow, d = d0 + od;
-      const bool inside = h < H && ww < W && d < D;
-      const T* hp = halo + ((oh * 6 + ow) * 10 + od) * CC + cq * 4;
+      const int rn = vs + NV * j;                   // run (oh, ow, od0 .. od0 + 3)
+      const int oh = rn >> 3, ow = (rn >> 1) & 3, od0 = (rn & 1) * R;
+      const int h = h0 + oh, ww = w0 + ow, d = d0 + od0;
+      const T* hp = halo + ((oh * 6 + ow) * PD + od0) * CC + cq * 4;
       const long long e = ((((long long)b * H + h) * W + ww) * D + d) * C + c;
       if (MODE == 2) {
-        float4 gv = Vec4<T>::load(gl + ov * CC + cq * 4);      // zero outside the volume
-        gv.x *= m.x; gv.y *= m.y; gv.z *= m.z; gv.w *= m.w;
-        bs.x += gv.x; bs.y += gv.y; bs.z += gv.z; bs.w += gv.w;
+        float4 gv[R];
 #pragma unroll
-        for (int tp = 0; tp < 27; ++tp) {
-          const int td = tp / 9, th = (tp / 3) % 3, tw = tp % 3;
-          const float4 q = Vec4<T>::load(hp + ((th * 6 + tw) * 10 + td) * CC);
-          wr[tp].x += gv.x * q.x; wr[tp].y += gv.y * q.y; wr[tp].z += gv.z * q.z; wr[tp].w += gv.w * q.w;
+        for (int r = 0; r < R; ++r) {
+          gv[r] = Vec4<T>::load(gl + ((oh << 5) + (ow << 3) + od0 + r) * CC + cq * 4);      // zero outside the volume
+          gv[r].x *= m.x; gv[r].y *= m.y; gv[r].z *= m.z; gv[r].w *= m.w;
+          bs.x += gv[r].x; bs.y += gv[r].y; bs.z += gv[r].z; bs.w += gv[r].w;
         }
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+          for (int tw = 0; tw < 3; ++tw) {
+            float4 q[R + 2];
+#pragma unroll
+            for (int i = 0; i < R + 2; ++i) q[i] = Vec4<T>::load(hp + ((th * 6 + tw) * PD + i) * CC);
+#pragma unroll
+            for (int td = 0; td < 3; ++td) {
+              float4& a = wr[td * 9 + th * 3 + tw];
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                a.x += gv[r].x * q[r + td].x; a.y += gv[r].y * q[r + td].y; a.z += gv[r].z * q[r + td].z; a.w += gv[r].w * q[r + td].w;
+              }
+            }
+            // one tap row at a time (the accumulators are pinned here in program order): with all 54 reads hoisted above the
+            // arithmetic the kernel needs 300 registers and loses the second wave per SIMD
+#pragma unroll
+            for (int td = 0; td < 3; ++td) {
+              float4& a = wr[td * 9 + th * 3 + tw];
+              asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+            }
+          }
       } else {
-        const float4 ctr = Vec4<T>::load(hp + ((1 * 6 + 1) * 10 + 1) * CC);
-        float4 acc = make_float4(bs.x + ctr.x, bs.y + ctr.y, bs.z + ctr.z, bs.w + ctr.w);
+        float4 acc[R];
 #pragma unroll
-        for (int tp = 0; tp < 27; ++tp) {
-          const int td = tp / 9, th = (tp / 3) % 3, tw = tp % 3;
-          const float4 q = Vec4<T>::load(hp + ((th * 6 + tw) * 10 + td) * CC);
-          acc.x += wr[tp].x * q.x; acc.y += wr[tp].y * q.y; acc.z += wr[tp].z * q.z; acc.w += wr[tp].w * q.w;
+        for (int r = 0; r < R; ++r) acc[r] = bs;
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+          for (int tw = 0; tw < 3; ++tw) {
+            float4 q[R + 2];
+#pragma unroll
+            for (int i = 0; i < R + 2; ++i) q[i] = Vec4<T>::load(hp + ((th * 6 + tw) * PD + i) * CC);
+            if (th == 1 && tw == 1) {               // the identity term: the run's own voxels
+#pragma unroll
+              for (int r = 0; r < R; ++r) { acc[r].x += q[r + 1].x; acc[r].y += q[r + 1].y; acc[r].z += q[r + 1].z; acc[r].w += q[r + 1].w; }
+            }
+#pragma unroll
+            for (int td = 0; td < 3; ++td) {
+              const float4 wv = wr[td * 9 + th * 3 + tw];
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                acc[r].x += wv.x * q[r + td].x; acc[r].y += wv.y * q[r + td].y; acc[r].z += wv.z * q[r + td].z; acc[r].w += wv.w * q[r + td].w;
+              }
+            }
+            // one tap row at a time: left alone, hipcc sinks all the arithmetic into the guarded store block below, behind all 54
+            // reads (300 registers: no second wave per SIMD)
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r].x), "+v"(acc[r].y), "+v"(acc[r].z), "+v"(acc[r].w));
+          }
+        if (h < H && ww < W) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (d + r < D) Vec4<T>::store(y + e + (long long)r * C, make_float4(acc[r].x * m.x, acc[r].y * m.y, acc[r].z * m.z, acc[r].w * m.w));
         }
-        if (inside) Vec4<T>::store(y + e, make_float4(acc.x * m.x, acc.y * m.y, acc.z * m.z, acc.w * m.w));
       }
     }
   }
