@@ -257,6 +257,12 @@ long long ltu_norm_ws_floats(void);
 int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s);
 int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C, int act,
                        float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+/* stats + apply in ONE call (what the model's forward uses): when the shape qualifies (bf16 or fp32, C a power of two, a few KB
+ * of partial sums per sample) the statistics kernel leaves its per-chunk partials in `ws` and every workgroup of the apply kernel
+ * folds them itself - no fold launch in between; workgroup 0 of each sample publishes sums[b][c][1..2] for the backward pass.
+ * Otherwise exactly ltu_instnorm_stats followed by ltu_instnorm_apply. */
+int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const void* res, void* y, int B, long long S, int C, int act, float slope,
+                     float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dx from dy (+ dy2 + dy3, nullable: the gradients of further consumers of y, summed on load instead of by a stand-alone add pass:
  * the skip tensors of the U-Net and the transformer inputs have two or three consumers); bsums [B][C][2] zero-filled scratch */
 int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3, const void* x, const float* sums, float* bsums, float* ws,

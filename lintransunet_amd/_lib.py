@@ -82,6 +82,7 @@ SIGNATURES = {
     'ltu_norm_ws_floats': [],
     'ltu_instnorm_stats': [P, P, P, I, L, I, I, P],
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_instnorm_fwd': [P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_instnorm_bwd': [P, P, P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
     'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],

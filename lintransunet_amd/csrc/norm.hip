@@ -80,31 +80,154 @@ __device__ __forceinline__ float in_fold_rowgroups(const float* red, int nrg, in
   return (a0 + a1) + (a2 + a3);
 }
 
+// ---- VW-wide vector access: 4 elements (8 / 16 bytes) or 8 elements (16 bytes of bf16: twice the bytes in flight per thread;
+// the statistics and apply passes keep one or two loads per thread in flight and are latency-, not bandwidth-limited) ----------
+template <typename T, int VW>
+__device__ __forceinline__ void ldv(const T* p, float (&f)[VW]) {
+  if constexpr (VW == 8 && sizeof(T) == 2) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < VW / 4; ++q) {
+      const float4 t = Vec4<T>::load(p + 4 * q);
+      f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+    }
+  }
+}
+template <typename T, int VW>
+__device__ __forceinline__ void stv(T* p, const float (&f)[VW]) {
+  if constexpr (VW == 8 && sizeof(T) == 2) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  } else {
+#pragma unroll
+    for (int q = 0; q < VW / 4; ++q) Vec4<T>::store(p + 4 * q, make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]));
+  }
+}
+// keep-mask * scale of the VW elements starting at element index e (a multiple of VW): the groups of four of drop4
+template <int VW>
+__device__ __forceinline__ void dropmaskv(const DropCfg& dc, long long e, float (&m)[VW]) {
+#pragma unroll
+  for (int q = 0; q < VW / 4; ++q) {
+    const float4 t = dropmask4(dc, (uint64_t)((e >> 2) + q));
+    m[4 * q] = t.x; m[4 * q + 1] = t.y; m[4 * q + 2] = t.z; m[4 * q + 3] = t.w;
+  }
+}
+template <typename T, int VW>
+__device__ __forceinline__ void load_gradv(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3, long long e, float (&g)[VW]) {
+  ldv<T, VW>(dy + e, g);
+  if (dy2 != nullptr) {
+    float t[VW];
+    ldv<T, VW>(dy2 + e, t);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) g[k] += t[k];
+  }
+  if (dy3 != nullptr) {
+    float t[VW];
+    ldv<T, VW>(dy3 + e, t);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) g[k] += t[k];
+  }
+}
+
+// ---- second stage inside the consumer ----------------------------------------------------------------------------------------
+// The statistics kernels leave per-chunk partial sums [nparts][n] (n = 2 C); instead of a fold launch of their own (5 us for a few
+// KB, 46 of them per training step) every workgroup of the APPLY kernel that follows folds them itself - same code, same order, so
+// all workgroups hold bit-identical statistics - and workgroup 0 of each sample publishes them for the backward pass.  Bounded by
+// IN_FOLD_MAX floats per sample so that the redundant reads stay a few KB per workgroup (the chunk count is chosen accordingly).
+#define IN_FOLD_MAX 8192
+#define IN_FOLD_LDS 1024
+// lds[0 .. n) = sum over parts; n a power of two in [4, IN_FOLD_LDS], nparts * n <= IN_FOLD_MAX; all 256 threads call this; ends
+// with a barrier.  A thread owns one 4-column group and every G-th part: at most IN_FOLD_MAX / 1024 = 8 float4 loads, ALL requested
+// before the first add (as a loop of dependent L2 round trips this prologue cost more than the fold launch it replaces).
+__device__ __forceinline__ void in_fold_parts(const float* __restrict__ part, int nparts, int n, float* lds, int tid) {
+  const int W = n >> 2, G = 256 / W;            // W column quads (<= 256), G part groups
+  const int cq = tid % W, g = tid / W;
+  constexpr int NL = IN_FOLD_MAX / 1024;
+  float4 v[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int z = g + k * G;
+    v[k] = *reinterpret_cast<const float4*>(part + (long long)(z < nparts ? z : 0) * n + cq * 4);
+  }
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < NL; ++k)
+    if (g + k * G < nparts) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+  // groups of a wave that share cq sit W lanes apart: fold them across lanes first when W < 64, then across waves through LDS
+  if (W < 64) {
+    for (int o = W; o < 64; o <<= 1) {
+      a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  const int rows = W < 64 ? 4 : G;              // partial rows left: one per wave, or one per group
+  if (W < 64) { if (lane < W) *reinterpret_cast<float4*>(lds + wave * n + lane * 4) = a; }
+  else *reinterpret_cast<float4*>(lds + g * n + cq * 4) = a;
+  __syncthreads();
+  float r = 0.f;
+  if (tid < n) {                                 // n <= 1024: up to 4 columns per thread
+    for (int q = 0; q < rows; ++q) r += lds[q * n + tid];
+  }
+  float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+  if (n > 256) {
+    for (int q = 0; q < rows; ++q) {
+      if (tid + 256 < n) r1 += lds[q * n + tid + 256];
+      if (tid + 512 < n) r2 += lds[q * n + tid + 512];
+      if (tid + 768 < n) r3 += lds[q * n + tid + 768];
+    }
+  }
+  __syncthreads();
+  if (tid < n) lds[tid] = r;
+  if (n > 256) {
+    if (tid + 256 < n) lds[tid + 256] = r1;
+    if (tid + 512 < n) lds[tid + 512] = r2;
+    if (tid + 768 < n) lds[tid + 768] = r3;
+  }
+  __syncthreads();
+}
+
 // grid (nchunks, B), block 256.  x [B][S][C]; sums [B][C][3] must be zero on entry.
-template <typename T>
-__global__ void instnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, float* __restrict__ ws, long long S,
-                                      int C, int rows_per_block) {
+template <typename T, int VW>
+__global__ void __launch_bounds__(256) instnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, float* __restrict__ ws, long long S,
+                                                              int C, int rows_per_block) {
   extern __shared__ float red[];   // [rowgroups][C][2]
   const int b = blockIdx.y;
-  const int cv = C / 4;                       // vectors per row
+  const int cv = C / VW;                      // vectors per row
   const int tid = threadIdx.x;
   const int v = tid % cv, rg = tid / cv, nrg = blockDim.x / cv;
   const T* xb = x + (long long)b * S * C;
-  float4 shift = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 a1 = shift, a2 = shift;
+  float shift[VW], a1[VW], a2[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) { shift[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; }
   if (rg < nrg) {
-    shift = Vec4<T>::load(xb + v * 4);
+    ldv<T, VW>(xb + v * VW, shift);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > S) r1 = S;
-    for (long long r = r0 + rg; r < r1; r += nrg) {
-      float4 t = Vec4<T>::load(xb + r * C + v * 4);
-      t.x -= shift.x; t.y -= shift.y; t.z -= shift.z; t.w -= shift.w;
-      a1.x += t.x; a1.y += t.y; a1.z += t.z; a1.w += t.w;
-      a2.x += t.x * t.x; a2.y += t.y * t.y; a2.z += t.z * t.z; a2.w += t.w * t.w;
+    long long r = r0 + rg;
+    for (; r + nrg < r1; r += 2 * nrg) {       // two rows per step: both loads in flight
+      float t[VW], u[VW];
+      ldv<T, VW>(xb + r * C + v * VW, t);
+      ldv<T, VW>(xb + (r + nrg) * C + v * VW, u);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        t[k] -= shift[k]; u[k] -= shift[k];
+        a1[k] += t[k] + u[k];
+        a2[k] += t[k] * t[k] + u[k] * u[k];
+      }
     }
-    float* dst = red + ((long long)rg * C + v * 4) * 2;
-    dst[0] = a1.x; dst[1] = a2.x; dst[2] = a1.y; dst[3] = a2.y; dst[4] = a1.z; dst[5] = a2.z; dst[6] = a1.w; dst[7] = a2.w;
+    if (r < r1) {
+      float t[VW];
+      ldv<T, VW>(xb + r * C + v * VW, t);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) { t[k] -= shift[k]; a1[k] += t[k]; a2[k] += t[k] * t[k]; }
+    }
+    float* dst = red + ((long long)rg * C + v * VW) * 2;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { dst[2 * k] = a1[k]; dst[2 * k + 1] = a2[k]; }
   }
   __syncthreads();
   for (int i = tid; i < C * 2; i += blockDim.x) {
@@ -148,41 +271,77 @@ __global__ void instnorm_apply_kernel(const T* __restrict__ x, const float* __re
 }
 
 // The same with the channel statistics hoisted out of the loop: grid (blocks, B) and a loop stride that is a multiple of the
-// channel count (C | 1024), so a thread meets one channel quad only.  The kernel above recomputes 4 in_stat()s (12 loads, 4
+// channel count (C | 256 VW), so a thread meets one channel vector only.  The kernel above recomputes 4 in_stat()s (12 loads, 4
 // rsqrt) and two 64-bit divisions per 4 elements, which made it VALU-bound at 3 TB/s.
-template <typename T>
-__global__ void __launch_bounds__(256) instnorm_apply_fixedc_kernel(const T* __restrict__ x, const float* __restrict__ sums,
+// FOLD: `sums` holds only the shifts; the sums themselves are folded here from the statistics kernel's partials `ws`
+// [B][nchunks][2 C] and published to `sums` by workgroup 0 of each sample (see in_fold_parts).
+template <typename T, int VW, bool FOLD>
+__global__ void __launch_bounds__(256) instnorm_apply_fixedc_kernel(const T* __restrict__ x, float* __restrict__ sums,
                                                                     const T* __restrict__ res, T* __restrict__ y, long long S,
                                                                     int C, int act, float slope, float p, uint64_t seed,
-                                                                    const uint64_t* step) {
+                                                                    const uint64_t* step, const float* __restrict__ ws, int nchunks) {
+  __shared__ float fold[FOLD ? IN_FOLD_LDS : 1];
   const int b = blockIdx.y;
-  const long long per_b = S * C / 4;
+  const long long per_b = S * C / VW;
   const float invS = 1.f / (float)S;
   const DropCfg dc = make_drop(p, seed, step);
-  const int c = (threadIdx.x * 4) % C;
-  float mean[4], rstd[4];
+  const int c = (threadIdx.x * VW) % C;
+  float mean[VW], rstd[VW];
+  if constexpr (FOLD) {
+    in_fold_parts(ws + (long long)b * nchunks * C * 2, nchunks, C * 2, fold, threadIdx.x);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
-    mean[k] = st.mean; rstd[k] = st.rstd;
+    for (int k = 0; k < VW; ++k) {
+      const float m1 = fold[(c + k) * 2] * invS;
+      const float var = fmaxf(fold[(c + k) * 2 + 1] * invS - m1 * m1, 0.f);
+      mean[k] = sums[((long long)b * C + c + k) * 3] + m1;
+      rstd[k] = rsqrtf(var + IN_EPS);
+    }
+    if (blockIdx.x == 0)
+      for (int i = threadIdx.x; i < 2 * C; i += 256) sums[((long long)b * C + (i >> 1)) * 3 + 1 + (i & 1)] = fold[i];
+  } else {
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
+      mean[k] = st.mean; rstd[k] = st.rstd;
+    }
   }
   const long long base = (long long)b * per_b;
-  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < per_b; j += (long long)gridDim.x * 256) {
-    const long long i = base + j;
-    const float4 v = Vec4<T>::load(x + i * 4);
-    float4 o;
+  const long long stride = (long long)gridDim.x * 256;
+  auto one = [&](long long i, const float (&v)[VW], const float (&r)[VW]) {
+    float o[VW], mk[VW];
+    dropmaskv<VW>(dc, i * VW, mk);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float h = (f4at(v, k) - mean[k]) * rstd[k];
+    for (int k = 0; k < VW; ++k) {
+      float h = (v[k] - mean[k]) * rstd[k];
       if (act == LTU_ACT_LRELU) h = h > 0.f ? h : h * slope;
-      f4at(o, k) = h;
+      o[k] = h * mk[k] + r[k];
     }
-    o = drop4(dc, (uint64_t)i, o);
-    if (res) {
-      const float4 r = Vec4<T>::load(res + i * 4);
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    stv<T, VW>(y + i * VW, o);
+  };
+  long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; j + stride < per_b; j += 2 * stride) {          // two vectors per step: their loads are in flight together
+    const long long i0 = base + j, i1 = i0 + stride;
+    float v0[VW], v1[VW], r0[VW], r1[VW];
+    ldv<T, VW>(x + i0 * VW, v0);
+    ldv<T, VW>(x + i1 * VW, v1);
+    if (res) { ldv<T, VW>(res + i0 * VW, r0); ldv<T, VW>(res + i1 * VW, r1); }
+    else {
+#pragma unroll
+      for (int k = 0; k < VW; ++k) { r0[k] = 0.f; r1[k] = 0.f; }
     }
-    Vec4<T>::store(y + i * 4, o);
+    one(i0, v0, r0);
+    one(i1, v1, r1);
+  }
+  if (j < per_b) {
+    const long long i0 = base + j;
+    float v0[VW], r0[VW];
+    ldv<T, VW>(x + i0 * VW, v0);
+    if (res) ldv<T, VW>(res + i0 * VW, r0);
+    else {
+#pragma unroll
+      for (int k = 0; k < VW; ++k) r0[k] = 0.f;
+    }
+    one(i0, v0, r0);
   }
 }
 
@@ -196,81 +355,101 @@ __device__ __forceinline__ float4 load_grad3(const T* __restrict__ dy, const T* 
   return g;
 }
 
-template <typename T>
+// FOLD: bsums are folded here from the partials of instnorm_bwd_stats_kernel (see in_fold_parts) and published by workgroup 0
+template <typename T, int VW, bool FOLD>
 __global__ void __launch_bounds__(256) instnorm_bwd_apply_fixedc_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                                         const T* __restrict__ dy3, const T* __restrict__ x,
                                                                         const float* __restrict__ sums,
-                                                                        const float* __restrict__ bsums, T* __restrict__ dx,
+                                                                        float* __restrict__ bsums, T* __restrict__ dx,
                                                                         long long S, int C, int act, float slope, float p,
-                                                                        uint64_t seed, const uint64_t* step) {
+                                                                        uint64_t seed, const uint64_t* step, const float* __restrict__ ws,
+                                                                        int nchunks) {
+  __shared__ float fold[FOLD ? IN_FOLD_LDS : 1];
   const int b = blockIdx.y;
-  const long long per_b = S * C / 4;
+  const long long per_b = S * C / VW;
   const float invS = 1.f / (float)S;
   const DropCfg dc = make_drop(p, seed, step);
-  const int c = (threadIdx.x * 4) % C;
-  float mean[4], rstd[4], b0[4], b1[4];
+  const int c = (threadIdx.x * VW) % C;
+  float mean[VW], rstd[VW], b0[VW], b1[VW];
+  if constexpr (FOLD) {
+    in_fold_parts(ws + (long long)b * nchunks * C * 2, nchunks, C * 2, fold, threadIdx.x);
+    if (blockIdx.x == 0)
+      for (int i = threadIdx.x; i < 2 * C; i += 256) bsums[(long long)b * C * 2 + i] = fold[i];
+  }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < VW; ++k) {
     const InStat st = in_stat(sums + ((long long)b * C + c + k) * 3, invS);
     mean[k] = st.mean; rstd[k] = st.rstd;
-    b0[k] = bsums[((long long)b * C + c + k) * 2] * invS;
-    b1[k] = bsums[((long long)b * C + c + k) * 2 + 1] * invS;
+    if constexpr (FOLD) {
+      b0[k] = fold[(c + k) * 2] * invS;
+      b1[k] = fold[(c + k) * 2 + 1] * invS;
+    } else {
+      b0[k] = bsums[((long long)b * C + c + k) * 2] * invS;
+      b1[k] = bsums[((long long)b * C + c + k) * 2 + 1] * invS;
+    }
   }
   const long long base = (long long)b * per_b;
   for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < per_b; j += (long long)gridDim.x * 256) {
     const long long i = base + j;
-    const float4 xv = Vec4<T>::load(x + i * 4);
-    const float4 g = load_grad3<T>(dy, dy2, dy3, i * 4);
-    const float4 mk = dropmask4(dc, (uint64_t)i);
-    float4 o;
+    float xv[VW], g[VW], mk[VW], o[VW];
+    ldv<T, VW>(x + i * VW, xv);
+    load_gradv<T, VW>(dy, dy2, dy3, i * VW, g);
+    dropmaskv<VW>(dc, i * VW, mk);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float h = (f4at(xv, k) - mean[k]) * rstd[k];
-      float gg = f4at(g, k) * f4at(mk, k);
+    for (int k = 0; k < VW; ++k) {
+      const float h = (xv[k] - mean[k]) * rstd[k];
+      float gg = g[k] * mk[k];
       if (act == LTU_ACT_LRELU && h <= 0.f) gg *= slope;
-      f4at(o, k) = rstd[k] * (gg - b0[k] - h * b1[k]);
+      o[k] = rstd[k] * (gg - b0[k] - h * b1[k]);
     }
-    Vec4<T>::store(dx + i * 4, o);
+    stv<T, VW>(dx + i * VW, o);
   }
 }
 
 // backward reductions: bsums[b][c][2] += { sum g, sum g*xhat },  g = dy*mask*act'(xhat)
-template <typename T>
-__global__ void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3,
+template <typename T, int VW>
+__global__ void __launch_bounds__(256) instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3,
                                           const T* __restrict__ x, const float* __restrict__ sums,
                                           float* __restrict__ bsums, float* __restrict__ ws, long long S, int C,
                                           int rows_per_block, int act, float slope, float p, uint64_t seed, const uint64_t* step) {
   extern __shared__ float red[];
   const int b = blockIdx.y;
-  const int cv = C / 4;
+  const int cv = C / VW;
   const int tid = threadIdx.x;
   const int v = tid % cv, rg = tid / cv, nrg = blockDim.x / cv;
   const float invS = 1.f / (float)S;
   const DropCfg dc = make_drop(p, seed, step);
-  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
-  if (rg < nrg) {
-    InStat st[4];
+  float a1[VW], a2[VW];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) st[k] = in_stat(sums + ((long long)b * C + v * 4 + k) * 3, invS);
+  for (int k = 0; k < VW; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
+  if (rg < nrg) {
+    float mean[VW], rstd[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const InStat st = in_stat(sums + ((long long)b * C + v * VW + k) * 3, invS);
+      mean[k] = st.mean; rstd[k] = st.rstd;
+    }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > S) r1 = S;
     for (long long r = r0 + rg; r < r1; r += nrg) {
-      const long long e = ((long long)b * S + r) * C + v * 4;
-      const float4 xv = Vec4<T>::load(x + e);
-      float4 g = load_grad3<T>(dy, dy2, dy3, e);
-      const float4 mk = dropmask4(dc, (uint64_t)(e >> 2));
+      const long long e = ((long long)b * S + r) * C + v * VW;
+      float xv[VW], g[VW], mk[VW];
+      ldv<T, VW>(x + e, xv);
+      load_gradv<T, VW>(dy, dy2, dy3, e, g);
+      dropmaskv<VW>(dc, e, mk);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float h = (f4at(xv, k) - st[k].mean) * st[k].rstd;
-        float gg = f4at(g, k) * f4at(mk, k);
+      for (int k = 0; k < VW; ++k) {
+        const float h = (xv[k] - mean[k]) * rstd[k];
+        float gg = g[k] * mk[k];
         if (act == LTU_ACT_LRELU && h <= 0.f) gg *= slope;
-        f4at(a1, k) += gg;
-        f4at(a2, k) += gg * h;
+        a1[k] += gg;
+        a2[k] += gg * h;
       }
     }
-    float* dst = red + ((long long)rg * C + v * 4) * 2;
-    dst[0] = a1.x; dst[1] = a2.x; dst[2] = a1.y; dst[3] = a2.y; dst[4] = a1.z; dst[5] = a2.z; dst[6] = a1.w; dst[7] = a2.w;
+    float* dst = red + ((long long)rg * C + v * VW) * 2;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { dst[2 * k] = a1[k]; dst[2 * k + 1] = a2[k]; }
   }
   __syncthreads();
   for (int i = tid; i < C * 2; i += blockDim.x) {
@@ -468,21 +647,36 @@ static int stats_rows(long long S, int B, int* nchunks) {
   return (int)rows;
 }
 
-extern "C" int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s) {
-  if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
-  int nchunks;
-  const int rows = stats_rows(S, B, &nchunks);
-  const int block = 256;
-  const int nrg = block / (C / 4);
-  if (nrg < 1) return LTU_E_SHAPE;
-  const size_t lds = (size_t)nrg * C * 2 * sizeof(float);
-  LTU_DISPATCH_T(dtype, {
-    if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
-    hipLaunchKernelGGL((instnorm_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)x, sums, ws, S, C, rows);
-    if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, sums, nullptr, 1, (hipStream_t)s);
-  });
-  return ltu_check_launch();
+// vector width of the InstanceNorm kernels.  8 elements (16 bytes of bf16) is built and tested but OFF: at 34 / 17 / 4 MB the
+// statistics pass took 12.7 / 11.2 / 2.6 us against 6.5 / 4.9 / 1.3 (half the loop trips, the same epilogue) and the three-tensor
+// backward 41 / 32 / 13.5 against 37 / 25 / 12 (tools/sweep_in.sh): these passes already stream at 4-5 TB/s at 8 bytes per lane.
+static int in_vw(int dtype, int C) {
+  return (dtype == LTU_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 && ltu_knob("LTU_IN_VW8", 0)) ? 8 : 4;
 }
+// Second stage folded by the apply kernel (in_fold_parts): chunk count per sample such that the partials of a sample stay within
+// IN_FOLD_MAX floats.  Returns false when the shape does not qualify (the two-stage path with its own fold launch runs then).
+static bool in_fold_plan(long long S, int B, int C, int vw, const float* ws, int* nchunks, int* rows) {
+  // OFF by default (LTU_IN_FOLD=1 enables): measured per tensor size 34 / 17 / 4 / 1 MB (tools/sweep_in.sh), forward 25.0 / 19.2 /
+  // 11.5 / 7.3 us against 27.9 / 20.3 / 10.2 / 8.0 with the fold launch, backward 40.1 / 29.6 / 15.4 / 9.4 against 36.8 / 25.5 / 11.8 /
+  // 10.1: bounding the partials to a few KB per sample leaves the statistics kernels 4x fewer workgroups, which costs the
+  // mid-sized tensors and the heavier backward statistics more than the 5 us launch this removes.
+  if (ws == nullptr || !ltu_knob("LTU_IN_FOLD", 0)) return false;
+  if ((256 * vw) % C != 0 || 2 * C > IN_FOLD_LDS || C < 4) return false;
+  long long want = IN_FOLD_MAX / (2 * C);
+  const long long cap = ltu_knob_pos("LTU_IN_CHUNKS", 2048) / (B > 0 ? B : 1);
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  long long r = (S + want - 1) / want;
+  if (r < 64) r = 64;
+  *nchunks = (int)((S + r - 1) / r);
+  *rows = (int)r;
+  return (long long)*nchunks * B * C * 2 <= LTU_NORM_WS_FLOATS;
+}
+#define IN_DISPATCH_VW(vw, ...)                    \
+  do {                                             \
+    if ((vw) == 8) { constexpr int VW = 8; __VA_ARGS__ } \
+    else { constexpr int VW = 4; __VA_ARGS__ }     \
+  } while (0)
 
 static unsigned stream_grid(long long nvec) {
   long long blocks = (nvec + 255) / 256;
@@ -491,26 +685,74 @@ static unsigned stream_grid(long long nvec) {
   return (unsigned)blocks;
 }
 
-static unsigned per_sample_grid(long long nvec_per_sample, int B) {
+static unsigned per_sample_grid(long long nvec_per_sample, int B, int total = 4096) {
   long long blocks = (nvec_per_sample + 255) / 256;
-  const long long cap = 4096 / (B > 0 ? B : 1) > 1 ? 4096 / (B > 0 ? B : 1) : 1;
+  const long long cap = total / (B > 0 ? B : 1) > 1 ? total / (B > 0 ? B : 1) : 1;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
+}
+
+template <typename T, int VW>
+static void launch_in_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int nchunks, int rows, hipStream_t st) {
+  const size_t lds = (size_t)(256 / (C / VW)) * C * 2 * sizeof(float);
+  hipLaunchKernelGGL((instnorm_stats_kernel<T, VW>), dim3(nchunks, B), dim3(256), lds, st, (const T*)x, sums, ws, S, C, rows);
+}
+template <typename T, int VW, bool FOLD>
+static void launch_in_apply(const void* x, float* sums, const void* res, void* y, int B, long long S, int C, int act, float slope, float p,
+                            uint64_t seed, const uint64_t* step, const float* ws, int nchunks, hipStream_t st) {
+  const unsigned gx = per_sample_grid(S * C / VW, B, FOLD ? ltu_knob_pos("LTU_IN_FOLD_BLOCKS", 2048) : 4096);
+  hipLaunchKernelGGL((instnorm_apply_fixedc_kernel<T, VW, FOLD>), dim3(gx, B), dim3(256), 0, st, (const T*)x, sums, (const T*)res, (T*)y,
+                     S, C, act, slope, p, seed, step, ws, nchunks);
+}
+
+extern "C" int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s) {
+  if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  int nchunks;
+  const int rows = stats_rows(S, B, &nchunks);
+  const int vw = in_vw(dtype, C);
+  LTU_DISPATCH_T(dtype, {
+    if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
+    IN_DISPATCH_VW(vw, { launch_in_stats<T, VW>(x, sums, ws, B, S, C, nchunks, rows, (hipStream_t)s); });
+    if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, sums, nullptr, 1, (hipStream_t)s);
+  });
+  return ltu_check_launch();
 }
 
 extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C,
                                   int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 != 0) return LTU_E_SHAPE;
   const long long nvec = (long long)B * S * C / 4;
-  const bool fixedc = 1024 % C == 0;           // the loop stride (256 vectors) is then a multiple of the channel count
+  const int vw = (256 * in_vw(dtype, C)) % C == 0 ? in_vw(dtype, C) : 4;
+  const bool fixedc = (256 * vw) % C == 0;     // the loop stride (256 vectors) is then a multiple of the channel count
   LTU_DISPATCH_T(dtype, {
     if (fixedc)
-      hipLaunchKernelGGL((instnorm_apply_fixedc_kernel<T>), dim3(per_sample_grid(S * C / 4, B), B), dim3(256), 0, (hipStream_t)s,
-                         (const T*)x, sums, (const T*)res, (T*)y, S, C, act, slope, p, seed, step);
+      IN_DISPATCH_VW(vw, {
+        launch_in_apply<T, VW, false>(x, const_cast<float*>(sums), res, y, B, S, C, act, slope, p, seed, step, nullptr, 0, (hipStream_t)s);
+      });
     else
       hipLaunchKernelGGL((instnorm_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)x, sums,
                          (const T*)res, (T*)y, S, C, B, act, slope, p, seed, step);
+  });
+  return ltu_check_launch();
+}
+
+// statistics + apply in one call: sums [B][C][3] (zero on entry) receives the statistics for the backward pass.  When the shape
+// qualifies the statistics kernel's partials are folded by the apply kernel itself (no fold launch in between).
+extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const void* res, void* y, int B, long long S, int C, int act,
+                                float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+  if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  const int vw = in_vw(dtype, C);
+  int nchunks = 0, rows = 0;
+  if (!in_fold_plan(S, B, C, vw, ws, &nchunks, &rows)) {
+    const int rc = ltu_instnorm_stats(x, sums, ws, B, S, C, dtype, s);
+    return rc != LTU_OK ? rc : ltu_instnorm_apply(x, sums, res, y, B, S, C, act, slope, p, seed, step, dtype, s);
+  }
+  LTU_DISPATCH_T(dtype, {
+    IN_DISPATCH_VW(vw, {
+      launch_in_stats<T, VW>(x, sums, ws, B, S, C, nchunks, rows, (hipStream_t)s);
+      launch_in_apply<T, VW, true>(x, sums, res, y, B, S, C, act, slope, p, seed, step, ws, nchunks, (hipStream_t)s);
+    });
   });
   return ltu_check_launch();
 }
@@ -520,25 +762,33 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3
                                 long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype,
                                 ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
-  int nchunks;
-  const int rows = stats_rows(S, B, &nchunks);
-  const int block = 256;
-  const int nrg = block / (C / 4);
-  if (nrg < 1) return LTU_E_SHAPE;
-  const size_t lds = (size_t)nrg * C * 2 * sizeof(float);
+  const int vw = in_vw(dtype, C);
+  int nchunks = 0, rows = 0;
+  const bool fold = in_fold_plan(S, B, C, vw, ws, &nchunks, &rows);
+  if (!fold) rows = stats_rows(S, B, &nchunks);
   const long long nvec = (long long)B * S * C / 4;
+  hipStream_t st = (hipStream_t)s;
   LTU_DISPATCH_T(dtype, {
-    if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
-    hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T>), dim3(nchunks, B), dim3(block), lds, (hipStream_t)s, (const T*)dy,
-                       (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
-    if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, bsums, nullptr, 0, (hipStream_t)s);
-    if (1024 % C == 0)
-      hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T>), dim3(per_sample_grid(S * C / 4, B), B), dim3(256), 0,
-                         (hipStream_t)s, (const T*)dy, (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope,
-                         p, seed, step);
-    else
-      hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)s, (const T*)dy,
-                         (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
+    if (!fold && (long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
+    IN_DISPATCH_VW(vw, {
+      const size_t lds = (size_t)(256 / (C / VW)) * C * 2 * sizeof(float);
+      hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T, VW>), dim3(nchunks, B), dim3(256), lds, st, (const T*)dy, (const T*)dy2,
+                         (const T*)dy3, (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
+      if (fold) {
+        hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T, VW, true>),
+                           dim3(per_sample_grid(S * C / VW, B, ltu_knob_pos("LTU_IN_FOLD_BLOCKS", 2048)), B), dim3(256), 0, st, (const T*)dy,
+                           (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope, p, seed, step, ws, nchunks);
+      } else {
+        if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, bsums, nullptr, 0, st);
+        if ((256 * VW) % C == 0)
+          hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T, VW, false>), dim3(per_sample_grid(S * C / VW, B), B), dim3(256), 0, st,
+                             (const T*)dy, (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope, p, seed, step,
+                             nullptr, 0);
+        else
+          hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, st, (const T*)dy,
+                             (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, B, act, slope, p, seed, step);
+      }
+    });
   });
   return ltu_check_launch();
 }

@@ -838,9 +838,9 @@ class _InstNormAct(torch.autograd.Function):
         S = x.numel() // (B * C)
         sums = lc.scratch_zeros((B, C, 3), x.device)
         dt = _dt(x)
-        _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(lc.norm_ws(x.device)), B, S, C, dt, _s())
         y = torch.empty_like(x)
-        _lib.call('ltu_instnorm_apply', _p(x), _p(sums), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed, lc.step_ptr(), dt, _s())
+        _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(lc.norm_ws(x.device)), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed,
+                  lc.step_ptr(), dt, _s())
         ctx.save_for_backward(x, sums)
         ctx.cfg = (act, p, seed, res is not None, res_dup is not None)
         return _ports(y, fork)

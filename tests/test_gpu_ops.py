@@ -301,6 +301,56 @@ def test_instnorm_act(ops, C, with_res):
         assert rel_err(from_cl(rd.grad), rr.grad) < 1e-6
 
 
+@pytest.fixture(params=['two_stage', 'fold_in_apply', 'vw8'])
+def instnorm_variant(request):
+    """the InstanceNorm launch variants behind run-time knobs (ltu_config_set): the default, the apply kernels folding the
+    statistics partials themselves (no fold launch), 16-byte bf16 vectors"""
+    from lintransunet_amd import _lib
+    knob = {'two_stage': None, 'fold_in_apply': b'LTU_IN_FOLD', 'vw8': b'LTU_IN_VW8'}[request.param]
+    if knob:
+        _lib.call('ltu_config_set', knob, 1, 0)
+    yield request.param
+    if knob:
+        _lib.call('ltu_config_set', knob, 0, 1)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,S,C', [(2, 8 * 8 * 8, 256), (2, 37 * 11 * 3, 16), (1, 64 * 64 * 32, 16), (2, 20 * 13 * 8, 64), (3, 4097, 8),
+                                   (2, 1000, 4), (2, 70, 128)])
+def test_instnorm_fwd_one_call(ops, instnorm_variant, dtype, B, S, C):
+    """ltu_instnorm_fwd (statistics + apply in one call; with LTU_IN_FOLD an apply kernel that folds the partial sums itself)
+    against the separate ltu_instnorm_stats / ltu_instnorm_apply calls (own fold launch) and a torch fp32 reference; the published
+    statistics feed ltu_instnorm_bwd, whose apply kernel folds its partials the same way: checked against autograd"""
+    from lintransunet_amd import _lib
+    g = G(41)
+    x = (torch.randn(B, S, C, generator=g) * 2 + 0.7).to(DEV).to(dtype)
+    res = torch.randn(B, S, C, generator=g).to(DEV).to(dtype)
+    dt = 0 if dtype == torch.float32 else 1
+    ws = torch.empty(_lib.load().ltu_norm_ws_floats(), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    s1, s2 = torch.zeros(B, C, 3, device=DEV), torch.zeros(B, C, 3, device=DEV)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    _lib.call('ltu_instnorm_stats', x.data_ptr(), s1.data_ptr(), ws.data_ptr(), B, S, C, dt, st)
+    _lib.call('ltu_instnorm_apply', x.data_ptr(), s1.data_ptr(), res.data_ptr(), y1.data_ptr(), B, S, C, 1, 0.01, 0.0, 0, 0, dt, st)
+    _lib.call('ltu_instnorm_fwd', x.data_ptr(), s2.data_ptr(), ws.data_ptr(), res.data_ptr(), y2.data_ptr(), B, S, C, 1, 0.01, 0.0, 0, 0, dt, st)
+    assert torch.equal(s1[..., 0], s2[..., 0])
+    assert rel_err(s2, s1) < 1e-5
+    xr = x.float().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr.transpose(1, 2), eps=1e-5), 0.01).transpose(1, 2) + res.float()
+    tol = 1e-4 if dtype == torch.float32 else 6e-3
+    assert rel_err(y2.float(), yr) < tol and rel_err(y2.float(), y1.float()) < (1e-5 if dtype == torch.float32 else 3e-3)
+    go = torch.randn(B, S, C, generator=g).to(DEV).to(dtype)
+    yr.backward(go.float())
+    bs, dx = torch.zeros(B, C, 2, device=DEV), torch.empty_like(x)
+    _lib.call('ltu_instnorm_bwd', go.data_ptr(), 0, 0, x.data_ptr(), s2.data_ptr(), bs.data_ptr(), ws.data_ptr(), dx.data_ptr(), B, S, C, 1,
+              0.01, 0.0, 0, 0, dt, st)
+    assert rel_err(dx.float(), xr.grad) < (2e-4 if dtype == torch.float32 else 8e-3)
+    xh = (x.float() - x.float().mean(1, keepdim=True)) * torch.rsqrt(x.float().var(1, unbiased=False, keepdim=True) + 1e-5)
+    gg = go.float() * torch.where(xh > 0, 1.0, 0.01)
+    want = torch.stack((gg.sum(1), (gg * xh).sum(1)), -1)
+    assert rel_err(bs, want) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
 def test_res_layernorm(ops, d):
     g = G(6)

@@ -36,10 +36,11 @@ def inorm(B, S, C):
     st = lambda: _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(WS), B, S, C, 1, _s())
     ap = lambda: _lib.call('ltu_instnorm_apply', _p(x), _p(sums), 0, _p(y), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
     bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), 0, 0, _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
-    t1, t2, t3 = timed(st), timed(ap), timed(bw)
+    fw = lambda: _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(WS), 0, _p(y), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
+    t1, t2, t3, t4 = timed(st), timed(ap), timed(bw), timed(fw)
     mb = B * S * C * 2 / 1e6
     print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.1f} TB/s)  apply {t2:6.1f} us ({2 * mb / t2:.1f} TB/s)  '
-          f'bwd(stats+apply) {t3:6.1f} us ({5 * mb / t3:.1f} TB/s)', flush=True)
+          f'fwd(stats+apply, one call) {t4:6.1f} us ({3 * mb / t4:.1f} TB/s)  bwd(stats+apply) {t3:6.1f} us ({5 * mb / t3:.1f} TB/s)', flush=True)
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
