@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     // PACK: pair wave + 4 i = taps 2 (wave + 4 i) (columns 0..15) and + 1 (columns 16..31; tap 27 does not exist: clamped, dropped)
-    const int tap = PACK ? min(2 * (wave + 4 * i) + ((lane >> 4) & 1), 26) : wave + 4 * i;
+    const int tap = PACK ? min(2 * (wave + 4 * i) + ((lane >> 4) & 1), 26) : min(wave + 4 * i, 26);
     tapoff[i] = (((tap / 9) * HALO_W + (tap / 3) % 3) * HALO_D + tap % 3) * LDWH;
   }
   // transposing-read lane geometry (see wgrad_tn_bf16_kernel): lane -> (row trow (+4), columns tcol..tcol+3) of a 16-row slab
@@ -812,7 +812,12 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
   // slab ks covers brick rows 16ks..16ks+15 = (h = ks>>1, w = 2(ks&1) + (row>>3), d = row&7)
   const int hbase = ((gq >> 1) * HALO_D + tq) * LDWH + (PACK ? 4 * tp : tcol);
 
+  // Global loads are UNCONDITIONAL (clamped address; padding is selected to zero when the registers go to LDS): with a test around
+  // each load hipcc gives it a basic block of its own and waits for the earlier ones there (the ISA of the first version shows
+  // vmcnt(0) between the pieces of one brick), so the prefetch of the next brick was a chain of round trips in front of the MFMAs
+  // instead of eight loads in flight behind them.
   uint4 hreg[6], greg[2];
+  unsigned hin = 0, gin = 0;
   auto load_brick = [&](int brick) {
     int t = brick;
     const int bd = t % nbd; t /= nbd;
@@ -820,37 +825,34 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
     const int bh = t % nbh;
     const int b = t / nbh;
     const int h0 = bh * 4, w0 = bw * 4, d0 = bd * 8;
+    hin = 0; gin = 0;
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
       const int idx = tid + p * 256;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (idx < HALO_VOX * VPV) {
-        const int hv = idx / VPV, part = idx - hv * VPV;
-        const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
-        const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
-        const int c = chunk * a.CC + part * 8;
-        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C) {
-          const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
-          const uint16_t* src = c < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + c
-                                         : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (c - a.c0);
-          v = *reinterpret_cast<const uint4*>(src);
-        }
-      }
-      hreg[p] = v;
+      const int hv = idx / VPV, part = idx - hv * VPV;
+      const int hd = hv % HALO_D, hw = (hv / HALO_D) % HALO_W, hh = hv / (HALO_D * HALO_W);
+      const int h = h0 - 1 + hh, w = w0 - 1 + hw, d = d0 - 1 + hd;
+      const int c = chunk * a.CC + part * 8;
+      const bool in = idx < HALO_VOX * VPV && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && (unsigned)d < (unsigned)a.D && c < a.C;
+      const long long vox = in ? (((long long)b * a.H + h) * a.W + w) * a.D + d : 0;
+      const int cc = in ? c : 0;
+      const uint16_t* src = cc < a.c0 ? reinterpret_cast<const uint16_t*>(a.x0) + vox * a.lda0 + cc
+                                      : reinterpret_cast<const uint16_t*>(a.x1) + vox * a.lda1 + (cc - a.c0);
+      hreg[p] = *reinterpret_cast<const uint4*>(src);
+      hin |= in ? 1u << p : 0u;
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int idx = tid + p * 256;
       const int row = idx >> 2, n = n_blk + (idx & 3) * 8;
       const int h = h0 + (row >> 5), w = w0 + ((row >> 3) & 3), d = d0 + (row & 7);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (h < a.H && w < a.W && d < a.D && n < a.N) {
-        const long long vox = (((long long)b * a.H + h) * a.W + w) * a.D + d;
-        const uint16_t* gp = (a.grad1 != nullptr && n >= a.gn0) ? reinterpret_cast<const uint16_t*>(a.grad1) + vox * a.ldg1 + (n - a.gn0)
-                                                                 : reinterpret_cast<const uint16_t*>(a.grad) + vox * a.ldg + n;
-        v = *reinterpret_cast<const uint4*>(gp);
-      }
-      greg[p] = v;
+      const bool in = h < a.H && w < a.W && d < a.D && n < a.N;
+      const long long vox = in ? (((long long)b * a.H + h) * a.W + w) * a.D + d : 0;
+      const int nn = in ? n : 0;
+      const uint16_t* gp = (a.grad1 != nullptr && nn >= a.gn0) ? reinterpret_cast<const uint16_t*>(a.grad1) + vox * a.ldg1 + (nn - a.gn0)
+                                                                : reinterpret_cast<const uint16_t*>(a.grad) + vox * a.ldg + nn;
+      greg[p] = *reinterpret_cast<const uint4*>(gp);
+      gin |= in ? 1u << p : 0u;
     }
   };
   auto store_brick = [&]() {
@@ -859,13 +861,13 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
       const int idx = tid + p * 256;
       if (idx < HALO_VOX * VPV) {
         const int hv = idx / VPV, part = idx - hv * VPV;
-        *reinterpret_cast<uint4*>(&halo[hv * LDWH + part * 8]) = hreg[p];
+        *reinterpret_cast<uint4*>(&halo[hv * LDWH + part * 8]) = (hin >> p) & 1u ? hreg[p] : make_uint4(0u, 0u, 0u, 0u);
       }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int idx = tid + p * 256;
-      *reinterpret_cast<uint4*>(&Gs[(idx >> 2) * LDGH + (idx & 3) * 8]) = greg[p];
+      *reinterpret_cast<uint4*>(&Gs[(idx >> 2) * LDGH + (idx & 3) * 8]) = (gin >> p) & 1u ? greg[p] : make_uint4(0u, 0u, 0u, 0u);
     }
   };
 
@@ -891,16 +893,17 @@ __global__ void __launch_bounds__(256, PACK ? 3 : 2) conv3_wgrad_halo_bf16_kerne
       ua.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)pg);
       ua.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(pg + 4 * LDGH));
       const int slab = ((ks >> 1) * HALO_W * HALO_D + (ks & 1) * 2 * HALO_D) * LDWH + hbase;
-      if (do_bias) acc[NA - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ones, acc[NA - 1], 0, 0, 0);
+      // no test around the MFMAs (the wave index comes from threadIdx: a divergent branch per MFMA for the compiler, which also
+      // stops it from requesting the operand reads ahead): a slot without a tap reads a clamped tap and is dropped in the epilogue;
+      // wave 3's spare slot takes the tile of ones (bias sums) instead
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        if (wave + 4 * i < (PACK ? 14 : 27)) {
-          union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
-          const uint16_t* px = &halo[slab + tapoff[i]];
-          ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
-          ub.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(px + 4 * LDWH));
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
-        }
+        union { struct { hs16x4 l, h; } s; bf16x8 v; } ub;
+        const uint16_t* px = &halo[slab + tapoff[i]];
+        ub.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)px);
+        ub.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs16x4*)(px + 4 * LDWH));
+        if (i == NA - 1) ub.v = do_bias ? ones : ub.v;
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
       }
     }
   }
