@@ -23,6 +23,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define HALO_VOX (HALO_H * HALO_W * HALO_D)
 #define LDH 40            // LDS row stride in bf16 elements (32 channels + 8 pad = 80 bytes)
 
+template <int WN, int TN, int TS>
+constexpr int halo_smem_bytes() {
+  constexpr int BN = WN * TN * 32;
+  constexpr int be = HALO_VOX * 32 + 2 * TS * BN * LDH, se = 128 * (BN + 8);
+  return 2 * (be > se ? be : se);
+}
 template <int WM, int WN, int TM, int TN, int TS, int CC>
 __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) {
   static_assert(WM * TM == 4 && WM * WN == 4, "128-row brick on 4 waves");
@@ -30,8 +36,7 @@ __global__ void __launch_bounds__(256) conv3_halo_bf16_kernel(const HaloArgs a) 
   constexpr int VPV = CC / 8, KS = CC / 16;               // 16-byte parts per voxel / weight row of one chunk; k-steps per tap
   constexpr int PD = CC == 16 ? 12 : HALO_D, VMASK = VPV - 1;
   constexpr int HALO_ELEMS = HALO_VOX * 32, B_ELEMS = 2 * TS * BN * LDH, LDC = BN + 8, STAGE_ELEMS = 128 * LDC;
-  constexpr int SMEM_ELEMS = (HALO_ELEMS + B_ELEMS) > STAGE_ELEMS ? (HALO_ELEMS + B_ELEMS) : STAGE_ELEMS;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];        // halo_smem_bytes<...>(): the deep-stage variants exceed 64 KB
   // halo image: voxel (hh, hw, hd) at row (hh * HALO_W + hw) * PD + hd, CC elements per row, the 16-byte parts XOR-ed with the
   // low bits of hw (PD = 12 for 32-byte rows): conflict-free ds_read_b128 fragments for every tap (tools/lds_conflicts.py; the
   // padded [360][40] image this kernel started with was a 3-way conflict)
@@ -736,22 +741,41 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   a.cps = cps;
   if (a.ksplit < 2) a.part = nullptr;
   const unsigned gz = (unsigned)a.ksplit;
-#define HALO_LAUNCH(...)                                                                                 \
-  do {                                                                                                   \
-    if (a.CC == 32) hipLaunchKernelGGL((conv3_halo_bf16_kernel<__VA_ARGS__, 32>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((conv3_halo_bf16_kernel<__VA_ARGS__, 16>), grid, dim3(256), 0, st, a);            \
+  // TS = taps per weight stage.  A stage's weights are requested one stage ahead and every stage ends in a barrier: with 3 taps
+  // (12 MFMAs per wave) a stage is shorter than the L2 round trip of the next one's weights.  9 taps per stage (3 for the 128-column
+  // tile; 115 / 84 KB of LDS, dynamic) cover it - worth 11-14 % where a workgroup walks at least four channel chunks
+  // (16x16x64, 128 -> 64: 32.3 -> 28.7 us; 64+64 -> 64: 28.6 -> 24.8); with fewer chunks the larger first stage is exposed instead
+  // (8x8x64, 256 -> 128 split over the chunks: 30.3 -> 36.3; data gradient of 32+32 -> 32: 50 -> 76), so those keep the short stages.
+  const int chunks_per_wg = a.ksplit > 1 ? a.cps : (a.C + a.CC - 1) / a.CC;
+  const bool deep = ltu_knob("LTU_HALO_DEEP", chunks_per_wg >= 4 ? 1 : 0) != 0;
+#define HALO_LAUNCH1(WM, WN, TM, TN, TS, CCV)                                                                        \
+  do {                                                                                                               \
+    auto kern = &conv3_halo_bf16_kernel<WM, WN, TM, TN, TS, CCV>;                                                    \
+    constexpr int bytes = halo_smem_bytes<WN, TN, TS>();                                                            \
+    static LtuDevOnce once;                                                                                          \
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, a);                                                         \
+  } while (0)
+#define HALO_LAUNCH(WM, WN, TM, TN, TS)                     \
+  do {                                                      \
+    if (a.CC == 32) HALO_LAUNCH1(WM, WN, TM, TN, TS, 32);   \
+    else HALO_LAUNCH1(WM, WN, TM, TN, TS, 16);              \
   } while (0)
   if (a.N > 64 && bricks * cdiv(a.N, 128) >= 256) {
     dim3 grid((unsigned)bricks, cdiv(a.N, 128), gz);
-    HALO_LAUNCH(2, 2, 2, 2, 1);
+    if (deep) HALO_LAUNCH(2, 2, 2, 2, 3);
+    else HALO_LAUNCH(2, 2, 2, 2, 1);
   } else if (a.N > 32) {                    // also wide outputs on small grids: 64-column tiles double the workgroup count
     dim3 grid((unsigned)bricks, cdiv(a.N, 64), gz);
-    HALO_LAUNCH(4, 1, 1, 2, 3);
+    if (deep) HALO_LAUNCH(4, 1, 1, 2, 9);
+    else HALO_LAUNCH(4, 1, 1, 2, 3);
   } else {
     dim3 grid((unsigned)bricks, 1, gz);
-    HALO_LAUNCH(4, 1, 1, 1, 3);
+    if (deep) HALO_LAUNCH(4, 1, 1, 1, 9);
+    else HALO_LAUNCH(4, 1, 1, 1, 3);
   }
 #undef HALO_LAUNCH
+#undef HALO_LAUNCH1
   if (a.part != nullptr) {
     const long long M = (long long)a.B * a.H * a.W * a.D;
     long long blocks = (M * (a.N / 4) + 255) / 256;
