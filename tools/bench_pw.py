@@ -42,6 +42,23 @@ def inorm(B, S, C):
     print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.1f} TB/s)  apply {t2:6.1f} us ({2 * mb / t2:.1f} TB/s)  '
           f'fwd(stats+apply, one call) {t4:6.1f} us ({3 * mb / t4:.1f} TB/s)  bwd(stats+apply) {t3:6.1f} us ({5 * mb / t3:.1f} TB/s)', flush=True)
 
+def gate(B, S, C):
+    """attention gate (Unet_3Dblock.py:217-221): forward | backward (reduce + fold + apply)"""
+    u1, u2, skip, out, dout, dskip, du1, du2 = (bf(B, S, C) for _ in range(8))
+    s1, s2 = torch.zeros(B, C, 3, device='cuda'), torch.zeros(B, C, 3, device='cuda')
+    s1[..., 2] = S; s2[..., 2] = S
+    pw, pb = torch.randn(C, device='cuda'), torch.zeros(1, device='cuda')
+    a, ds = torch.empty(B * S, device='cuda'), torch.empty(B * S, device='cuda')
+    dpw, dpb = torch.zeros(C, device='cuda'), torch.zeros(1, device='cuda')
+    b1, b2 = torch.zeros(B, C, 2, device='cuda'), torch.zeros(B, C, 2, device='cuda')
+    f = lambda: _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, 1, _s())
+    bw = lambda: _lib.call('ltu_gate_bwd', _p(dout), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
+                           _p(dpb), _p(b1), _p(b2), _p(WS), _p(du1), _p(du2), B, S, C, 1, _s())
+    tf, tb = timed(f), timed(bw)
+    mb = B * S * C * 2 / 1e6
+    print(f'gate B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): fwd {tf:6.1f} us ({4 * mb / tf:.1f} TB/s)  bwd {tb:6.1f} us ({9 * mb / tb:.1f} TB/s)', flush=True)
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if which in ('all', 'ln'):
@@ -53,3 +70,6 @@ if __name__ == '__main__':
     if which in ('all', 'in'):
         for B, S, C in [(2, 524288, 16), (2, 131072, 32), (2, 16384, 64), (2, 2048, 128)]:
             inorm(B, S, C)
+    if which in ('all', 'gate'):
+        for B, S, C in [(2, 524288, 16), (2, 131072, 32), (2, 16384, 64), (2, 2048, 128)]:
+            gate(B, S, C)
