@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(1024) linattn_kv_combine(const float* __restri
 // The same merge as ONE launch (two dependent 5 us launches were pure latency at every level): grid (8, B*H), block 256.  Workgroup w
 // produces accT rows j = 4w .. 4w+3 (128 elements) from ALL nsplit partials; every workgroup recomputes the 32 column maxima and
 // sums itself (2 x nsplit x 128 B from L2) and keeps the nsplit x 32 rescale factors exp(m_s - m) in LDS.
+template <int NB>
 __global__ void __launch_bounds__(256) linattn_kv_combine1(const float* __restrict__ part, int nsplit, float* __restrict__ stats,
                                                            float* __restrict__ ctx, int H) {
   extern __shared__ __attribute__((aligned(16))) float fs[];       // [nsplit][32]
@@ -356,34 +357,83 @@ __global__ void __launch_bounds__(256) linattn_kv_combine1(const float* __restri
   const float* p0 = part + ((long long)b * nsplit * H + h) * PART_STRIDE;
   const long long sstride = (long long)H * PART_STRIDE;
   const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  float m = -INFINITY;
-#pragma unroll 8
-  for (int s = grp; s < nsplit; s += 8) m = fmaxf(m, p0[s * sstride + l]);
-  red[grp][l] = m;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) m = fmaxf(m, red[q][l]);
-  __syncthreads();
-  float ss = 0.f;
-#pragma unroll 8
-  for (int s = grp; s < nsplit; s += 8) {
-    const float f = __expf(p0[s * sstride + l] - m);
-    fs[s * 32 + l] = f;
-    ss += p0[s * sstride + 32 + l] * f;
-  }
-  red[grp][l] = ss;
-  __syncthreads();                             // also: every factor is in LDS
-  ss = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) ss += red[q][l];          // same order in every thread and workgroup: one value per column
-  // accT slice: thread (grp, l) takes the float4 at element e0 = 128 w + 4 l of splits grp, grp + 8, ...; its 4 columns are 4 (l & 7) ..
+  // Up to 256 splits (32 per thread) the three passes are three BATCHES of loads: the maxima and sums of a thread's splits are
+  // requested together and stay in registers for the rescale factors, then all of its accT quads are requested together.  As three
+  // loops of 8 loads in flight each pass was four dependent L2 round trips (12.7 us at 256 splits for 9 MB).
+  const bool fast = nsplit <= 8 * NB;            // NB = batch depth, chosen by the host from the split count
+  float m = -INFINITY, ss = 0.f;
   const int e0 = blockIdx.x * 128 + l * 4, c0 = e0 & 31;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fast) {
+    float pm[NB], ps[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int sp = grp + 8 * k, sc = sp < nsplit ? sp : 0;
+      pm[k] = p0[sc * sstride + l];
+      ps[k] = p0[sc * sstride + 32 + l];
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (grp + 8 * k < nsplit) m = fmaxf(m, pm[k]);
+    red[grp][l] = m;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m = fmaxf(m, red[q][l]);
+    __syncthreads();
+    float4 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {             // the accT quads: requested before the exponentials below are needed
+      const int sp = grp + 8 * k, sc = sp < nsplit ? sp : 0;
+      v[k] = *reinterpret_cast<const float4*>(p0 + sc * sstride + 64 + e0);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int sp = grp + 8 * k;
+      if (sp < nsplit) {
+        const float f = __expf(pm[k] - m);
+        fs[sp * 32 + l] = f;
+        ss += ps[k] * f;
+      }
+    }
+    red[grp][l] = ss;
+    __syncthreads();                           // also: every factor is in LDS
+    ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ss += red[q][l];        // same order in every thread and workgroup: one value per column
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int sp = grp + 8 * k;
+      if (sp < nsplit) {
+        const float4 f = *reinterpret_cast<const float4*>(fs + sp * 32 + c0);
+        a.x += v[k].x * f.x; a.y += v[k].y * f.y; a.z += v[k].z * f.z; a.w += v[k].w * f.w;
+      }
+    }
+  } else {
 #pragma unroll 8
-  for (int s = grp; s < nsplit; s += 8) {
-    const float4 v = *reinterpret_cast<const float4*>(p0 + s * sstride + 64 + e0);
-    const float4 f = *reinterpret_cast<const float4*>(fs + s * 32 + c0);
-    a.x += v.x * f.x; a.y += v.y * f.y; a.z += v.z * f.z; a.w += v.w * f.w;
+    for (int s = grp; s < nsplit; s += 8) m = fmaxf(m, p0[s * sstride + l]);
+    red[grp][l] = m;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m = fmaxf(m, red[q][l]);
+    __syncthreads();
+#pragma unroll 8
+    for (int s = grp; s < nsplit; s += 8) {
+      const float f = __expf(p0[s * sstride + l] - m);
+      fs[s * 32 + l] = f;
+      ss += p0[s * sstride + 32 + l] * f;
+    }
+    red[grp][l] = ss;
+    __syncthreads();                             // also: every factor is in LDS
+    ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ss += red[q][l];          // same order in every thread and workgroup: one value per column
+    // accT slice: thread (grp, l) takes the float4 at element e0 = 128 w + 4 l of splits grp, grp + 8, ...; its 4 columns are 4 (l & 7) ..
+#pragma unroll 8
+    for (int s = grp; s < nsplit; s += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(p0 + s * sstride + 64 + e0);
+      const float4 f = *reinterpret_cast<const float4*>(fs + s * 32 + c0);
+      a.x += v.x * f.x; a.y += v.y * f.y; a.z += v.z * f.z; a.w += v.w * f.w;
+    }
   }
   if (grp > 0) red4[grp - 1][l] = a;
   // column sums of this thread's 4 columns (threads with l < 8 of group 0 hold all 32 between them after the exchange below)
@@ -1006,7 +1056,11 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
       const int group = KVC_GROUP, ngroups = (nsplit + group - 1) / group;
       float* part2 = part_ws + (size_t)B * nsplit * H * PART_STRIDE;
       if (nsplit * 32 * sizeof(float) <= 48 * 1024 && !ltu_knob("LTU_LA_TWO_LEVEL", 0)) {
-        hipLaunchKernelGGL(linattn_kv_combine1, dim3(8, B * H), dim3(256), (size_t)nsplit * 32 * sizeof(float), st, part_ws, nsplit, colstats, ctx, H);
+        const size_t fsb = (size_t)nsplit * 32 * sizeof(float);
+        if (nsplit <= 32) hipLaunchKernelGGL(linattn_kv_combine1<4>, dim3(8, B * H), dim3(256), fsb, st, part_ws, nsplit, colstats, ctx, H);
+        else if (nsplit <= 64) hipLaunchKernelGGL(linattn_kv_combine1<8>, dim3(8, B * H), dim3(256), fsb, st, part_ws, nsplit, colstats, ctx, H);
+        else if (nsplit <= 128) hipLaunchKernelGGL(linattn_kv_combine1<16>, dim3(8, B * H), dim3(256), fsb, st, part_ws, nsplit, colstats, ctx, H);
+        else hipLaunchKernelGGL(linattn_kv_combine1<32>, dim3(8, B * H), dim3(256), fsb, st, part_ws, nsplit, colstats, ctx, H);
       } else if (ngroups > 1) {
         hipLaunchKernelGGL(linattn_kv_combine, dim3(ngroups, B * H), dim3(1024), 0, st, part_ws, nsplit, group, part2, colstats, ctx, H, 0);
         hipLaunchKernelGGL(linattn_kv_combine, dim3(1, B * H), dim3(1024), 0, st, part2, ngroups, ngroups, nullptr, colstats, ctx, H, 1);
