@@ -582,10 +582,16 @@ __global__ void __launch_bounds__(256) wgroup_fold_kernel(const WFoldArgs fa) {
         cur = *reinterpret_cast<const float4*>(o);
       }
       const float* p = jb.part + e;
-#pragma unroll 4
-      for (int sp = grp; sp < jb.nsplit; sp += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (long long)sp * nk);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      for (int s0 = grp; s0 < jb.nsplit; s0 += 32) {       // 8 splits per thread requested together (one trip up to 32 splits)
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int sp = s0 + 4 * k;
+          v[k] = *reinterpret_cast<const float4*>(p + (long long)(sp < jb.nsplit ? sp : s0) * nk);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s0 + 4 * k < jb.nsplit) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
       }
     }
     if (grp > 0) red[grp - 1][lane64] = acc;

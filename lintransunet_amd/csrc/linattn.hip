@@ -787,16 +787,24 @@ __global__ void __launch_bounds__(2 * D) linattn_dctx_partial(const T* __restric
 // grid (8, B*H), block 256: dctx[bh][i][j] = sum_s partT[s][j][i].  Workgroup w folds partT rows j = 4w .. 4w+3 (32 float4 outputs
 // x 8 thread groups that share the splits).  One workgroup per (sample, head) pulled 0.9 MB through a single CU (8.5 us); the
 // Jacobian term tvec[i] = sum_j dctx[i][j] ctx[i][j] moved into linattn_bwd_apply's prologue (its lanes hold both rows).
+// NB = splits per thread requested together (the host picks it from the split count: one batch up to 8 NB splits)
+template <int NB>
 __global__ void __launch_bounds__(256) linattn_dctx_combine(const float* __restrict__ part, float* __restrict__ dctx, int nsplit, int H) {
   __shared__ float4 red4[7][32];
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const float* p0 = part + ((long long)b * nsplit * H + h) * 1024 + blockIdx.x * 128;
   const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-  for (int s = grp; s < nsplit; s += 8) {
-    const float4 v = *reinterpret_cast<const float4*>(p0 + (long long)s * H * 1024 + l * 4);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  for (int s0 = grp; s0 < nsplit; s0 += 8 * NB) {
+    float4 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int sp = s0 + 8 * k;
+      v[k] = *reinterpret_cast<const float4*>(p0 + (long long)(sp < nsplit ? sp : s0) * H * 1024 + l * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (s0 + 8 * k < nsplit) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
   }
   if (grp > 0) red4[grp - 1][l] = a;
   __syncthreads();
@@ -1099,7 +1107,10 @@ extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* c
       const size_t lds_p = IsBf16<T>::value ? (size_t)4 * TOK * (D + LA_TR_PAD) * 2 + (size_t)2 * TOK * H * 2 * sizeof(float)
                                             : (size_t)(2 * TOK * D + TOK * H * 2) * sizeof(float);
       hipLaunchKernelGGL((linattn_dctx_partial<T, D>), dim3(nsplit, B), dim3(2 * D), lds_p, st, (const T*)qkv, (const T*)dout, qstat, part_ws, N, tps);
-      hipLaunchKernelGGL(linattn_dctx_combine, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
+      if (nsplit <= 32) hipLaunchKernelGGL(linattn_dctx_combine<4>, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
+      else if (nsplit <= 64) hipLaunchKernelGGL(linattn_dctx_combine<8>, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
+      else if (nsplit <= 128) hipLaunchKernelGGL(linattn_dctx_combine<16>, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
+      else hipLaunchKernelGGL(linattn_dctx_combine<32>, dim3(8, B * H), dim3(256), 0, st, part_ws, dctx, nsplit, H);
       hipLaunchKernelGGL((linattn_bwd_apply<T, D>), dim3(cdiv(N, tokb), B), dim3(2 * D), lds_b, st, (const T*)qkv, (const T*)dout, ctx, dctx, colstats, tvec, qstat, (T*)dqkv, N, tokb);
     });
   });

@@ -35,21 +35,34 @@ __device__ __forceinline__ InStat in_stat(const float* sums, float invS) {
 // ([group][part][n]) and this kernel folds them.  mode 0: out[g*n + i];  mode 1 (InstanceNorm sums [B][C][3]):
 // out[(g*n/2 + i/2)*3 + 1 + (i&1)];  mode 2 (LayerNorm): i even -> out[i/2], odd -> out2[i/2].
 #define LTU_NORM_WS_FLOATS (1 << 20)
+// NB = loads per thread, all requested before the first add: as a loop of 4 loads per trip a fold over 1 024 partials was eight
+// dependent L2 round trips - most of the 5 us of a launch that moves a few KB (54 of them per training step).
+template <int NB>
 __global__ void __launch_bounds__(1024) reduce_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out,
                                                             float* __restrict__ out2, int mode) {
   __shared__ float red[32][33];
   const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + el, g = blockIdx.y;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float acc = 0.f;
   if (i < n) {
     const float* p = part + (long long)g * nparts * n + i;
-    int z = zq;
-    for (; z + 96 < nparts; z += 128) {
-      a0 += p[(long long)z * n]; a1 += p[(long long)(z + 32) * n]; a2 += p[(long long)(z + 64) * n]; a3 += p[(long long)(z + 96) * n];
+    for (int z0 = zq; z0 < nparts; z0 += 32 * NB) {         // one trip unless nparts > 32 NB
+      float v[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int z = z0 + 32 * k;
+        v[k] = p[(long long)(z < nparts ? z : z0) * n];
+      }
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const float t = z0 + 32 * k < nparts ? v[k] : 0.f;
+        if ((k & 3) == 0) a0 += t; else if ((k & 3) == 1) a1 += t; else if ((k & 3) == 2) a2 += t; else a3 += t;
+      }
+      acc += (a0 + a1) + (a2 + a3);
     }
-    for (; z < nparts; z += 32) a0 += p[(long long)z * n];
   }
-  red[zq][el] = (a0 + a1) + (a2 + a3);
+  red[zq][el] = acc;
   __syncthreads();
   if (zq != 0 || i >= n) return;
   float v = 0.f;
@@ -62,7 +75,11 @@ __global__ void __launch_bounds__(1024) reduce_parts_kernel(const float* __restr
 }
 static void launch_reduce_parts(const float* part, int nparts, int n, int groups, float* out, float* out2, int mode, hipStream_t st) {
   if (ltu_knob("LTU_DBG_NO_STAGE2", 0)) return;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 32), groups), dim3(1024), 0, st, part, nparts, n, out, out2, mode);
+  const dim3 grid(cdiv(n, 32), groups);
+  if (nparts <= 128) hipLaunchKernelGGL(reduce_parts_kernel<4>, grid, dim3(1024), 0, st, part, nparts, n, out, out2, mode);
+  else if (nparts <= 256) hipLaunchKernelGGL(reduce_parts_kernel<8>, grid, dim3(1024), 0, st, part, nparts, n, out, out2, mode);
+  else if (nparts <= 512) hipLaunchKernelGGL(reduce_parts_kernel<16>, grid, dim3(1024), 0, st, part, nparts, n, out, out2, mode);
+  else hipLaunchKernelGGL(reduce_parts_kernel<32>, grid, dim3(1024), 0, st, part, nparts, n, out, out2, mode);
 }
 extern "C" long long ltu_norm_ws_floats(void) { return LTU_NORM_WS_FLOATS; }
 
@@ -867,6 +884,39 @@ __global__ void __launch_bounds__(1024) reduce_batch_kernel(const ReduceBatch b)
   const int el = threadIdx.x & 31, zq = threadIdx.x >> 5;
   const long long e = (long long)blockIdx.x * 32 + el;
   if ((long long)blockIdx.x * 32 >= total) return;
+  if (jb.mode == 1 && (jb.n & 31) == 0) {
+    // LayerNorm gamma / beta sums of the chain kernels: one partial row per 32-token block, i.e. thousands of splits of a few hundred
+    // floats.  A thread owns a float4 column and every 128th split and requests 8 of them at a time (as 4 scalar loads per trip
+    // the 7 176 splits of the largest level were 56 dependent round trips: 21 us for 7 MB).
+    __shared__ float4 red4[16][8];
+    const int c4 = threadIdx.x & 7, zg = threadIdx.x >> 3;
+    const float* p = jb.part + (long long)blockIdx.x * 32 + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z0 = zg; z0 < jb.nsplit; z0 += 128 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int z = z0 + 128 * k;
+        v[k] = *reinterpret_cast<const float4*>(p + (long long)(z < jb.nsplit ? z : z0) * jb.n);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (z0 + 128 * k < jb.nsplit) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {         // the 8 split groups of a wave
+      acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+    }
+    if ((threadIdx.x & 63) < 8) red4[threadIdx.x >> 6][c4] = acc;
+    __syncthreads();
+    if (threadIdx.x >= 32) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += reinterpret_cast<const float*>(&red4[q][0])[threadIdx.x];
+    float* o = (e & 1) ? jb.out[1] : jb.out[0];
+    o[e >> 1] += v;
+    return;
+  }
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (e < total) {
     const float* p;
