@@ -73,6 +73,26 @@ __device__ __forceinline__ uint4 gather_a8c(const IGemmArgs& g, const Tap* taps,
   return *reinterpret_cast<const uint4*>(p);
 }
 
+// The same as an ADDRESS + validity: the caller loads unconditionally (from g.a0 when there is nothing to read) and selects zero when
+// the registers go to LDS.  With the test around the load (gather_a8c) hipcc gives every load of a tile a basic block of its own
+// and waits for the earlier ones there: the tiles that were meant to be in flight behind the MFMAs arrived one round trip at a time.
+__device__ __forceinline__ const uint16_t* gather_a8c_ptr(const IGemmArgs& g, const Tap* taps, bool row_ok, const RowCoord& rc, const KCur& q,
+                                                          bool& valid) {
+  const bool kin = q.slot < g.ntaps;
+  const Tap tp = taps[kin ? q.slot : 0];
+  int h = rc.h * g.mh + tp.dh, w = rc.w * g.mw + tp.dw, d = rc.d * g.md + tp.dd;
+  valid = row_ok && kin && (unsigned)h < (unsigned)g.sh && (unsigned)w < (unsigned)g.sw && (unsigned)d < (unsigned)g.sd;
+  int ph = g.sh, pw = g.sw, pd = g.sd;
+  if (g.ups) {
+    h >>= 1; w >>= 1; d >>= 1;
+    ph >>= 1; pw >>= 1; pd >>= 1;
+  }
+  const long long vox = valid ? (((long long)rc.b * ph + h) * pw + w) * pd + d : 0;
+  const int c = valid ? q.c : 0;
+  return c < g.c0 ? reinterpret_cast<const uint16_t*>(g.a0) + vox * g.lda0 + c
+                  : reinterpret_cast<const uint16_t*>(g.a1) + vox * g.lda1 + (c - g.c0);
+}
+
 // 8 consecutive bf16 channels of the A operand at (row, k); zero outside the source / beyond K
 __device__ __forceinline__ uint4 gather_a8(const IGemmArgs& g, bool row_ok, const RowCoord& rc, int k) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -175,27 +195,39 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
     }
   }
 
-  // loads the NEXT tile of the K sequence into a register set
-  auto load_tile = [&](uint4 (&ra)[LA], uint4 (&rb)[LB]) {
+  // loads the NEXT tile of the K sequence into a register set; `okm` = which of its vectors are real (bits 0.. A, bits LA.. B)
+  auto load_tile = [&](uint4 (&ra)[LA], uint4 (&rb)[LB], unsigned& okm) {
+    okm = 0;
 #pragma unroll
-    for (int p = 0; p < LA; ++p) ra[p] = (g.dbg & 4) ? make_uint4(1u, 2u, 3u, 4u) : gather_a8c(g, s_tap, rok[p], rc[p], cur);
+    for (int p = 0; p < LA; ++p) {
+      bool valid;
+      const uint16_t* src = gather_a8c_ptr(g, s_tap, rok[p], rc[p], cur, valid);
+      ra[p] = *reinterpret_cast<const uint4*>(src);
+      okm |= valid ? 1u << p : 0u;
+    }
     const bool kin = cur.slot < g.ntaps;
     const int woff = kin ? (int)s_tap[cur.slot].wt * g.C + cur.c : 0;
 #pragma unroll
-    for (int p = 0; p < LB; ++p)
-      rb[p] = (kin && wrow[p]) ? *reinterpret_cast<const uint4*>(wrow[p] + woff) : make_uint4(0u, 0u, 0u, 0u);
+    for (int p = 0; p < LB; ++p) {
+      const bool valid = kin && wrow[p] != nullptr;
+      const uint16_t* src = valid ? wrow[p] + woff : reinterpret_cast<const uint16_t*>(g.w[0]);
+      rb[p] = *reinterpret_cast<const uint4*>(src);
+      okm |= valid ? 1u << (LA + p) : 0u;
+    }
     kcur_advance(g, cur, BK);
   };
-  auto store_tile = [&](const uint4 (&ra)[LA], const uint4 (&rb)[LB], int buf) {
+  // (the zero is selected per component: `ok ? ra[p] : z` on the whole vector selects an ADDRESS and sends the register sets to scratch)
+  auto keep = [](uint4 v, bool ok) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); };
+  auto store_tile = [&](const uint4 (&ra)[LA], const uint4 (&rb)[LB], unsigned okm, int buf) {
 #pragma unroll
     for (int p = 0; p < LA; ++p) {
       const int idx = tid + p * NT;
-      if (idx < BM * CPRK) *reinterpret_cast<uint4*>(&As[(buf * BM + idx / CPRK) * LDK + (idx % CPRK) * 8]) = ra[p];
+      if (idx < BM * CPRK) *reinterpret_cast<uint4*>(&As[(buf * BM + idx / CPRK) * LDK + (idx % CPRK) * 8]) = keep(ra[p], (okm >> p) & 1u);
     }
 #pragma unroll
     for (int p = 0; p < LB; ++p) {
       const int idx = tid + p * NT;
-      if (idx < BN * CPRK) *reinterpret_cast<uint4*>(&Bs[(buf * BN + idx / CPRK) * LDK + (idx % CPRK) * 8]) = rb[p];
+      if (idx < BN * CPRK) *reinterpret_cast<uint4*>(&Bs[(buf * BN + idx / CPRK) * LDK + (idx % CPRK) * 8]) = keep(rb[p], (okm >> (LA + p)) & 1u);
     }
   };
   const int li = lane & 31, lh = lane >> 5;
@@ -217,40 +249,43 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_nt_bf16_kernel(const IGemmA
     }
   };
 
+  static_assert(LA + LB <= 32, "validity bits");
   uint4 ra0[LA], rb0[LB];
+  unsigned ok0 = 0;
   if (NBUF == 2) {
     // 3-stage pipeline: tile t in LDS being consumed, tile t+1 arrived in registers, tile t+2 in flight.
     uint4 ra1[LA], rb1[LB];
-    load_tile(ra0, rb0);                          // tile 0
-    store_tile(ra0, rb0, 0);
-    if (nkt > 1) load_tile(ra0, rb0);             // tile 1
-    if (nkt > 2) load_tile(ra1, rb1);             // tile 2
+    unsigned ok1 = 0;
+    load_tile(ra0, rb0, ok0);                     // tile 0
+    store_tile(ra0, rb0, ok0, 0);
+    if (nkt > 1) load_tile(ra0, rb0, ok0);        // tile 1
+    if (nkt > 2) load_tile(ra1, rb1, ok1);        // tile 2
     __syncthreads();
     for (int kt = 0; kt < nkt; kt += 2) {
       compute(0);                                 // tile kt
       if (kt + 1 < nkt) {
-        store_tile(ra0, rb0, 1);                  // tile kt+1 (buffer 1 was released by the previous barrier)
-        if (kt + 3 < nkt) load_tile(ra0, rb0);    // tile kt+3
+        store_tile(ra0, rb0, ok0, 1);             // tile kt+1 (buffer 1 was released by the previous barrier)
+        if (kt + 3 < nkt) load_tile(ra0, rb0, ok0);    // tile kt+3
       }
       __syncthreads();
       if (kt + 1 >= nkt) break;
       compute(1);                                 // tile kt+1
       if (kt + 2 < nkt) {
-        store_tile(ra1, rb1, 0);                  // tile kt+2
-        if (kt + 4 < nkt) load_tile(ra1, rb1);    // tile kt+4
+        store_tile(ra1, rb1, ok1, 0);             // tile kt+2
+        if (kt + 4 < nkt) load_tile(ra1, rb1, ok1);    // tile kt+4
       }
       __syncthreads();
     }
   } else {
-    load_tile(ra0, rb0);
-    store_tile(ra0, rb0, 0);
+    load_tile(ra0, rb0, ok0);
+    store_tile(ra0, rb0, ok0, 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) load_tile(ra0, rb0);
+      if (kt + 1 < nkt) load_tile(ra0, rb0, ok0);
       compute(0);
       if (kt + 1 < nkt) {
         __syncthreads();                          // single buffer: everyone is done reading before it is refilled
-        store_tile(ra0, rb0, 0);
+        store_tile(ra0, rb0, ok0, 0);
       }
       __syncthreads();
     }
