@@ -245,6 +245,25 @@ __global__ void head_softmax_fwd_kernel(const T* __restrict__ z, float* __restri
     for (int c = 0; c < C; ++c) p[m * C + c] = v[c] / sum;
   }
 }
+// compile-time class count, CP % 4 == 0: the row's first four logits as ONE vector load (instead of C two-byte loads in a run-time
+// loop), the probabilities as one store for C = 2
+template <typename T, int C>
+__global__ void head_softmax_fwd_vec_kernel(const T* __restrict__ z, float* __restrict__ p, long long M, int CP) {
+  GRID_STRIDE(m, M) {
+    const float4 q = Vec4<T>::load(z + m * CP);
+    const float v[4] = {q.x, q.y, q.z, q.w};
+    float mx = -INFINITY, e[C], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, v[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) { e[c] = expf(v[c] - mx); sum += e[c]; }
+    if constexpr (C == 2) *reinterpret_cast<float2*>(p + m * 2) = make_float2(e[0] / sum, e[1] / sum);
+    else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) p[m * C + c] = e[c] / sum;
+    }
+  }
+}
 template <typename T>
 __global__ void head_softmax_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p, T* __restrict__ dz,
                                         long long M, int C, int CP) {
@@ -255,16 +274,27 @@ __global__ void head_softmax_bwd_kernel(const float* __restrict__ dp, const floa
   }
 }
 // bf16 rows of CP = 8k padded logits: one 16-byte store per 8 channels (the fused conv pairs pad the heads to 16 / 32 columns)
+template <int CT>
 __global__ void head_softmax_bwd_bf16x8_kernel(const float* __restrict__ dp, const float* __restrict__ p, uint4* __restrict__ dz,
-                                               long long M, int C, int CP) {
+                                               long long M, int C_rt, int CP) {
+  const int C = CT > 0 ? CT : C_rt;
   const int v8 = CP / 8;
   GRID_STRIDE(i, M * v8) {
     const long long m = i / v8;
     uint4 o = make_uint4(0u, 0u, 0u, 0u);
     if (i - m * v8 == 0) {
-      float dot = 0.f, g[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < C; ++c) dot += dp[m * C + c] * p[m * C + c];
-      for (int c = 0; c < C; ++c) g[c] = p[m * C + c] * (dp[m * C + c] - dot);
+      float dot = 0.f, g[4] = {0.f, 0.f, 0.f, 0.f}, a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (CT == 2) {
+        const float2 av = *reinterpret_cast<const float2*>(dp + m * 2), bv = *reinterpret_cast<const float2*>(p + m * 2);
+        a[0] = av.x; a[1] = av.y; b[0] = bv.x; b[1] = bv.y;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) { a[c] = dp[m * C + c]; b[c] = p[m * C + c]; }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) dot += a[c] * b[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) g[c] = b[c] * (a[c] - dot);
       o.x = pack_bf16x2(g[0], g[1]);
       o.y = pack_bf16x2(g[2], g[3]);
     }
@@ -273,14 +303,20 @@ __global__ void head_softmax_bwd_bf16x8_kernel(const float* __restrict__ dp, con
 }
 extern "C" int ltu_head_softmax_fwd(const void* z, float* p, long long M, int C, int CP, int dtype, ltu_stream_t s) {
   if (C > 4 || CP < C) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((head_softmax_fwd_kernel<T>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, M, C, CP); });
+  LTU_DISPATCH_T(dtype, {
+    if (CP % 4 == 0 && C == 2) hipLaunchKernelGGL((head_softmax_fwd_vec_kernel<T, 2>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, M, CP);
+    else if (CP % 4 == 0 && C == 3) hipLaunchKernelGGL((head_softmax_fwd_vec_kernel<T, 3>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, M, CP);
+    else hipLaunchKernelGGL((head_softmax_fwd_kernel<T>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, M, C, CP);
+  });
   return ltu_check_launch();
 }
 extern "C" int ltu_head_softmax_bwd(const float* dp, const float* p, void* dz, long long M, int C, int CP, int dtype,
                                     ltu_stream_t s) {
   if (C > 4 || CP < C) return LTU_E_SHAPE;
   if (dtype == LTU_BF16 && CP % 8 == 0 && ((uintptr_t)dz & 15) == 0) {
-    hipLaunchKernelGGL(head_softmax_bwd_bf16x8_kernel, dim3(sgrid(M * (CP / 8))), dim3(256), 0, (hipStream_t)s, dp, p, (uint4*)dz, M, C, CP);
+    if (C == 2) hipLaunchKernelGGL(head_softmax_bwd_bf16x8_kernel<2>, dim3(sgrid(M * (CP / 8))), dim3(256), 0, (hipStream_t)s, dp, p, (uint4*)dz, M, C, CP);
+    else if (C == 3) hipLaunchKernelGGL(head_softmax_bwd_bf16x8_kernel<3>, dim3(sgrid(M * (CP / 8))), dim3(256), 0, (hipStream_t)s, dp, p, (uint4*)dz, M, C, CP);
+    else hipLaunchKernelGGL(head_softmax_bwd_bf16x8_kernel<0>, dim3(sgrid(M * (CP / 8))), dim3(256), 0, (hipStream_t)s, dp, p, (uint4*)dz, M, C, CP);
     return ltu_check_launch();
   }
   LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((head_softmax_bwd_kernel<T>), dim3(sgrid(M)), dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, M, C, CP); });
@@ -289,8 +325,11 @@ extern "C" int ltu_head_softmax_bwd(const float* dp, const float* p, void* dz, l
 
 // final head (model/Unet_3Dblock.py:1392-1394): z T [B,h,w,D,4C] -> window un-embedding + softmax over classes
 // -> probs f32 [B,2h,2w,D,C];  channel c*4 + kh*2 + kw of voxel (h,w) is class c of voxel (2h+kh, 2w+kw).
-template <typename T>
-__global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restrict__ p, int B, int h, int w, int D, int C, int CP) {
+// CT: compile-time class count (0 = run-time C).  With a run-time C the class loops stay loops: one scalar load per trip, each
+// waited for where it stands (16 dependent round trips per thread in the backward kernel).
+template <typename T, int CT>
+__global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restrict__ p, int B, int h, int w, int D, int C_rt, int CP) {
+  const int C = CT > 0 ? CT : C_rt;
   const long long n = (long long)B * h * w * D;
   GRID_STRIDE(i, n) {
     const int d = (int)(i % D);
@@ -299,23 +338,33 @@ __global__ void final_softmax_fwd_kernel(const T* __restrict__ z, float* __restr
     const int hh = (int)(t % h);
     const int b = (int)(t / h);
     float v[16];
-    for (int k = 0; k < 4 * C; k += 4) {
-      const float4 q = Vec4<T>::load(z + i * CP + k);
-      v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      if (k < 4 * C) {
+        const float4 q = Vec4<T>::load(z + i * CP + k);
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float mx = -INFINITY, e[4], sum = 0.f;
-      for (int c = 0; c < C; ++c) mx = fmaxf(mx, v[c * 4 + q]);
-      for (int c = 0; c < C; ++c) { e[c] = expf(v[c * 4 + q] - mx); sum += e[c]; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) mx = fmaxf(mx, v[c * 4 + q]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) { e[c] = expf(v[c * 4 + q] - mx); sum += e[c]; }
       float* o = p + ((((long long)b * 2 * h + 2 * hh + (q >> 1)) * 2 * w + 2 * ww + (q & 1)) * D + d) * C;
-      for (int c = 0; c < C; ++c) o[c] = e[c] / sum;
+      if constexpr (CT == 2) *reinterpret_cast<float2*>(o) = make_float2(e[0] / sum, e[1] / sum);
+      else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) o[c] = e[c] / sum;
+      }
     }
   }
 }
-template <typename T>
+template <typename T, int CT>
 __global__ void final_softmax_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p, T* __restrict__ dz, int B,
-                                         int h, int w, int D, int C, int CP) {
+                                         int h, int w, int D, int C_rt, int CP) {
+  const int C = CT > 0 ? CT : C_rt;
   const long long n = (long long)B * h * w * D;
   GRID_STRIDE(i, n) {
     const int d = (int)(i % D);
@@ -323,27 +372,51 @@ __global__ void final_softmax_bwd_kernel(const float* __restrict__ dp, const flo
     const int ww = (int)(t % w); t /= w;
     const int hh = (int)(t % h);
     const int b = (int)(t / h);
-    float v[16];
+    float v[16], gv[4][4], pv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // all loads of the four fine voxels first
+      const long long o = ((((long long)b * 2 * h + 2 * hh + (q >> 1)) * 2 * w + 2 * ww + (q & 1)) * D + d) * C;
+      if constexpr (CT == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(dp + o), c2 = *reinterpret_cast<const float2*>(p + o);
+        gv[q][0] = a.x; gv[q][1] = a.y; pv[q][0] = c2.x; pv[q][1] = c2.y;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) { gv[q][c] = dp[o + c]; pv[q][c] = p[o + c]; }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const long long o = ((((long long)b * 2 * h + 2 * hh + (q >> 1)) * 2 * w + 2 * ww + (q & 1)) * D + d) * C;
       float dot = 0.f;
-      for (int c = 0; c < C; ++c) dot += dp[o + c] * p[o + c];
-      for (int c = 0; c < C; ++c) v[c * 4 + q] = p[o + c] * (dp[o + c] - dot);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) dot += gv[q][c] * pv[q][c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) v[c * 4 + q] = pv[q][c] * (gv[q][c] - dot);
     }
-    for (int k = 0; k < 4 * C; k += 4) Vec4<T>::store(dz + i * CP + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+#pragma unroll
+    for (int k = 0; k < 16; k += 4)
+      if (k < 4 * C) Vec4<T>::store(dz + i * CP + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
     for (int k = 4 * C; k < CP; k += 4) Vec4<T>::store(dz + i * CP + k, make_float4(0.f, 0.f, 0.f, 0.f));      // padded conv columns
   }
 }
 extern "C" int ltu_final_softmax_fwd(const void* z, float* p, int B, int h, int w, int D, int C, int CP, int dtype, ltu_stream_t s) {
   if (C < 1 || C > 4 || CP < 4 * C || CP % 4) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((final_softmax_fwd_kernel<T>), dim3(sgrid((long long)B * h * w * D)), dim3(256), 0, (hipStream_t)s, (const T*)z, p, B, h, w, D, C, CP); });
+  LTU_DISPATCH_T(dtype, {
+    const dim3 grid(sgrid((long long)B * h * w * D));
+    if (C == 2) hipLaunchKernelGGL((final_softmax_fwd_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)s, (const T*)z, p, B, h, w, D, C, CP);
+    else if (C == 3) hipLaunchKernelGGL((final_softmax_fwd_kernel<T, 3>), grid, dim3(256), 0, (hipStream_t)s, (const T*)z, p, B, h, w, D, C, CP);
+    else hipLaunchKernelGGL((final_softmax_fwd_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)s, (const T*)z, p, B, h, w, D, C, CP);
+  });
   return ltu_check_launch();
 }
 extern "C" int ltu_final_softmax_bwd(const float* dp, const float* p, void* dz, int B, int h, int w, int D, int C, int CP,
                                      int dtype, ltu_stream_t s) {
   if (C < 1 || C > 4 || CP < 4 * C || CP % 4) return LTU_E_SHAPE;
-  LTU_DISPATCH_T(dtype, { hipLaunchKernelGGL((final_softmax_bwd_kernel<T>), dim3(sgrid((long long)B * h * w * D)), dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, B, h, w, D, C, CP); });
+  LTU_DISPATCH_T(dtype, {
+    const dim3 grid(sgrid((long long)B * h * w * D));
+    if (C == 2) hipLaunchKernelGGL((final_softmax_bwd_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, B, h, w, D, C, CP);
+    else if (C == 3) hipLaunchKernelGGL((final_softmax_bwd_kernel<T, 3>), grid, dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, B, h, w, D, C, CP);
+    else hipLaunchKernelGGL((final_softmax_bwd_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)s, dp, p, (T*)dz, B, h, w, D, C, CP);
+  });
   return ltu_check_launch();
 }
 
