@@ -236,7 +236,7 @@ int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int 
  * qkv [B*N][3d] (q | k | v; head h = columns h*32..h*32+31 of each third) -> out [B*N][d].
  * Saved for backward: ctx [B*H][32][32], colstats [B*H][64] (column max | column sum of exp),
  * qstat [B*N][H][2] (row max, 1/(rowsum*sqrt(32))).  part_ws: B * (ns + ns/16 + 2) * H * 1088 floats,
- * ns = ltu_linattn_splits(B,N) (the backward needs B * ns * H * 1024). */
+ * ns = ltu_linattn_splits(B,N), an upper bound of the split count over d (the backward needs B * ns * H * 1024). */
 int ltu_linattn_splits(int B, int N);
 int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws, int B, int N,
                     int d, int dtype, ltu_stream_t s);

@@ -1004,10 +1004,12 @@ __global__ void __launch_bounds__(2 * D, 2) linattn_bwd_apply(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int pick_splits(int B, int N, int* tokens_per_split) {
-  // ~256..512 streaming workgroups in total, whole 32-token tiles each
+static int pick_splits(int B, int N, int d, int* tokens_per_split) {
+  // ~256..512 streaming workgroups in total, whole 32-token tiles each.  d = 256 (512-thread workgroups, a 35 KB partial per split):
+  // 256 - with the one-batch merge fewer, longer splits win there (21 504 x 256: forward 25.8 -> 22.5 us, backward 36.9 -> 34.8;
+  // 8 640 x 256: 22.3 -> 17.8, 28.3 -> 26.2); d <= 128 keeps 512 (114 816 x 128: 37.1 | 71.0 against 38.6 | 75.3 at 256).
   int total = -1;
-  total = ltu_knob_pos("LTU_LA_SPLITS", 512);
+  total = ltu_knob_pos("LTU_LA_SPLITS", d >= 256 ? 256 : 512);
   int want = total / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   if (want > KVC_GROUP * KVC_GROUP) want = KVC_GROUP * KVC_GROUP;      // the merge is two levels of at most KVC_GROUP partials
@@ -1030,7 +1032,7 @@ static int pick_tokb(int B, int N, int d) {
 
 extern "C" int ltu_linattn_splits(int B, int N) {
   int tps;
-  return pick_splits(B, N, &tps);
+  return pick_splits(B, N, 128, &tps);      // the largest count any d uses: an upper bound for workspace sizing
 }
 
 #define LA_DISPATCH_D(d, ...)                                   \
@@ -1054,7 +1056,7 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
                                int B, int N, int d, int dtype, ltu_stream_t s) {
   const int H = d / 32;
   int tps;
-  const int nsplit = pick_splits(B, N, &tps);
+  const int nsplit = pick_splits(B, N, d, &tps);
   hipStream_t st = (hipStream_t)s;
   const int tokb = pick_tokb(B, N, d);
   LTU_DISPATCH_T(dtype, {
@@ -1098,7 +1100,7 @@ extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* c
                                int d, int dtype, ltu_stream_t s) {
   const int H = d / 32;
   int tps;
-  const int nsplit = pick_splits(B, N, &tps);
+  const int nsplit = pick_splits(B, N, d, &tps);
   hipStream_t st = (hipStream_t)s;
   const size_t lds_b = (size_t)(32 * (3 * d + 4) + 32 * (d + 4) + H * 96) * sizeof(float);
   const int tokb = pick_tokb(B, N, d);
