@@ -1006,7 +1006,7 @@ static void launch_dwconv_halo(const void* x, const void* x2, const void* g, con
   constexpr int CC = 128 / (int)sizeof(T);
   const int nchunk = cdiv(C, CC);
   const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
-  long long nblk = (MODE == 2 ? 512 : 1024) / nchunk;      // fewer, longer-lived workgroups for the reduction
+  long long nblk = (MODE == 2 ? ltu_knob_pos("LTU_DW_BLOCKS2", 512) : ltu_knob_pos("LTU_DW_BLOCKS", 512)) / nchunk;      // fewer, longer-lived workgroups for the reduction
   if (nblk < 1) nblk = 1;
   if (nblk > bricks) nblk = bricks;
   const int bpb = (int)((bricks + nblk - 1) / nblk);
@@ -1021,7 +1021,7 @@ extern "C" long long ltu_dwconv_bwd_ws_floats(int B, int H, int W, int D, int C,
   const int CC = dtype == LTU_BF16 ? 64 : 32;
   const int nchunk = cdiv(C, CC);
   const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
-  long long nblk = 512 / nchunk;
+  long long nblk = ltu_knob_pos("LTU_DW_BLOCKS2", 512) / nchunk;
   if (nblk < 1) nblk = 1;
   if (nblk > bricks) nblk = bricks;
   const int bpb = (int)((bricks + nblk - 1) / nblk);
