@@ -655,7 +655,7 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
 // ------------------------------------------------------------------------------------------------ host side
 static int stats_rows(long long S, int B, int* nchunks) {
   int chunks = -1;
-  chunks = ltu_knob_pos("LTU_IN_CHUNKS", 2048);
+  chunks = ltu_knob_pos("LTU_IN_CHUNKS", 1024);
   long long want = chunks / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   long long rows = (S + want - 1) / want;
@@ -680,7 +680,7 @@ static bool in_fold_plan(long long S, int B, int C, int vw, const float* ws, int
   if (ws == nullptr || !ltu_knob("LTU_IN_FOLD", 0)) return false;
   if ((256 * vw) % C != 0 || 2 * C > IN_FOLD_LDS || C < 4) return false;
   long long want = IN_FOLD_MAX / (2 * C);
-  const long long cap = ltu_knob_pos("LTU_IN_CHUNKS", 2048) / (B > 0 ? B : 1);
+  const long long cap = ltu_knob_pos("LTU_IN_CHUNKS", 1024) / (B > 0 ? B : 1);
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   long long r = (S + want - 1) / want;
