@@ -126,8 +126,8 @@ class KernelTimer:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--batch', type=int, default=2, help='patches per GPU')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
