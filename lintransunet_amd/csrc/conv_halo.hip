@@ -302,7 +302,14 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
     q.b = t / nbh;
     return q;
   };
-  const BrickPos stepd = decompose((int)gridDim.x);
+  // brick order: a contiguous run per workgroup, adjacent runs on one XCD (see conv3_halo_wr_bf16_kernel)
+  const bool xcd_order = (gridDim.x & 7) == 0 && !a.no_xcd_order;
+  const int slot = xcd_order ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int per = (bricks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int brick_first = xcd_order ? slot * per : (int)blockIdx.x;
+  const int brick_step = xcd_order ? 1 : (int)gridDim.x;
+  const int brick_end = xcd_order ? min(bricks, brick_first + per) : bricks;
+  const BrickPos stepd = decompose(brick_step);
   auto advance = [&](BrickPos& q) {
     q.bd += stepd.bd; if (q.bd >= nbd) { q.bd -= nbd; ++q.bw; }
     q.bw += stepd.bw; if (q.bw >= nbw) { q.bw -= nbw; ++q.bh; }
@@ -365,9 +372,9 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   }
   uint16_t* Cs = halo;
 
-  int brick = blockIdx.x;
-  BrickPos cur = decompose(brick), nxt = cur;
-  if (brick < bricks) load_halo(cur);
+  int brick = brick_first;
+  BrickPos cur = decompose(min(brick, bricks - 1)), nxt = cur;
+  if (brick < brick_end) load_halo(cur);
   // output pieces of this thread: rows (tid >> 3) + 32 it, 4 channels from (tid & 7) * 4
   const int o_w = tid >> 6, o_d = (tid >> 3) & 7, o_n = (tid & 7) * 4;
   uint16_t* const o_base = o_n < a.n0 ? reinterpret_cast<uint16_t*>(a.o0) + o_n : reinterpret_cast<uint16_t*>(a.o1) + (o_n - a.n0);
@@ -376,11 +383,11 @@ __global__ void __launch_bounds__(256) conv3_halo_ws_bf16_kernel(const HaloArgs 
   // placed behind freshly issued stores would also wait for their acknowledgement: vmcnt is one in-order counter).  Deferring
   // them by a whole brick was tried as well: 59 -> 55 us at C = 16 but 78 -> 92 us at C = 32; not kept.
   __syncthreads();                         // the weights are in place
-  if (brick < bricks) store_halo();
+  if (brick < brick_end) store_halo();
   __syncthreads();
-  for (; brick < bricks; brick += gridDim.x) {
+  for (; brick < brick_end; brick += brick_step) {
     advance(nxt);
-    const bool more = brick + (int)gridDim.x < bricks;
+    const bool more = brick + brick_step < brick_end;
     if (more) load_halo(nxt);
     f32x16 acc;
 #pragma unroll
@@ -502,7 +509,17 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
     q.b = t / nbh;
     return q;
   };
-  const BrickPos stepd = decompose((int)gridDim.x);
+  // Brick order: workgroup -> a CONTIGUOUS run of bricks (consecutive bricks along d share a halo face), and the runs of the 64
+  // workgroups that land on one XCD (linear id % 8 under round-robin dispatch) are adjacent, so the in-plane halo overlap of
+  // neighbouring rows is served by that XCD's L2.  Strided (brick = id + k * grid) every brick fetched its whole 2.8x halo through
+  // the fabric: no two bricks in flight on an XCD were neighbours.
+  const bool xcd_order = (gridDim.x & 7) == 0 && !a.no_xcd_order;
+  const int slot = xcd_order ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int per = (bricks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int brick_first = xcd_order ? slot * per : (int)blockIdx.x;
+  const int brick_step = xcd_order ? 1 : (int)gridDim.x;
+  const int brick_end = xcd_order ? min(bricks, brick_first + per) : bricks;
+  const BrickPos stepd = decompose(brick_step);
   auto advance = [&](BrickPos& q) {
     q.bd += stepd.bd; if (q.bd >= nbd) { q.bd -= nbd; ++q.bw; }
     q.bw += stepd.bw; if (q.bw >= nbw) { q.bw -= nbw; ++q.bh; }
@@ -583,17 +600,17 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
   }
   uint16_t* const Cs = smem + 2 * HELEMS + wave * SELEMS;
 
-  int brick = blockIdx.x;
-  if (brick >= bricks) return;             // never taken: the grid is at most `bricks` wide
+  int brick = brick_first;
+  if (brick >= brick_end) return;
   BrickPos cur = decompose(brick), nxt = cur;
   load_halo(cur);
   store_halo(smem);
   advance(nxt);
-  if (brick + (int)gridDim.x < bricks) load_halo(nxt);
+  if (brick + brick_step < brick_end) load_halo(nxt);
   __syncthreads();
   int buf = 0;
-  for (; brick < bricks; brick += gridDim.x) {
-    const bool more = brick + (int)gridDim.x < bricks;
+  for (; brick < brick_end; brick += brick_step) {
+    const bool more = brick + brick_step < brick_end;
     const uint16_t* const halo = smem + buf * HELEMS;
     f32x16 acc;
 #pragma unroll
@@ -648,7 +665,7 @@ __global__ void __launch_bounds__(256) conv3_halo_wr_bf16_kernel(const HaloArgs 
     if (more) {
       store_halo(smem + (buf ^ 1) * HELEMS);
       advance(nxt);
-      if (brick + 2 * (int)gridDim.x < bricks) load_halo(nxt);
+      if (brick + 2 * brick_step < brick_end) load_halo(nxt);
     }
     {
       const long long vox0 = origin(done);
@@ -719,6 +736,7 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   if (a.c0 % a.CC != 0 && a.c0 != a.C) return 1;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
+  a.no_xcd_order = ltu_knob("LTU_HALO_NO_XCD", 0);
   if (a.N <= 32 && a.C <= 32 && !ltu_knob("LTU_NO_HALO_WS", 0)) {      // few channels: weights stationary, persistent over bricks
     int wsb = -1;
     wsb = ltu_knob_pos("LTU_HALO_WS_BLOCKS", 512);

@@ -129,6 +129,7 @@ struct HaloArgs {
   // adds the splits and the bias.  part == nullptr: one workgroup per tile walks all chunks.
   float* part;
   int ksplit, cps;
+  int no_xcd_order;     // 1: bricks dealt to the workgroups of the persistent kernels strided by the grid (LTU_HALO_NO_XCD: the old order)
 };
 long long conv_halo_ws_floats(int B, int H, int W, int D, int C, int N);
 int launch_conv_halo_bf16(HaloArgs a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled (fall back)
