@@ -575,16 +575,123 @@ __global__ void __launch_bounds__(256) tri_adj1d_kernel(const T* __restrict__ in
   else tri_adj1d_body<T, HAS2, 8>(ib, ib2, ob, os, ws, inner, nvec);
 }
 
+// Two adjacent output rows per workgroup: their candidate lists overlap (x2: rows 2l-1 .. 2l+2 and 2l+1 .. 2l+4), so the union is
+// 5-6 input rows instead of 8 - a third fewer 16-byte loads (and sums of the two gradient tensors) per output vector.  The merged
+// lists come from a table as well (TriPair: union rows, the weights of either output, zero where a row does not contribute).
+struct TriPair { int n; int o[8]; float w0[8]; float w1[8]; int pad[7]; };     // 128 bytes; n < 0: union longer than 8, rows done singly
+// entries [0, PH) for the height axis, [PH, PH + PW) width, then depth; P* = (L + 1) / 2
+__global__ void tri_pair_table_kernel(TriPair* __restrict__ t, int H, int W, int D, int Ho, int Wo, int Do, TriScale sc) {
+  const int PH = (H + 1) / 2, PW = (W + 1) / 2, PD = (D + 1) / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PH + PW + PD) return;
+  int L, Lo, pr;
+  float scale, inv;
+  if (i < PH) { L = H; Lo = Ho; pr = i; scale = sc.h; inv = sc.ih; }
+  else if (i < PH + PW) { L = W; Lo = Wo; pr = i - PH; scale = sc.w; inv = sc.iw; }
+  else { L = D; Lo = Do; pr = i - PH - PW; scale = sc.d; inv = sc.id; }
+  int o0[8], o1[8];
+  float w0[8], w1[8];
+  const int n0 = tri_cands(2 * pr, L, Lo, scale, inv, o0, w0);
+  const int n1 = 2 * pr + 1 < L ? tri_cands(2 * pr + 1, L, Lo, scale, inv, o1, w1) : 0;
+  TriPair e;
+  int a = 0, b = 0, n = 0;
+  bool over = false;
+  for (int q = 0; q < 8; ++q) { e.o[q] = o0[0]; e.w0[q] = 0.f; e.w1[q] = 0.f; }
+  while (a < n0 || b < n1) {
+    if (n == 8) { over = true; break; }
+    const int oa = a < n0 ? o0[a] : 0x7fffffff, ob = b < n1 ? o1[b] : 0x7fffffff;
+    const int o = oa < ob ? oa : ob;
+    e.o[n] = o;
+    if (oa == o) { e.w0[n] = w0[a]; ++a; }
+    if (ob == o) { e.w1[n] = w1[b]; ++b; }
+    ++n;
+  }
+  e.n = over ? -1 : n;
+  for (int q = 0; q < 7; ++q) e.pad[q] = 0;
+  t[i] = e;
+}
+template <typename T, bool HAS2, int N>
+__device__ __forceinline__ void tri_adj1d_pair_body(const T* ib, const T* ib2, T* ob0, T* ob1, const int (&os)[8], const float (&w0)[8],
+                                                    const float (&w1)[8], long long inner, long long nvec) {
+  constexpr int NV = TriVec<T>::NV;
+  for (long long v = (long long)blockIdx.y * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.y * 256) {
+    float q[N][NV], q2[N][NV];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      TriVec<T>::load(ib + (long long)os[k] * inner + v * NV, q[k]);
+      if constexpr (HAS2) TriVec<T>::load(ib2 + (long long)os[k] * inner + v * NV, q2[k]);
+    }
+    float a0[NV], a1[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const float x = HAS2 ? q[k][e] + q2[k][e] : q[k][e];
+        a0[e] += x * w0[k];
+        a1[e] += x * w1[k];
+      }
+    TriVec<T>::store(ob0 + v * NV, a0);
+    if (ob1 != nullptr) TriVec<T>::store(ob1 + v * NV, a1);
+  }
+}
+// grid (outer * pairs, blocks): rows 2 pair and 2 pair + 1 of one outer slice
+template <typename T, bool HAS2>
+__global__ void __launch_bounds__(256) tri_adj1d_pair_kernel(const T* __restrict__ in, const T* __restrict__ in2, T* __restrict__ out,
+                                                             int L_fine, int L_coarse, long long inner, const TriEntry* __restrict__ table,
+                                                             const TriPair* __restrict__ ptable) {
+  const unsigned npair = ((unsigned)L_coarse + 1u) >> 1;
+  const unsigned outer = blockIdx.x / npair, pr = blockIdx.x - outer * npair;
+  const int l0 = 2 * (int)pr, l1 = l0 + 1;
+  const long long nvec = inner / TriVec<T>::NV;
+  const T* ib = in + (long long)outer * L_fine * inner;
+  const T* ib2 = HAS2 ? in2 + (long long)outer * L_fine * inner : nullptr;
+  T* ob0 = out + ((long long)outer * L_coarse + l0) * inner;
+  T* ob1 = l1 < L_coarse ? ob0 + inner : nullptr;
+  const TriPair* tp = ptable + pr;
+  const int n = tp->n;
+  if (n < 0) {                               // union too long (never for x2): the two rows one after the other
+    for (int which = 0; which < 2; ++which) {
+      const int l = which == 0 ? l0 : l1;
+      if (l >= L_coarse) break;
+      const TriEntry* te = table + l;
+      int os[8];
+      float ws[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { os[q] = te->o[q]; ws[q] = te->w[q]; }
+      tri_adj1d_body<T, HAS2, 8>(ib, ib2, which == 0 ? ob0 : ob1, os, ws, inner, nvec);
+    }
+    return;
+  }
+  int os[8];
+  float w0[8], w1[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { os[q] = tp->o[q]; w0[q] = tp->w0[q]; w1[q] = tp->w1[q]; }
+  if (n <= 2) tri_adj1d_pair_body<T, HAS2, 2>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
+  else if (n == 3) tri_adj1d_pair_body<T, HAS2, 3>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
+  else if (n == 4) tri_adj1d_pair_body<T, HAS2, 4>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
+  else if (n == 5) tri_adj1d_pair_body<T, HAS2, 5>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
+  else if (n == 6) tri_adj1d_pair_body<T, HAS2, 6>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
+  else tri_adj1d_pair_body<T, HAS2, 8>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
+}
+
 static float tri_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 static float tri_inv(int in, int out) { return (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1); }
 
 template <typename T>
 static void launch_tri_adj1d(const T* in, const T* in2, T* out, long long outer, int L_fine, int L_coarse, long long inner,
-                             const TriEntry* table, hipStream_t st) {
+                             const TriEntry* table, const TriPair* ptable, hipStream_t st) {
   const long long nv = inner / TriVec<T>::NV;
   unsigned gx = (unsigned)((nv + 255) / 256);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
+  if (ptable != nullptr && L_fine != L_coarse) {
+    const dim3 pgrid((unsigned)(outer * ((L_coarse + 1) / 2)), gx);
+    if (in2 != nullptr) hipLaunchKernelGGL((tri_adj1d_pair_kernel<T, true>), pgrid, dim3(256), 0, st, in, in2, out, L_fine, L_coarse, inner, table, ptable);
+    else hipLaunchKernelGGL((tri_adj1d_pair_kernel<T, false>), pgrid, dim3(256), 0, st, in, (const T*)nullptr, out, L_fine, L_coarse, inner, table, ptable);
+    return;
+  }
   const dim3 grid((unsigned)(outer * L_coarse), gx);
   if (in2 != nullptr) hipLaunchKernelGGL((tri_adj1d_kernel<T, true>), grid, dim3(256), 0, st, in, in2, out, L_fine, L_coarse, inner, table);
   else hipLaunchKernelGGL((tri_adj1d_kernel<T, false>), grid, dim3(256), 0, st, in, (const T*)nullptr, out, L_fine, L_coarse, inner, table);
@@ -594,7 +701,7 @@ extern "C" long long ltu_trilinear_adjoint_ws_elems(int B, int H, int W, int D, 
   // depth pass output [B][2H][2W][D][C] (only when sd == 2) + width pass output [B][2H][W][D][C], in elements of the storage type,
   // + the candidate tables (H + W + D entries of 128 bytes, counted as 4-byte elements at most)
   const long long t2 = (long long)B * 2 * H * W * D * C;
-  return (sd == 2 ? 2 * t2 + t2 : t2) + (long long)(H + W + D + 1) * 64;
+  return (sd == 2 ? 2 * t2 + t2 : t2) + (long long)(H + W + D + 1) * 64 + (long long)((H + 1) / 2 + (W + 1) / 2 + (D + 1) / 2 + 2) * 64;
 }
 
 extern "C" int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, int B, int H, int W, int D, int C, int sd,
@@ -613,14 +720,18 @@ extern "C" int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, 
     T* tend = sd == 2 ? t1 + 2 * t2n : t1;
     TriEntry* table = reinterpret_cast<TriEntry*>((reinterpret_cast<uintptr_t>(tend) + 127) & ~(uintptr_t)127);
     hipLaunchKernelGGL(tri_table_kernel, dim3((unsigned)((H + W + D + 127) / 128)), dim3(128), 0, st, table, H, W, D, Ho, Wo, Do, sc);
+    TriPair* ptable = ltu_knob("LTU_TRI_NO_PAIR", 0) ? nullptr : reinterpret_cast<TriPair*>(table + (H + W + D + 1));
+    const int PH = (H + 1) / 2, PW = (W + 1) / 2, PDn = (D + 1) / 2;
+    if (ptable != nullptr)
+      hipLaunchKernelGGL(tri_pair_table_kernel, dim3((unsigned)((PH + PW + PDn + 127) / 128)), dim3(128), 0, st, ptable, H, W, D, Ho, Wo, Do, sc);
     const T* src = (const T*)dy;
     const T* src2 = (const T*)dy2;
     if (sd == 2) {                                               // depth: [B Ho Wo][Do -> D][C]
-      launch_tri_adj1d<T>(src, src2, t1, (long long)B * Ho * Wo, Do, D, C, table + H + W, st);
+      launch_tri_adj1d<T>(src, src2, t1, (long long)B * Ho * Wo, Do, D, C, table + H + W, ptable ? ptable + PH + PW : nullptr, st);
       src = t1; src2 = nullptr;
     }
-    launch_tri_adj1d<T>(src, src2, t2, (long long)B * Ho, Wo, W, (long long)D * C, table + H, st);       // width: [B Ho][Wo -> W][D C]
-    launch_tri_adj1d<T>(t2, (const T*)nullptr, (T*)dx, B, Ho, H, (long long)W * D * C, table, st);        // height: [B][Ho -> H][W D C]
+    launch_tri_adj1d<T>(src, src2, t2, (long long)B * Ho, Wo, W, (long long)D * C, table + H, ptable ? ptable + PH : nullptr, st);       // width: [B Ho][Wo -> W][D C]
+    launch_tri_adj1d<T>(t2, (const T*)nullptr, (T*)dx, B, Ho, H, (long long)W * D * C, table, ptable, st);        // height: [B][Ho -> H][W D C]
   });
   return ltu_check_launch();
 }
