@@ -706,6 +706,78 @@ def test_trilinear(ops, sd, shape):
         assert rel_err(res[0], res[1]) < tol, dt
 
 
+def _with_knob(name, value, fn):
+    """run fn() with a run-time knob of the library set (ltu_config_set), then clear it"""
+    from lintransunet_amd import _lib
+    _lib.call('ltu_config_set', name, value, 0)
+    try:
+        return fn()
+    finally:
+        _lib.call('ltu_config_set', name, 0, 1)
+
+
+@pytest.mark.parametrize('sd,shape', [(2, (2, 8, 5, 7, 6)), (1, (1, 16, 9, 4, 8)), (2, (1, 8, 3, 3, 3))])
+def test_trilinear_adjoint_row_pairs(ops, sd, shape):
+    """the separable adjoint with two adjacent output rows per workgroup (merged candidate table) against one row per workgroup
+    (LTU_TRI_NO_PAIR): the same terms in the same order, so bit-identical; odd lengths leave a last pair with one row"""
+    g = G(12)
+    x = torch.randn(shape, generator=g)
+    out = []
+    go1 = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], sd * shape[4], generator=g)
+    go2 = torch.randn(go1.shape, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+
+        def run():
+            xq = to_cl(x).to(dt).requires_grad_(True)
+            y1, y2 = ops.trilinear_up(xq, sd, fork=2)
+            torch.autograd.backward([y1, y2], [to_cl(go1).to(dt), to_cl(go2).to(dt)])
+            return xq.grad.float().clone()
+        a, b = run(), _with_knob(b'LTU_TRI_NO_PAIR', 1, run)
+        assert torch.equal(a, b), dt
+        out.append(a)
+    assert rel_err(out[1], out[0]) < 1.5e-2
+
+
+def test_conv3d_persistent_brick_orders(ops):
+    """the persistent few-channel convs with contiguous brick runs per workgroup (XCD-aware, default) against the strided order
+    (LTU_HALO_NO_XCD): the same bricks, bit-identical results; 720 ragged bricks on 512 workgroups"""
+    g = G(13)
+    for Ci, Co in ((16, 16), (32, 32)):
+        x = torch.randn(1, Ci, 36, 38, 60, generator=g).bfloat16()
+        w = (torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1).bfloat16().float()
+        b = torch.randn(Co, generator=g)
+        go = torch.randn(1, Co, 36, 38, 60, generator=g).bfloat16()
+
+        def run():
+            xd = to_cl(x.float(), torch.bfloat16).requires_grad_(True)
+            wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+            yd = ops.conv3d(xd, wd, bd)
+            yd.backward(to_cl(go.float(), torch.bfloat16))
+            return yd.detach().float().clone(), xd.grad.float().clone()
+        (y0, dx0), (y1, dx1) = run(), _with_knob(b'LTU_HALO_NO_XCD', 1, run)
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1), (Ci, Co)
+
+
+def test_level_loss_vector_path(ops):
+    """level losses: four voxels per thread (default when S % 4 == 0) against one voxel per thread (LTU_LOSS_SCALAR); the sums
+    differ in association only, the gradients not at all"""
+    g = G(14)
+    for C in (2, 3):
+        B, S = 2, 4 * 1237
+        logits = torch.randn(B, S, C, generator=g)
+        lab = torch.randint(0, C, (B, S), generator=g).to(torch.uint8).to(DEV)
+
+        def run():
+            p = torch.softmax(logits, -1).to(DEV).requires_grad_(True)
+            tot, values = ops.level_loss(p, lab, 1.0, 1.0, [1.0] * 4 + [1.0])
+            tot.backward()
+            keep = [0, 1, 2] + [3 + c for c in range(C)] + [7]        # total, CE, balanced Dice, Dice per class, foreground Dice
+            return torch.cat((tot.detach().reshape(1), values.detach().reshape(-1)[keep])).clone(), p.grad.clone()
+        (v0, g0), (v1, g1) = run(), _with_knob(b'LTU_LOSS_SCALAR', 1, run)
+        assert rel_err(v0, v1) < 1e-5
+        assert rel_err(g0, g1) < 1e-5
+
+
 def test_roi_golden(ops, golden_dir):
     """box finder (bit-exact), both warps and their adjoints against the reference's vectors, all edge cases"""
     Gd = np.load(os.path.join(golden_dir, 'roi.npz'))
