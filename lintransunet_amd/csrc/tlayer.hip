@@ -112,6 +112,9 @@ __device__ __forceinline__ void tl_run(const uint16_t* __restrict__ W, int ct, c
   }
 }
 
+#ifndef TL_LN_E128
+#define TL_LN_E128 8
+#endif
 __device__ __forceinline__ uint2 pack_quad(float a, float b, float c, float d) {
   uint2 r;
   r.x = pack_bf16x2(a, b);
@@ -131,31 +134,59 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
                                              const float* __restrict__ gamma, const float* __restrict__ beta, uint16_t* zg,
                                              uint16_t* yg, float* stat, long long row0, long long M, float eps, const DropCfg& dc,
                                              int tid) {
-  constexpr int G = D / 4;                 // lanes per row (64 or 32)
+  // E elements per lane.  d = 128: 8 (16 lanes per row = one DPP row: the two reductions of a row stay inside it, 16-byte LDS and
+  // global accesses, half the passes); d = 256: 4 (a row is a wave).
+  constexpr int E = D == 128 ? TL_LN_E128 : 4, Q = E / 4;
+  constexpr int G = D / E;                 // lanes per row (64, 32 or 16)
   constexpr int RPP = (D >= 256 ? 512 : 256) / G;      // rows per pass (the workgroup has D / 32 waves, at most 8)
   const int gl = tid % G;
-  const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4), bt = *reinterpret_cast<const float4*>(beta + gl * 4);
+  float gm[E], bt[E];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const float4 a = *reinterpret_cast<const float4*>(gamma + gl * E + 4 * q), c = *reinterpret_cast<const float4*>(beta + gl * E + 4 * q);
+    gm[4 * q] = a.x; gm[4 * q + 1] = a.y; gm[4 * q + 2] = a.z; gm[4 * q + 3] = a.w;
+    bt[4 * q] = c.x; bt[4 * q + 1] = c.y; bt[4 * q + 2] = c.z; bt[4 * q + 3] = c.w;
+  }
   for (int r = tid / G; r < TL_ROWS; r += RPP) {
     const long long row = row0 + r;
     const bool ok = row < M;
-    float4 rv = unpack_quad(*reinterpret_cast<const uint2*>(rl + r * LD + gl * 4));
-    float4 xv;
-    if constexpr (RES_LDS) xv = unpack_quad(*reinterpret_cast<const uint2*>(res_l + r * LD + gl * 4));
-    else xv = ok ? unpack_quad(*reinterpret_cast<const uint2*>(res_g + row * D + gl * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rv = drop4(dc, (unsigned long long)((row * D + gl * 4) >> 2), rv);
-    float z[4] = {xv.x + rv.x, xv.y + rv.y, xv.z + rv.z, xv.w + rv.w};
-    if (ok) *reinterpret_cast<uint2*>(zg + row * D + gl * 4) = pack_quad(z[0], z[1], z[2], z[3]);
-    const float mean = group_sum<G>(z[0] + z[1] + z[2] + z[3]) / (float)D;
+    float z[E];
+    uint2 zq[Q];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float4 rv = unpack_quad(*reinterpret_cast<const uint2*>(rl + r * LD + gl * E + 4 * q));
+      float4 xv;
+      if constexpr (RES_LDS) xv = unpack_quad(*reinterpret_cast<const uint2*>(res_l + r * LD + gl * E + 4 * q));
+      else xv = ok ? unpack_quad(*reinterpret_cast<const uint2*>(res_g + row * D + gl * E + 4 * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rv = drop4(dc, (unsigned long long)(((row * D + gl * E) >> 2) + q), rv);
+      z[4 * q] = xv.x + rv.x; z[4 * q + 1] = xv.y + rv.y; z[4 * q + 2] = xv.z + rv.z; z[4 * q + 3] = xv.w + rv.w;
+      zq[q] = pack_quad(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+      sum += (z[4 * q] + z[4 * q + 1]) + (z[4 * q + 2] + z[4 * q + 3]);
+    }
+    if (ok) {
+      if constexpr (Q == 2) *reinterpret_cast<uint4*>(zg + row * D + gl * E) = make_uint4(zq[0].x, zq[0].y, zq[1].x, zq[1].y);
+      else *reinterpret_cast<uint2*>(zg + row * D + gl * E) = zq[0];
+    }
+    const float mean = group_sum<G>(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { z[k] -= mean; sq += z[k] * z[k]; }
+    for (int k = 0; k < E; ++k) { z[k] -= mean; sq += z[k] * z[k]; }
     const float rstd = rsqrtf(group_sum<G>(sq) / (float)D + eps);
-    const uint2 yv = pack_quad(z[0] * rstd * gm.x + bt.x, z[1] * rstd * gm.y + bt.y, z[2] * rstd * gm.z + bt.z, z[3] * rstd * gm.w + bt.w);
-    if constexpr (Y_LDS) *reinterpret_cast<uint2*>(yl + r * LD + gl * 4) = yv;
-    if (ok) {
-      *reinterpret_cast<uint2*>(yg + row * D + gl * 4) = yv;
-      if (gl == 0) { stat[row * 2] = mean; stat[row * 2 + 1] = rstd; }
+    uint2 yv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      yv[q] = pack_quad(z[4 * q] * rstd * gm[4 * q] + bt[4 * q], z[4 * q + 1] * rstd * gm[4 * q + 1] + bt[4 * q + 1],
+                        z[4 * q + 2] * rstd * gm[4 * q + 2] + bt[4 * q + 2], z[4 * q + 3] * rstd * gm[4 * q + 3] + bt[4 * q + 3]);
+    if constexpr (Q == 2) {
+      const uint4 y4 = make_uint4(yv[0].x, yv[0].y, yv[1].x, yv[1].y);
+      if constexpr (Y_LDS) *reinterpret_cast<uint4*>(yl + r * LD + gl * E) = y4;
+      if (ok) *reinterpret_cast<uint4*>(yg + row * D + gl * E) = y4;
+    } else {
+      if constexpr (Y_LDS) *reinterpret_cast<uint2*>(yl + r * LD + gl * E) = yv[0];
+      if (ok) *reinterpret_cast<uint2*>(yg + row * D + gl * E) = yv[0];
     }
+    if (ok && gl == 0) { stat[row * 2] = mean; stat[row * 2 + 1] = rstd; }
   }
 }
 
