@@ -458,23 +458,39 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
                                                  const float* __restrict__ gamma, uint16_t* dzl, uint16_t* dzg, uint16_t* drl,
                                                  uint16_t* drg, float* __restrict__ lnws, float* red, int LD, long long row0,
                                                  long long M, const DropCfg& dc, int tid) {
-  constexpr int G = D / 4, RPP = NTHR / G, NR = TL_ROWS / RPP;
+  // E elements per lane: 8 at d = 128 (see tl_layernorm), 4 at d = 256
+  constexpr int E = D == 128 ? TL_LN_E128 : 4, Q = E / 4;
+  constexpr int G = D / E, RPP = NTHR / G, NR = TL_ROWS / RPP;
   const int gl = tid % G, rgp = tid / G;
-  const float4 gm = *reinterpret_cast<const float4*>(gamma + gl * 4);
-  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  float gmv[E], ag[E], ab[E];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(gamma + gl * E + 4 * q);
+    gmv[4 * q] = t.x; gmv[4 * q + 1] = t.y; gmv[4 * q + 2] = t.z; gmv[4 * q + 3] = t.w;
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
   // all global operands of the thread's NR rows first (one round trip, not one per row), then the arithmetic
-  uint2 zq[NR], q1[NR], q2[NR];
+  uint2 zq[NR][Q], q1[NR][Q], q2[NR][Q];
   float2 st[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const long long row = row0 + rgp + i * RPP;
-    zq[i] = q1[i] = q2[i] = make_uint2(0u, 0u);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) zq[i][q] = q1[i][q] = q2[i][q] = make_uint2(0u, 0u);
     st[i] = make_float2(0.f, 0.f);
     if (row < M) {
-      zq[i] = *reinterpret_cast<const uint2*>(zg + row * D + gl * 4);
+      if constexpr (Q == 2) {
+        const uint4 t = *reinterpret_cast<const uint4*>(zg + row * D + gl * E);
+        zq[i][0] = make_uint2(t.x, t.y); zq[i][1] = make_uint2(t.z, t.w);
+        if (gg1 != nullptr) { const uint4 u = *reinterpret_cast<const uint4*>(gg1 + row * D + gl * E); q1[i][0] = make_uint2(u.x, u.y); q1[i][1] = make_uint2(u.z, u.w); }
+        if (gg2 != nullptr) { const uint4 u = *reinterpret_cast<const uint4*>(gg2 + row * D + gl * E); q2[i][0] = make_uint2(u.x, u.y); q2[i][1] = make_uint2(u.z, u.w); }
+      } else {
+        zq[i][0] = *reinterpret_cast<const uint2*>(zg + row * D + gl * E);
+        if (gg1 != nullptr) q1[i][0] = *reinterpret_cast<const uint2*>(gg1 + row * D + gl * E);
+        if (gg2 != nullptr) q2[i][0] = *reinterpret_cast<const uint2*>(gg2 + row * D + gl * E);
+      }
       st[i] = *reinterpret_cast<const float2*>(stat + row * 2);
-      if (gg1 != nullptr) q1[i] = *reinterpret_cast<const uint2*>(gg1 + row * D + gl * 4);
-      if (gg2 != nullptr) q2[i] = *reinterpret_cast<const uint2*>(gg2 + row * D + gl * 4);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -483,48 +499,65 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
     const int r = rgp + i * RPP;
     const long long row = row0 + r;
     const bool ok = row < M;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (G_LDS) g = unpack_quad(*reinterpret_cast<const uint2*>(gl_ + r * LD + gl * 4));
-    if constexpr (G2_LDS) {
-      const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gl2_ + r * LD + gl * 4));
-      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-    }
-    if (gg1 != nullptr) {
-      const float4 t = unpack_quad(q1[i]);
-      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-    }
-    if (gg2 != nullptr) {
-      const float4 t = unpack_quad(q2[i]);
-      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-    }
-    const float4 zv = unpack_quad(zq[i]);
     const float mean = st[i].x, rstd = st[i].y;
-    const float gv[4] = {g.x, g.y, g.z, g.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w};
-    float h[4] = {(zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd};
-    float gg[4], s1 = 0.f, s2 = 0.f;
+    float gv[E], h[E], gg[E], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int q = 0; q < Q; ++q) {
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (G_LDS) g = unpack_quad(*reinterpret_cast<const uint2*>(gl_ + r * LD + gl * E + 4 * q));
+      if constexpr (G2_LDS) {
+        const float4 t = unpack_quad(*reinterpret_cast<const uint2*>(gl2_ + r * LD + gl * E + 4 * q));
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      }
+      if (gg1 != nullptr) {
+        const float4 t = unpack_quad(q1[i][q]);
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      }
+      if (gg2 != nullptr) {
+        const float4 t = unpack_quad(q2[i][q]);
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      }
+      const float4 zv = unpack_quad(zq[i][q]);
+      gv[4 * q] = g.x; gv[4 * q + 1] = g.y; gv[4 * q + 2] = g.z; gv[4 * q + 3] = g.w;
+      h[4 * q] = (zv.x - mean) * rstd; h[4 * q + 1] = (zv.y - mean) * rstd; h[4 * q + 2] = (zv.z - mean) * rstd; h[4 * q + 3] = (zv.w - mean) * rstd;
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
       if (ok) { ab[k] += gv[k]; ag[k] += gv[k] * h[k]; }
       gg[k] = gv[k] * gmv[k];
       s1 += gg[k]; s2 += gg[k] * h[k];
     }
     const float m1 = group_sum<G>(s1) / (float)D, m2 = group_sum<G>(s2) / (float)D;
-    const float4 dz = make_float4(rstd * (gg[0] - m1 - h[0] * m2), rstd * (gg[1] - m1 - h[1] * m2), rstd * (gg[2] - m1 - h[2] * m2),
-                                  rstd * (gg[3] - m1 - h[3] * m2));
-    const uint2 dzq = pack_quad(dz.x, dz.y, dz.z, dz.w);
-    const float4 dr = drop4(dc, (unsigned long long)((row * D + gl * 4) >> 2), dz);
-    const uint2 drq = pack_quad(dr.x, dr.y, dr.z, dr.w);
-    if constexpr (DZ_LDS) *reinterpret_cast<uint2*>(dzl + r * LD + gl * 4) = dzq;
-    *reinterpret_cast<uint2*>(drl + r * LD + gl * 4) = drq;
-    if (ok) {
-      if constexpr (DZ_GLOBAL) *reinterpret_cast<uint2*>(dzg + row * D + gl * 4) = dzq;
-      *reinterpret_cast<uint2*>(drg + row * D + gl * 4) = drq;
+    uint2 dzq[Q], drq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float4 dz = make_float4(rstd * (gg[4 * q] - m1 - h[4 * q] * m2), rstd * (gg[4 * q + 1] - m1 - h[4 * q + 1] * m2),
+                                    rstd * (gg[4 * q + 2] - m1 - h[4 * q + 2] * m2), rstd * (gg[4 * q + 3] - m1 - h[4 * q + 3] * m2));
+      dzq[q] = pack_quad(dz.x, dz.y, dz.z, dz.w);
+      const float4 dr = drop4(dc, (unsigned long long)(((row * D + gl * E) >> 2) + q), dz);
+      drq[q] = pack_quad(dr.x, dr.y, dr.z, dr.w);
+    }
+    if constexpr (Q == 2) {
+      const uint4 dz4 = make_uint4(dzq[0].x, dzq[0].y, dzq[1].x, dzq[1].y), dr4 = make_uint4(drq[0].x, drq[0].y, drq[1].x, drq[1].y);
+      if constexpr (DZ_LDS) *reinterpret_cast<uint4*>(dzl + r * LD + gl * E) = dz4;
+      *reinterpret_cast<uint4*>(drl + r * LD + gl * E) = dr4;
+      if (ok) {
+        if constexpr (DZ_GLOBAL) *reinterpret_cast<uint4*>(dzg + row * D + gl * E) = dz4;
+        *reinterpret_cast<uint4*>(drg + row * D + gl * E) = dr4;
+      }
+    } else {
+      if constexpr (DZ_LDS) *reinterpret_cast<uint2*>(dzl + r * LD + gl * E) = dzq[0];
+      *reinterpret_cast<uint2*>(drl + r * LD + gl * E) = drq[0];
+      if (ok) {
+        if constexpr (DZ_GLOBAL) *reinterpret_cast<uint2*>(dzg + row * D + gl * E) = dzq[0];
+        *reinterpret_cast<uint2*>(drg + row * D + gl * E) = drq[0];
+      }
     }
   }
   // column sums of the block: row groups meet in LDS (red: [RPP][2 D] floats)
-  float* dst = red + ((long long)rgp * D + gl * 4) * 2;
+  float* dst = red + ((long long)rgp * D + gl * E) * 2;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { dst[2 * k] = ag[k]; dst[2 * k + 1] = ab[k]; }
+  for (int k = 0; k < E; ++k) { dst[2 * k] = ag[k]; dst[2 * k + 1] = ab[k]; }
   __syncthreads();
   for (int i = tid; i < 2 * D; i += NTHR) {
     float acc = 0.f;
@@ -549,7 +582,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, WPS) tail_bwd_kernel(con
   uint16_t* UB = ZB + TL_ROWS * LD;                   // [32][LDH]  du
   float* red = reinterpret_cast<float*>(UB);          // [NTHR / (D/4)][2 D] column-sum scratch of the two LayerNorm stages: du is
                                                       // not yet written in stage 0 and no longer needed in stage 3
-  static_assert((NTHR / (D / 4)) * 2 * D * sizeof(float) <= TL_ROWS * LDH * sizeof(uint16_t), "column-sum scratch fits in UB");
+  static_assert((NTHR / (D / (D == 128 ? TL_LN_E128 : 4))) * 2 * D * sizeof(float) <= TL_ROWS * LDH * sizeof(uint16_t), "column-sum scratch fits in UB");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
