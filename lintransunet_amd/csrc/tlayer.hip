@@ -115,6 +115,9 @@ __device__ __forceinline__ void tl_run(const uint16_t* __restrict__ W, int ct, c
 #ifndef TL_LN_E128
 #define TL_LN_E128 8
 #endif
+#ifndef TL_LN_E256
+#define TL_LN_E256 8
+#endif
 __device__ __forceinline__ uint2 pack_quad(float a, float b, float c, float d) {
   uint2 r;
   r.x = pack_bf16x2(a, b);
@@ -134,9 +137,11 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
                                              const float* __restrict__ gamma, const float* __restrict__ beta, uint16_t* zg,
                                              uint16_t* yg, float* stat, long long row0, long long M, float eps, const DropCfg& dc,
                                              int tid) {
-  // E elements per lane.  d = 128: 8 (16 lanes per row = one DPP row: the two reductions of a row stay inside it, 16-byte LDS and
-  // global accesses, half the passes); d = 256: 4 (a row is a wave).
-  constexpr int E = D == 128 ? TL_LN_E128 : 4, Q = E / 4;
+  // E elements per lane: 8 (d = 128: 16 lanes per row = one DPP row, the two reductions of a row stay inside it; d = 256: 32 lanes,
+  // one row exchange instead of two), 16-byte LDS and global accesses, half the row passes of the 4-element form.  Measured
+  // (tools/bench_tail.py): forward 91.3 -> 86.8 us, backward 95.4 -> 85.3 us at 114 816 x 128; 47.0 -> 44.3 | 41.4 -> 40.0 at
+  // 21 504 x 256, 29.3 -> 27.6 | 26.0 -> 25.2 at 8 640 x 256, 15.9 -> 14.8 | 13.8 -> 13.2 at 1 024 x 256.
+  constexpr int E = D == 128 ? TL_LN_E128 : TL_LN_E256, Q = E / 4;
   constexpr int G = D / E;                 // lanes per row (64, 32 or 16)
   constexpr int RPP = (D >= 256 ? 512 : 256) / G;      // rows per pass (the workgroup has D / 32 waves, at most 8)
   const int gl = tid % G;
@@ -458,8 +463,8 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
                                                  const float* __restrict__ gamma, uint16_t* dzl, uint16_t* dzg, uint16_t* drl,
                                                  uint16_t* drg, float* __restrict__ lnws, float* red, int LD, long long row0,
                                                  long long M, const DropCfg& dc, int tid) {
-  // E elements per lane: 8 at d = 128 (see tl_layernorm), 4 at d = 256
-  constexpr int E = D == 128 ? TL_LN_E128 : 4, Q = E / 4;
+  // E elements per lane (see tl_layernorm)
+  constexpr int E = D == 128 ? TL_LN_E128 : TL_LN_E256, Q = E / 4;
   constexpr int G = D / E, RPP = NTHR / G, NR = TL_ROWS / RPP;
   const int gl = tid % G, rgp = tid / G;
   float gmv[E], ag[E], ab[E];
@@ -582,7 +587,7 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, WPS) tail_bwd_kernel(con
   uint16_t* UB = ZB + TL_ROWS * LD;                   // [32][LDH]  du
   float* red = reinterpret_cast<float*>(UB);          // [NTHR / (D/4)][2 D] column-sum scratch of the two LayerNorm stages: du is
                                                       // not yet written in stage 0 and no longer needed in stage 3
-  static_assert((NTHR / (D / (D == 128 ? TL_LN_E128 : 4))) * 2 * D * sizeof(float) <= TL_ROWS * LDH * sizeof(uint16_t), "column-sum scratch fits in UB");
+  static_assert((NTHR / (D / (D == 128 ? TL_LN_E128 : TL_LN_E256))) * 2 * D * sizeof(float) <= TL_ROWS * LDH * sizeof(uint16_t), "column-sum scratch fits in UB");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const long long row0 = (long long)blockIdx.x * TL_ROWS;
