@@ -129,6 +129,26 @@ __device__ __forceinline__ float4 unpack_quad(uint2 v) {
                      __uint_as_float(v.y & 0xffff0000u));
 }
 
+// Q quads (4 bf16 each) of one lane <-> memory: 16-byte accesses for pairs of quads
+template <int Q>
+__device__ __forceinline__ void st_quads(uint16_t* p, const uint2 (&v)[Q]) {
+  if constexpr (Q == 1) *reinterpret_cast<uint2*>(p) = v[0];
+  else {
+#pragma unroll
+    for (int q = 0; q < Q; q += 2) *reinterpret_cast<uint4*>(p + 4 * q) = make_uint4(v[q].x, v[q].y, v[q + 1].x, v[q + 1].y);
+  }
+}
+template <int Q>
+__device__ __forceinline__ void ld_quads(const uint16_t* p, uint2 (&v)[Q]) {
+  if constexpr (Q == 1) v[0] = *reinterpret_cast<const uint2*>(p);
+  else {
+#pragma unroll
+    for (int q = 0; q < Q; q += 2) {
+      const uint4 t = *reinterpret_cast<const uint4*>(p + 4 * q);
+      v[q] = make_uint2(t.x, t.y); v[q + 1] = make_uint2(t.z, t.w);
+    }
+  }
+}
 // (RES_LDS / Y_LDS are template flags rather than run-time null checks: hipcc 7.2 crashes in its inliner on the latter.)
 // LayerNorm stage over the block: row = res + drop(r), normalised.  r: LDS (bf16, stride LD); res: LDS (stride LD) or global
 // (stride D); z and y go to global memory, y also to LDS `yl` (nullable).  A row is handled by D/4 lanes (one quad each).
@@ -169,10 +189,7 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
       zq[q] = pack_quad(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
       sum += (z[4 * q] + z[4 * q + 1]) + (z[4 * q + 2] + z[4 * q + 3]);
     }
-    if (ok) {
-      if constexpr (Q == 2) *reinterpret_cast<uint4*>(zg + row * D + gl * E) = make_uint4(zq[0].x, zq[0].y, zq[1].x, zq[1].y);
-      else *reinterpret_cast<uint2*>(zg + row * D + gl * E) = zq[0];
-    }
+    if (ok) st_quads<Q>(zg + row * D + gl * E, zq);
     const float mean = group_sum<G>(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
@@ -183,14 +200,8 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
     for (int q = 0; q < Q; ++q)
       yv[q] = pack_quad(z[4 * q] * rstd * gm[4 * q] + bt[4 * q], z[4 * q + 1] * rstd * gm[4 * q + 1] + bt[4 * q + 1],
                         z[4 * q + 2] * rstd * gm[4 * q + 2] + bt[4 * q + 2], z[4 * q + 3] * rstd * gm[4 * q + 3] + bt[4 * q + 3]);
-    if constexpr (Q == 2) {
-      const uint4 y4 = make_uint4(yv[0].x, yv[0].y, yv[1].x, yv[1].y);
-      if constexpr (Y_LDS) *reinterpret_cast<uint4*>(yl + r * LD + gl * E) = y4;
-      if (ok) *reinterpret_cast<uint4*>(yg + row * D + gl * E) = y4;
-    } else {
-      if constexpr (Y_LDS) *reinterpret_cast<uint2*>(yl + r * LD + gl * E) = yv[0];
-      if (ok) *reinterpret_cast<uint2*>(yg + row * D + gl * E) = yv[0];
-    }
+    if constexpr (Y_LDS) st_quads<Q>(yl + r * LD + gl * E, yv);
+    if (ok) st_quads<Q>(yg + row * D + gl * E, yv);
     if (ok && gl == 0) { stat[row * 2] = mean; stat[row * 2 + 1] = rstd; }
   }
 }
@@ -485,16 +496,9 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
     for (int q = 0; q < Q; ++q) zq[i][q] = q1[i][q] = q2[i][q] = make_uint2(0u, 0u);
     st[i] = make_float2(0.f, 0.f);
     if (row < M) {
-      if constexpr (Q == 2) {
-        const uint4 t = *reinterpret_cast<const uint4*>(zg + row * D + gl * E);
-        zq[i][0] = make_uint2(t.x, t.y); zq[i][1] = make_uint2(t.z, t.w);
-        if (gg1 != nullptr) { const uint4 u = *reinterpret_cast<const uint4*>(gg1 + row * D + gl * E); q1[i][0] = make_uint2(u.x, u.y); q1[i][1] = make_uint2(u.z, u.w); }
-        if (gg2 != nullptr) { const uint4 u = *reinterpret_cast<const uint4*>(gg2 + row * D + gl * E); q2[i][0] = make_uint2(u.x, u.y); q2[i][1] = make_uint2(u.z, u.w); }
-      } else {
-        zq[i][0] = *reinterpret_cast<const uint2*>(zg + row * D + gl * E);
-        if (gg1 != nullptr) q1[i][0] = *reinterpret_cast<const uint2*>(gg1 + row * D + gl * E);
-        if (gg2 != nullptr) q2[i][0] = *reinterpret_cast<const uint2*>(gg2 + row * D + gl * E);
-      }
+      ld_quads<Q>(zg + row * D + gl * E, zq[i]);
+      if (gg1 != nullptr) ld_quads<Q>(gg1 + row * D + gl * E, q1[i]);
+      if (gg2 != nullptr) ld_quads<Q>(gg2 + row * D + gl * E, q2[i]);
       st[i] = *reinterpret_cast<const float2*>(stat + row * 2);
     }
   }
@@ -542,21 +546,11 @@ __device__ __forceinline__ void tl_layernorm_bwd(const uint16_t* gl_, const uint
       const float4 dr = drop4(dc, (unsigned long long)(((row * D + gl * E) >> 2) + q), dz);
       drq[q] = pack_quad(dr.x, dr.y, dr.z, dr.w);
     }
-    if constexpr (Q == 2) {
-      const uint4 dz4 = make_uint4(dzq[0].x, dzq[0].y, dzq[1].x, dzq[1].y), dr4 = make_uint4(drq[0].x, drq[0].y, drq[1].x, drq[1].y);
-      if constexpr (DZ_LDS) *reinterpret_cast<uint4*>(dzl + r * LD + gl * E) = dz4;
-      *reinterpret_cast<uint4*>(drl + r * LD + gl * E) = dr4;
-      if (ok) {
-        if constexpr (DZ_GLOBAL) *reinterpret_cast<uint4*>(dzg + row * D + gl * E) = dz4;
-        *reinterpret_cast<uint4*>(drg + row * D + gl * E) = dr4;
-      }
-    } else {
-      if constexpr (DZ_LDS) *reinterpret_cast<uint2*>(dzl + r * LD + gl * E) = dzq[0];
-      *reinterpret_cast<uint2*>(drl + r * LD + gl * E) = drq[0];
-      if (ok) {
-        if constexpr (DZ_GLOBAL) *reinterpret_cast<uint2*>(dzg + row * D + gl * E) = dzq[0];
-        *reinterpret_cast<uint2*>(drg + row * D + gl * E) = drq[0];
-      }
+    if constexpr (DZ_LDS) st_quads<Q>(dzl + r * LD + gl * E, dzq);
+    st_quads<Q>(drl + r * LD + gl * E, drq);
+    if (ok) {
+      if constexpr (DZ_GLOBAL) st_quads<Q>(dzg + row * D + gl * E, dzq);
+      st_quads<Q>(drg + row * D + gl * E, drq);
     }
   }
   // column sums of the block: row groups meet in LDS (red: [RPP][2 D] floats)
