@@ -5,6 +5,7 @@ from lintransunet_amd import _lib, ops
 from lintransunet_amd.ops import _p, _s
 from bench_nt import timed
 import numpy as np
+P = float(os.environ.get("TAIL_P", "0.3"))          # dropout probability of the chain kernels (0 = no mask hashing)
 
 
 def bf(*shape):
@@ -33,7 +34,7 @@ def run(M, d):
     u, h = (torch.empty(M, 2 * d, device='cuda', dtype=torch.bfloat16) for _ in range(2))
     s1, s2 = torch.empty(M, 2, device='cuda'), torch.empty(M, 2, device='cuda')
     tail = lambda: _lib.call('ltu_layer_tail_fwd', _p(a), _p(x), _p(fo), _p(f1), _p(f2), _p(bo), _p(b1), _p(b2), _p(g), _p(be), _p(g),
-                             _p(be), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(s1), _p(s2), M, d, 1e-6, 0.3, 11, 12, 13, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, _s())
+                             _p(be), _p(z1), _p(t1), _p(u), _p(h), _p(z2), _p(y), _p(s1), _p(s2), M, d, 1e-6, P, 11, 12, 13, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, _s())
     wob, w1b, w2b = wo.bfloat16(), w1.bfloat16(), w2.bfloat16()
     o, f = torch.empty(M, d, device='cuda', dtype=torch.bfloat16), torch.empty(M, d, device='cuda', dtype=torch.bfloat16)
     pa = ops._ptr_array
@@ -55,7 +56,7 @@ def run(M, d):
     dg, db = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
     ws = torch.empty(2048 * 2 * d, device='cuda')
     btail = lambda: _lib.call('ltu_layer_tail_bwd', _p(gy), 0, _p(z2), _p(z1), _p(u), _p(s2), _p(s1), _p(g), _p(g), _p(f2t), _p(f1t), _p(fot),
-                              _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), M, d, 0.3, 11, 12, 13, 0, 1, 1, _s())
+                              _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), M, d, P, 11, 12, 13, 0, 1, 1, _s())
     wot, w1t, w2t = wo.t().contiguous().bfloat16(), w1.t().contiguous().bfloat16(), w2.t().contiguous().bfloat16()
 
     def bsteps():
