@@ -5,6 +5,7 @@ from lintransunet_amd import _lib
 from lintransunet_amd.ops import _p, _s
 from bench_nt import timed
 
+PDROP = float(os.environ.get("PW_P", "0.3"))        # dropout probability of the InstanceNorm passes (0 = no mask hashing)
 WS = torch.empty(1 << 20, device='cuda') if os.environ.get('NO_WS') is None else None
 
 def bf(*shape):
@@ -34,9 +35,9 @@ def inorm(B, S, C):
     x, y, dy, dx = bf(B, S, C), bf(B, S, C), bf(B, S, C), bf(B, S, C)
     sums = torch.zeros(B, C, 3, device='cuda'); bs = torch.zeros(B, C, 2, device='cuda')
     st = lambda: _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(WS), B, S, C, 1, _s())
-    ap = lambda: _lib.call('ltu_instnorm_apply', _p(x), _p(sums), 0, _p(y), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
-    bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), 0, 0, _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
-    fw = lambda: _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(WS), 0, _p(y), B, S, C, 1, 0.01, 0.3, 1, 0, 1, _s())
+    ap = lambda: _lib.call('ltu_instnorm_apply', _p(x), _p(sums), 0, _p(y), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
+    bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), 0, 0, _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
+    fw = lambda: _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(WS), 0, _p(y), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
     t1, t2, t3, t4 = timed(st), timed(ap), timed(bw), timed(fw)
     mb = B * S * C * 2 / 1e6
     print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.1f} TB/s)  apply {t2:6.1f} us ({2 * mb / t2:.1f} TB/s)  '
