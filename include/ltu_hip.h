@@ -16,7 +16,7 @@
  *     knob table of ltu_config_set (mutex-protected; knobs are looked up per call: override, then
  *     the environment variable of the same name, then the default) and (b) per-device "dynamic
  *     LDS limit raised" latches for four kernels (atomic bit masks).
- *   - Dropout: (p, seed) select a counter-based hash mask (two chained murmur3 finalizers per
+ *   - Dropout: (p, seed) select a counter-based hash mask (a murmur3 finalizer + a linear expansion to 64 bits per
  *     4-element group, csrc/common.h); the backward entry points regenerate
  *     the mask from the same (p, seed) instead of reading a stored one.  p = 0 disables.  `step` (nullable) is a
  *     device-resident counter mixed into the seed at run time, so a captured HIP graph draws fresh masks per replay.

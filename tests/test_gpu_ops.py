@@ -415,7 +415,7 @@ def test_linear_gelu_fused(ops, M, K, N, dtype):
 
 
 def test_dropout_masks(ops):
-    """counter-hash dropout (csrc/common.h: two chained murmur3 finalizers per 4-element group): keep rate, 1/(1-p) scaling, and the
+    """counter-hash dropout (csrc/common.h: a murmur3 finalizer + a linear expansion per 4-element group): keep rate, 1/(1-p) scaling, and the
     backward regenerates exactly the forward mask"""
     n = 1 << 18
     u = torch.ones(n // 64, 64, device=DEV).requires_grad_(True)
@@ -435,6 +435,29 @@ def test_dropout_masks(ops):
     # IN backward mixes voxels, so test the mask through a second call instead
     y2 = ops.instnorm_act(x.detach(), None, 1, 0.3, 777)
     assert torch.equal(y2 != 0, keep)
+
+
+def test_dropout_mask_statistics(ops):
+    """the four keep decisions of a 4-element group come from one 32-bit murmur-finalized word and a linear expansion of it: per-slot
+    keep rates, pairwise correlations inside a group, correlations between neighbouring groups / rows, and the conditional keep
+    rates given the other slots of the group must look like independent Bernoulli(0.7) draws (4 M elements: sigma ~ 1e-3)"""
+    n = 1 << 22
+    u = torch.ones(n, device=DEV)
+    K = (ops.gelu_dropout(u, 0.3, 98765) != 0).double().reshape(-1, 4)
+    assert (K.mean(0) - 0.7).abs().max().item() < 3e-3
+    C = torch.corrcoef(K.t())
+    assert (C - torch.eye(4, device=DEV, dtype=C.dtype)).abs().max().item() < 5e-3
+    for lag in (1, 32, 64, 2048):
+        a, b = K[:-lag], K[lag:]
+        ca, cb = a - a.mean(0), b - b.mean(0)
+        corr = (ca.t() @ cb) / (ca.norm(dim=0)[:, None] * cb.norm(dim=0)[None, :])
+        assert corr.abs().max().item() < 5e-3, lag
+    xy = (K[:, 0] == 1) & (K[:, 1] == 1)
+    assert abs(K[xy, 2].mean().item() - 0.7) < 3e-3
+    xyz = xy & (K[:, 2] == 1)
+    assert abs(K[xyz, 3].mean().item() - 0.7) < 3e-3
+    nxy = (K[:, 0] == 0) & (K[:, 1] == 0)
+    assert abs(K[nxy, 2].mean().item() - 0.7) < 5e-3 and abs(K[nxy, 3].mean().item() - 0.7) < 5e-3
 
 
 @pytest.mark.parametrize('M,d', [(4320, 256), (2048, 128), (21504, 256), (1024, 256)])
