@@ -309,7 +309,7 @@ class MaskTransUnet(nn.Module):
             # the rest of the layer as one launch (csrc/tlayer.hip); with N a multiple of the kernel's 32-row blocks the
             # attention's phase B runs inside it too (the chain kernel reads its q rows and applies the merged context)
             s1, sg, s2 = ((seeds.next(), seeds.next(), seeds.next()) if p > 0 else (0, 0, 0))
-            fuse = ops.FUSE_ATTN_APPLY and N % 32 == 0 and qkv.dtype == torch.bfloat16
+            fuse = ops.FUSE_ATTN_APPLY and N % 32 == 0 and qkv.dtype == torch.bfloat16 and B * N <= ops.FUSE_ATTN_MAX_TOKENS
             a = qkv if fuse else ops.linear_attention(qkv, B, N, d)
             nx = None
             if nxt is not None:

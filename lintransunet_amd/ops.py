@@ -978,6 +978,7 @@ def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):
 
 
 FUSE_ATTN_APPLY = True      # phase B of the linear attention inside the forward chain kernel (tests flip it to compare)
+FUSE_ATTN_MAX_TOKENS = int(_os.environ.get('LTU_FUSE_ATTN_MAX_TOKENS', '1000000000'))      # experiment: stand-alone phase B above this many tokens
 FUSE_NEXT_QKV = _os.environ.get('LTU_NO_FUSE_QKV', '') == ''      # the next layer's q|k|v projection at the end of the forward chain kernel
 FUSE_QKV_MAX_TOKENS = int(_os.environ.get('LTU_FUSE_QKV_MAX_TOKENS', '50000'))      # measured: pays at the d = 256 levels (-0.05 ms), costs as much at 114 816 x 128
 FUSE_QKV_MIN_TOKENS = int(_os.environ.get('LTU_FUSE_QKV_MIN_TOKENS', '0'))
