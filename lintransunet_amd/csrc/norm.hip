@@ -449,11 +449,8 @@ __global__ void __launch_bounds__(256) instnorm_bwd_stats_kernel(const T* __rest
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > S) r1 = S;
-    for (long long r = r0 + rg; r < r1; r += nrg) {
-      const long long e = ((long long)b * S + r) * C + v * VW;
-      float xv[VW], g[VW], mk[VW];
-      ldv<T, VW>(x + e, xv);
-      load_gradv<T, VW>(dy, dy2, dy3, e, g);
+    auto add = [&](long long e, const float (&xv)[VW], const float (&g)[VW]) {
+      float mk[VW];
       dropmaskv<VW>(dc, e, mk);
 #pragma unroll
       for (int k = 0; k < VW; ++k) {
@@ -463,6 +460,24 @@ __global__ void __launch_bounds__(256) instnorm_bwd_stats_kernel(const T* __rest
         a1[k] += gg;
         a2[k] += gg * h;
       }
+    };
+    long long r = r0 + rg;
+    for (; r + nrg < r1; r += 2 * nrg) {        // two rows per step: their loads are in flight together
+      const long long e0 = ((long long)b * S + r) * C + v * VW, e1 = e0 + (long long)nrg * C;
+      float x0[VW], g0[VW], x1[VW], g1[VW];
+      ldv<T, VW>(x + e0, x0);
+      ldv<T, VW>(x + e1, x1);
+      load_gradv<T, VW>(dy, dy2, dy3, e0, g0);
+      load_gradv<T, VW>(dy, dy2, dy3, e1, g1);
+      add(e0, x0, g0);
+      add(e1, x1, g1);
+    }
+    if (r < r1) {
+      const long long e0 = ((long long)b * S + r) * C + v * VW;
+      float x0[VW], g0[VW];
+      ldv<T, VW>(x + e0, x0);
+      load_gradv<T, VW>(dy, dy2, dy3, e0, g0);
+      add(e0, x0, g0);
     }
     float* dst = red + ((long long)rg * C + v * VW) * 2;
 #pragma unroll
