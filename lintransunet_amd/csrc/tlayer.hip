@@ -118,6 +118,9 @@ __device__ __forceinline__ void tl_run(const uint16_t* __restrict__ W, int ct, c
 #ifndef TL_LN_E256
 #define TL_LN_E256 8
 #endif
+#ifndef TL_LN_E256F
+#define TL_LN_E256F TL_LN_E256      // forward stages (no column-sum scratch: 16 is possible there)
+#endif
 __device__ __forceinline__ uint2 pack_quad(float a, float b, float c, float d) {
   uint2 r;
   r.x = pack_bf16x2(a, b);
@@ -161,7 +164,7 @@ __device__ __forceinline__ void tl_layernorm(const uint16_t* rl, const uint16_t*
   // one row exchange instead of two), 16-byte LDS and global accesses, half the row passes of the 4-element form.  Measured
   // (tools/bench_tail.py): forward 91.3 -> 86.8 us, backward 95.4 -> 85.3 us at 114 816 x 128; 47.0 -> 44.3 | 41.4 -> 40.0 at
   // 21 504 x 256, 29.3 -> 27.6 | 26.0 -> 25.2 at 8 640 x 256, 15.9 -> 14.8 | 13.8 -> 13.2 at 1 024 x 256.
-  constexpr int E = D == 128 ? TL_LN_E128 : TL_LN_E256, Q = E / 4;
+  constexpr int E = D == 128 ? TL_LN_E128 : TL_LN_E256F, Q = E / 4;
   constexpr int G = D / E;                 // lanes per row (64, 32 or 16)
   constexpr int RPP = (D >= 256 ? 512 : 256) / G;      // rows per pass (the workgroup has D / 32 waves, at most 8)
   const int gl = tid % G;
