@@ -383,7 +383,7 @@ def main():
         # one graph -> collectives after the replay -> eager launches.
         # A failed capture must not cost the measurement; every rung runs the same kernels.
         multi = world > 1 or args.rehearse_comm
-        modes = [args.allreduce] if args.allreduce else (['segments', 'graph', 'after'] if multi else ['graph'])
+        modes = [args.allreduce] if args.allreduce else (['segments', 'graph', 'after'] if multi else ['segments', 'graph'])
         for mode in modes:
             try:
                 if ft is not None:

@@ -36,7 +36,7 @@ class _Done:
 class LocalComm:
     world, rank = 1, 0
 
-    def allreduce_avg(self, flat):
+    def allreduce_avg(self, flat, also=None):
         return _Done()
 
     def broadcast(self, t, src=0):
@@ -72,7 +72,7 @@ class GlooComm:
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
-    def allreduce_avg(self, flat):
+    def allreduce_avg(self, flat, also=None):
         if flat.is_cuda:
             raise _lib.LtuError('GlooComm reduces CPU tensors only; GPU gradients go through RcclComm (no silent staging copies)')
         return _GlooHandle(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, self.world)
@@ -102,8 +102,10 @@ class HostStagedComm:
         self.world, self.rank = control.world, control.rank
         self.calls = 0
 
-    def allreduce_avg(self, flat):
+    def allreduce_avg(self, flat, also=None):
         torch.cuda.current_stream().synchronize()
+        if also is not None:
+            also.synchronize()
         h = flat.cpu()
         self.control.allreduce_avg(h).wait()
         flat.copy_(h)
@@ -173,10 +175,13 @@ class RcclComm:
         self.handle = h
         self.calls = 0          # collectives enqueued (eagerly or into a capture): the tests and tools count these
 
-    def allreduce_avg(self, flat):
+    def allreduce_avg(self, flat, also=None):
+        """also: a second stream that contributed to the bucket (the weight-gradient queue's side stream)"""
         if not flat.is_cuda or flat.dtype != torch.float32 or not flat.is_contiguous():
             raise _lib.LtuError('RcclComm.allreduce_avg takes a contiguous fp32 CUDA tensor')
         self.stream.wait_stream(torch.cuda.current_stream())         # fork: everything issued so far produces this bucket
+        if also is not None:
+            self.stream.wait_stream(also)
         _lib.call('ltu_comm_allreduce_avg', self.handle, flat.data_ptr(), flat.numel(), self.stream.cuda_stream)
         self.calls += 1
         return _StreamHandle(self.stream)

@@ -106,7 +106,7 @@ class Context:
         self.arena = _Arena()
         self.step = None            # device-resident int64 step counter mixed into every dropout seed (common.h: make_drop)
         self.deferred = []          # (ReduceJob, workspace kept alive)
-        self.wg_branch = None       # {'side': torch.cuda.Stream, 'jobs': [(fn, tensors)]}
+        self.wq = None              # weight-gradient queue (see wq_install)
         self.norm_ws_by_dev = {}
         self.ones = {}
         self.wg_group = []          # pending projection weight gradients of the current transformer layer(s) (see wgrad_group_push)
@@ -155,7 +155,7 @@ class Context:
         if job.part:
             self.deferred.append((job, ws))
             if len(self.deferred) >= self._DEFER_MAX:
-                self.flush_deferred()
+                self._fold_flush()
 
     # -- grouped projection weight gradients: the four projections of a transformer layer (qkv, out, ffn1, ffn2) hand their
     # weight-gradient jobs in here during the layer's backward; the layer's last one (qkv) flushes them as ONE launch + ONE fold
@@ -182,6 +182,10 @@ class Context:
         if not jobs:
             return
         self.wg_group, self.wg_bytes, self.wg_layers = [], 0, 0
+        self.wq_push(lambda keep: self._wgrad_group_launch(jobs, keep), [t for j in jobs for t in j[:2]])
+
+    @staticmethod
+    def _wgrad_group_launch(jobs, keep):
         arr = (_lib.WgradJob * len(jobs))()
         for r, (g, x, dws, dbs, M, N, K) in zip(arr, jobs):
             r.grad, r.a, r.ldg, r.lda, r.nw, r.M, r.N, r.K = g.data_ptr(), x.data_ptr(), N, K, len(dws), M, N, K
@@ -191,51 +195,92 @@ class Context:
         n = lib.ltu_linear_wgrad_group_ws_floats(ctypes.addressof(arr), len(jobs))
         if n > 0:
             ws = torch.empty(n, device=jobs[0][0].device, dtype=torch.float32)
+            keep.append(ws)
             _lib.call('ltu_linear_wgrad_group', ctypes.addressof(arr), len(jobs), _p(ws), BF16, _s())
             return
         for g, x, dws, dbs, M, N, K in jobs:            # shapes the grouped kernel does not take: one call each
             wsb = _wgrad_ws(M, N, K, x)
+            keep.append(wsb)
             _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(dws), M, N, K, _p(wsb), 0,
                       _dt(x), _s())
 
-    def flush_deferred(self):
-        """fold every pending partial-sum workspace into its gradient (stream-ordered; call before gradients are consumed)"""
-        self.wgrad_group_flush()
+    def _fold_flush(self):
         if not self.deferred:
             return
-        arr = (_lib.ReduceJob * len(self.deferred))(*[j for j, _ in self.deferred])
-        _lib.call('ltu_reduce_batch', ctypes.addressof(arr), len(self.deferred), _s())
+        jobs = list(self.deferred)
         self.deferred.clear()
 
-    # -- weight-gradient branch: weight gradients of the transformer projections are consumed only at the end of the step, so they
-    # need not sit on the data-gradient chain.  With a branch installed their launches are collected and issued on a second stream
-    # once per transformer (ONE cross-stream edge per bridge: a HIP-graph edge between branches costs ~4 us, so per-kernel edges
-    # lose more than the overlap gains; two long branches gain 13-23 %, tools/bench_overlap.py).
-    def wgrad_branch_install(self, side_stream):
-        """collect the projection weight-gradient launches instead of issuing them inline (None uninstalls)"""
-        self.wg_branch = None if side_stream is None else {'side': side_stream, 'jobs': []}
+        def launch(keep, jobs=jobs):
+            arr = (_lib.ReduceJob * len(jobs))(*[j for j, _ in jobs])
+            _lib.call('ltu_reduce_batch', ctypes.addressof(arr), len(jobs), _s())
+        self.wq_push(launch, [ws for _, ws in jobs])
 
-    def wgrad_branch_flush(self):
-        """issue the collected launches on the side stream, ordered after everything issued so far on the current stream"""
-        br = self.wg_branch
-        if br is None or not br['jobs']:
+    def flush_deferred(self):
+        """fold every pending partial-sum workspace into its gradient and launch every weight gradient still held back
+        (stream-ordered; call before gradients are consumed)"""
+        self.wgrad_group_flush()
+        self._fold_flush()
+        self.wq_flush()
+
+    # -- weight-gradient queue (round 4).  Weight gradients are consumed only at the end of the step (or by a bucket's all-reduce),
+    # so they need not sit on the data-gradient chain: with a queue installed their launches are collected as closures and issued in
+    # batches at the flush points (the input of every token transformer, a closing gradient bucket, the end of backward) on a SIDE
+    # stream, where they run beside the latency-bound data-gradient kernels of the coarser levels.  train.GraphedStep captures each
+    # batch as a linear graph of its own and replays it on the side stream between the linear segments of the main chain (`on_flush`;
+    # no graph contains a fork: a fork inside a replayed graph costs more than it gains on ROCm 7, DESIGN.md section 6).
+    # Operands and workspaces of a batch stay alive until `wq_join` (the main stream has waited for the side stream): nothing
+    # the main chain allocates meanwhile can land on memory a batch still reads.
+    def wq_install(self, side_stream, on_flush=None):
+        """side_stream None uninstalls.  on_flush(run): called instead of issuing a batch on the side stream (run() issues it on the
+        current stream - the caller brackets it with its own capture)"""
+        self.wq = None if side_stream is None else {'side': side_stream, 'jobs': [], 'keep': [], 'on_flush': on_flush, 'running': False,
+                                                    'batches': 0}
+
+    def wq_push(self, fn, tensors=()):
+        """fn(keep): launches weight-gradient kernels on the current stream, appending the workspaces it allocates to `keep`"""
+        q = self.wq
+        if q is None or q['running']:
+            fn(q['keep'] if q is not None else [])
             return
-        side = br['side']
+        q['jobs'].append(fn)
+        q['keep'].extend(t for t in tensors if t is not None)
+
+    def wq_flush(self):
+        """issue the collected launches as one batch on the side stream, ordered behind everything issued so far on this stream"""
+        q = self.wq
+        if q is None or q['running'] or not q['jobs']:
+            return
+        jobs, q['jobs'] = q['jobs'], []
+        q['batches'] += 1
+
+        def run():
+            q['running'] = True
+            try:
+                for fn in jobs:
+                    fn(q['keep'])
+            finally:
+                q['running'] = False
+        if q['on_flush'] is not None:
+            q['on_flush'](run)
+            return
+        side = q['side']
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for fn, tensors in br['jobs']:
-                for t in tensors:
-                    t.record_stream(side)          # allocated on the main stream, read by the side stream
-                fn()
-        br['jobs'].clear()
+            run()
 
-    def wgrad_branch_join(self):
-        """flush what is left and make the current stream wait for the branch (end of backward)"""
-        br = self.wg_branch
-        if br is None:
+    def wq_side(self):
+        """the stream the queued weight gradients run on (None without a queue): a bucket's all-reduce has to wait for it too"""
+        return None if self.wq is None else self.wq['side']
+
+    def wq_join(self):
+        """end of backward: launch what is left, make the current stream wait for the side stream, release the kept tensors"""
+        q = self.wq
+        if q is None:
             return
-        self.wgrad_branch_flush()
-        torch.cuda.current_stream().wait_stream(br['side'])
+        self.flush_deferred()
+        if q['on_flush'] is None:
+            torch.cuda.current_stream().wait_stream(q['side'])
+        q['keep'].clear()
 
 
 _DEFAULT_CTX = Context()
@@ -273,14 +318,6 @@ def scratch_zeros(shape, device):
 
 def flush_deferred():
     current().flush_deferred()
-
-
-def wgrad_branch_install(side_stream):
-    current().wgrad_branch_install(side_stream)
-
-
-def wgrad_branch_join():
-    current().wgrad_branch_join()
 
 
 # ---------------------------------------------------------------------------------------------- gradients of parameters
@@ -327,6 +364,7 @@ DEFER_WGRAD = False
 GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_linear_wgrad_group)
 import os as _os
 WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '128'))     # operand bytes of the layers' weight-gradient groups launched together
+WQ_FLUSH_AT_TRANSFORMER = _os.environ.get('LTU_WQ_FLUSH', 'transformer') == 'transformer'     # weight-gradient queue: a batch per transformer
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
 
 
@@ -345,13 +383,16 @@ class _WgradFlushPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.lc.wgrad_group_flush()
-        ctx.lc.wgrad_branch_flush()
+        lc = ctx.lc
+        lc.wgrad_group_flush()
+        if lc.wq is not None and WQ_FLUSH_AT_TRANSFORMER:
+            lc._fold_flush()
+            lc.wq_flush()
         return g
 
 
 def wgrad_flush_point(x):
-    return _WgradFlushPoint.apply(x) if ((current().wg_branch is not None or WGRAD_DEFER_MB > 0) and x.requires_grad) else x
+    return _WgradFlushPoint.apply(x) if ((current().wq is not None or WGRAD_DEFER_MB > 0) and x.requires_grad) else x
 
 
 def _wgrad_ws(M, N, K, like):
@@ -507,9 +548,15 @@ class _Conv3d(torch.autograd.Function):
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
         # the weight gradient lands directly in the PyTorch layout [Co,Ci,3,3,3]; padded rows / channels are dropped
-        ws = _wgrad_ws(g.numel() // cop, cop, 27 * CiP, x0)
-        _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd, int(ups),
-                  Co, Ci, _p(ws), dt, _s())
+        def launch(keep):
+            ws = _wgrad_ws(g.numel() // cop, cop, 27 * CiP, x0)
+            keep.append(ws)
+            _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd, int(ups),
+                      Co, Ci, _p(ws), dt, _s())
+        if fw and fb:
+            lc.wq_push(launch, (g, x0, x1))          # fused gradient buffers: nothing reads them before the end of the step
+        else:
+            launch([])
         return dx0, dx1, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None, None, None, None
 
 
@@ -595,9 +642,15 @@ class _Conv3dPair(torch.autograd.Function):
         dba, fba = _grad_buf(ba)
         dwb, fwb = _grad_buf(wb)
         dbb, fbb = _grad_buf(bb)
-        ws = _wgrad_ws(g0.numel() // n0, n0 + n1, 27 * C, x)
-        _lib.call('ltu_conv3d_pair_wgrad', _p(g0), _p(g1), _p(x), _p(dwa), _p(dba), _p(dwb), _p(dbb), B, H, W, D, C, n0, n1,
-                  wa.shape[0], wb.shape[0], wa.shape[1], _p(ws), dt, _s())
+        def launch(keep):
+            ws = _wgrad_ws(g0.numel() // n0, n0 + n1, 27 * C, x)
+            keep.append(ws)
+            _lib.call('ltu_conv3d_pair_wgrad', _p(g0), _p(g1), _p(x), _p(dwa), _p(dba), _p(dwb), _p(dbb), B, H, W, D, C, n0, n1,
+                      wa.shape[0], wb.shape[0], wa.shape[1], _p(ws), dt, _s())
+        if fwa and fba and fwb and fbb:
+            lc.wq_push(launch, (g0, g1, x))
+        else:
+            launch([])
         outs = [_grad_done(wa, dwa, fwa), _grad_done(ba, dba, fba), _grad_done(wb, dwb, fwb), _grad_done(bb, dbb, fbb)]
         return (dx, *outs, None)
 
@@ -668,10 +721,17 @@ class _UpConv3d(torch.autograd.Function):
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
         dweff = lc.scratch_zeros((8, Co, 8, Ci), x.device)
-        ws = None
-        if x.dtype == torch.bfloat16:
-            ws = torch.empty(_lib.load().ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci), device=x.device, dtype=torch.float32)
-        _lib.call('ltu_upconv_wgrad', _p(g), _p(x), _p(dweff), _p(db), _p(dw), Co, Ci, _p(ws), B, H, W, D, Ci, Co, dt, _s())
+
+        def launch(keep):
+            ws = None
+            if x.dtype == torch.bfloat16:
+                ws = torch.empty(_lib.load().ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci), device=x.device, dtype=torch.float32)
+                keep.append(ws)
+            _lib.call('ltu_upconv_wgrad', _p(g), _p(x), _p(dweff), _p(db), _p(dw), Co, Ci, _p(ws), B, H, W, D, Ci, Co, dt, _s())
+        if fw and fb:
+            lc.wq_push(launch, (g, x))
+        else:
+            launch([])
         return dx, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None
 
 
@@ -724,18 +784,19 @@ class _Linear(torch.autograd.Function):
         gw = [_grad_buf(w) for w in ws]
         gb = [_grad_buf(b) for b in bs]
         grp = ctx.prep.group if ctx.prep is not None else None
-        if (grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16 and lc.wg_branch is None
+        if (grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16
                 and all(f for _, f in gw) and all(f for _, f in gb)):
             lc.wgrad_group_push(g, x, [t for t, _ in gw], [t for t, _ in gb], M, N, K, grp == 'flush')
             dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
             dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
             return (dx, None, *dws, *dbs)
-        if lc.wg_branch is not None and all(f for _, f in gw) and all(f for _, f in gb):
-            def launch(g=g, x=x, gw=gw, gb=gb):
+        if lc.wq is not None and all(f for _, f in gw) and all(f for _, f in gb):
+            def launch(keep):
                 wsb = _wgrad_ws(M, N, K, x)
+                keep.append(wsb)
                 _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
                           M, N, K, _p(wsb), 0, dt, _s())
-            lc.wg_branch['jobs'].append((launch, (g, x)))
+            lc.wq_push(launch, (g, x))
             dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
             dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
             return (dx, None, *dws, *dbs)
@@ -797,16 +858,17 @@ class _LinearGelu(torch.autograd.Function):
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
 
-        def launch(g=g, x=x):
+        def launch(keep):
             wsb = _wgrad_ws(M, N, K, x)
+            keep.append(wsb)
             _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
         grp = ctx.prep.group if ctx.prep is not None else None
-        if grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16 and lc.wg_branch is None and fw and fb:
+        if grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16 and fw and fb:
             lc.wgrad_group_push(g, x, [dw], [db], M, N, K, grp == 'flush')
-        elif lc.wg_branch is not None and fw and fb:
-            lc.wg_branch['jobs'].append((launch, (g, x)))
+        elif fw and fb:
+            lc.wq_push(launch, (g, x))
         else:
-            launch()
+            launch([])
         return dx, None, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
 
 
@@ -969,7 +1031,7 @@ def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):
     gw = [_grad_buf(w) for w in ws]
     gb = [_grad_buf(b) for b in bs]
     dws, dbs = [t for t, _ in gw], [t for t, _ in gb]
-    if GROUP_WGRAD and lc.wg_branch is None and all(f for _, f in gw) and all(f for _, f in gb):
+    if GROUP_WGRAD and all(f for _, f in gw) and all(f for _, f in gb):
         lc.wgrad_group_push(g, x, dws, dbs, M, N, K, False)
     else:
         _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(ws), M, N, K,
@@ -1052,7 +1114,7 @@ class _LayerTail(torch.autograd.Function):
                 gw = [_grad_buf(w) for w in nws]
                 gb = [_grad_buf(b) for b in nbs]
                 dws, dbs = [t for t, _ in gw], [t for t, _ in gb]
-                if GROUP_WGRAD and lc.wg_branch is None and all(f for _, f in gw) and all(f for _, f in gb):
+                if GROUP_WGRAD and all(f for _, f in gw) and all(f for _, f in gb):
                     lc.wgrad_group_push(gq, y, dws, dbs, M, 3 * d, d, True)
                 else:
                     _lib.call('ltu_linear_wgrad', _p(gq), 3 * d, _p(y), d, _ptr_array(dws), _ptr_array(dbs), 3, M, 3 * d, d,
@@ -1428,10 +1490,15 @@ class _Gate(torch.autograd.Function):
         dbx, f2 = _grad_buf(bx)
         dwg, f3 = _grad_buf(wg)
         dbg, f4 = _grad_buf(bg)
-        _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _ptr_array([dwx]), _ptr_array([dbx]), 1, M, C, C,
-                  _p(_wgrad_ws(M, C, C, skip)), 0, dt, _s())
-        _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _ptr_array([dwg]), _ptr_array([dbg]), 1, M, C, Cg,
-                  _p(_wgrad_ws(M, C, Cg, skip)), 0, dt, _s())
+        def launch(keep):
+            w1, w2 = _wgrad_ws(M, C, C, skip), _wgrad_ws(M, C, Cg, skip)
+            keep.extend((w1, w2))
+            _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _ptr_array([dwx]), _ptr_array([dbx]), 1, M, C, C, _p(w1), 0, dt, _s())
+            _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _ptr_array([dwg]), _ptr_array([dbg]), 1, M, C, Cg, _p(w2), 0, dt, _s())
+        if f1 and f2 and f3 and f4:
+            lc.wq_push(launch, (du1, du2, skip, up))
+        else:
+            launch([])
         return (dskip, dup, _grad_done(wx, dwx, f1), _grad_done(bx, dbx, f2), _grad_done(wg, dwg, f3), _grad_done(bg, dbg, f4),
                 _grad_done(pw, dpw, fpw), _grad_done(pb, dpb, fpb), None, None)
 

@@ -97,7 +97,7 @@ def train_step(model, images, labels, weights, step_times=1, specs=None, reducer
             reducer.prepare(lc, reduce=reduce)
         one = lc.one(images.device)
         torch.autograd.backward(totals, [one] * len(totals))
-        lc.wgrad_branch_join()               # weight-gradient branch (if one is installed) back into this stream
+        lc.wq_join()                         # weight-gradient queue (if one is installed): last batch, side stream back into this one
         lc.flush_deferred()                  # second stages of the two-stage reductions still queued by backward
         if reducer is not None:
             reducer.finish()
@@ -198,8 +198,9 @@ class GradReducer:
         rest = [p for b in self.buckets for p in b if p not in seen]
         self._assign(list(self.ready_order) + rest)
 
-    def _all_reduce(self, flat):
-        return self.comm.allreduce_avg(flat)
+    def _all_reduce(self, flat, also=None):
+        """also: a second stream whose work the bucket depends on (the weight-gradient queue's side stream)"""
+        return self.comm.allreduce_avg(flat, also) if also is not None else self.comm.allreduce_avg(flat)
 
     def zero_grad(self):
         for f in self.flat:
@@ -235,7 +236,7 @@ class GradReducer:
                 self.cut.append(bi)
                 self.on_bucket(bi)
             else:
-                self.handles.append((bi, self._all_reduce(self.flat[bi])))
+                self.handles.append((bi, self._all_reduce(self.flat[bi], self.ctx.wq_side())))
 
     def reduce_all(self):
         """all-reduce every bucket now (after a graph replay that did not capture the collectives)"""
@@ -254,7 +255,7 @@ class GradReducer:
                 self.cut_rest = rest                  # the caller reduces them after its last segment
             else:
                 for bi in rest:
-                    self.handles.append((bi, self._all_reduce(self.flat[bi])))
+                    self.handles.append((bi, self._all_reduce(self.flat[bi], (self.ctx or ops.current()).wq_side())))
             for bi, h in self.handles:
                 h.wait()
         self.handles = []
@@ -299,8 +300,11 @@ class GraphedStep:
         self.ctx.set_step_counter(self.counter)
         self.level_scale = torch.empty(self.n_levels, device=dev, dtype=torch.float32)
         self.set_weights(weights)
-        # opt-in (LTU_WGRAD_BRANCH=1): measured +0.5 % only (21.09 vs 21.20 ms), see DESIGN.md section 7
-        self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get('LTU_WGRAD_BRANCH', '0') == '1' else None
+        # weight-gradient queue (ops.Context.wq_install): with the step replayed as linear segments, the weight gradients of each
+        # transformer / decoder level are captured as linear graphs of their own and replayed on a side stream beside the
+        # data-gradient chain of the coarser, latency-bound levels (LTU_WQ=0: everything in line)
+        self.wq_stream = (torch.cuda.Stream(device=dev) if (self.overlap == 'segments' and os.environ.get('LTU_WQ', '1') != '0')
+                          else None)
         self.graphs = {}
         self.pool = None
         self._capture((True, True))
@@ -312,17 +316,17 @@ class GraphedStep:
         self.weights = tuple(float(w) for w in weights)
         self.level_scale.copy_(torch.tensor([w / self.step_times for w in self.weights], dtype=torch.float32))
 
-    def _body(self, zero, reduce):
+    def _body(self, zero, reduce, on_flush=None):
         self.counter.add_(1)
         if zero:
             self.reducer.zero_grad()
-        self.ctx.wgrad_branch_install(self.wg_stream)       # projection weight gradients on a second graph branch
+        self.ctx.wq_install(self.wq_stream, on_flush)       # weight gradients in batches on a side stream / as graphs of their own
         try:
             return train_step(self.model, self.x, self.lab, self.weights, step_times=self.step_times, specs=self.specs,
                               reducer=self.reducer, ctx=self.ctx, level_scale=self.level_scale,
                               reduce=reduce and self.overlap in ('graph', 'segments'))
         finally:
-            self.ctx.wgrad_branch_install(None)
+            self.ctx.wq_install(None)
 
     def _signature(self):
         ps = list(self.model.parameters())
@@ -343,7 +347,7 @@ class GraphedStep:
         # Nothing else needs to happen before a capture that contains collectives: the communicator (comm.RcclComm) enqueues
         # RCCL's kernels from this thread through a plain C call, so there is no watchdog or progress thread that could touch an
         # event of the capturing streams (round 2's ProcessGroupNCCL path needed a sleep here and could still abort).
-        if self.overlap == 'segments' and reduce and self.reducer.world > 1:
+        if self.overlap == 'segments' and ((reduce and self.reducer.world > 1) or self.wq_stream is not None):
             segs, totals, named, rest = self._capture_segments(zero, reduce)
         else:
             graph = torch.cuda.CUDAGraph()
@@ -353,7 +357,7 @@ class GraphedStep:
                 totals, named = self._body(zero, reduce)
             if self.pool is None:
                 self.pool = graph.pool()
-            segs, rest = [(graph, None)], []
+            segs, rest = [(graph, 'main', None)], []
         self.ctx.freeze()                  # the graphs hold addresses inside the scratch arena
         self.graphs[key] = (segs, totals, named, rest)
         self.sig = self._signature()
@@ -372,26 +376,41 @@ class GraphedStep:
         torch.cuda.empty_cache()
         stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))
-        segs, cur = [], [None]
+        segs, cur, kind = [], [None], ['main']
 
         def begin():
             cur[0] = torch.cuda.CUDAGraph()
             cur[0].capture_begin(pool=self.pool, capture_error_mode='relaxed')
 
-        def end():
-            with warnings.catch_warnings():          # a segment may be empty (two buckets closing at the same point, or nothing
-                warnings.simplefilter('ignore')      # left after the last one): torch warns about empty graphs
+        def end(bi=None):
+            with warnings.catch_warnings(record=True) as w:          # a segment may be empty (two buckets closing at the same point,
+                warnings.simplefilter('always')                      # or nothing left after the last one): torch warns about empty graphs
                 cur[0].capture_end()
+            empty = any('empty' in str(x.message).lower() for x in w)
+            if not empty or bi is not None:
+                segs.append((None if empty else cur[0], kind[0], bi))
 
         def cut(bi):
-            end()
-            segs.append((cur[0], bi))
+            end(bi)
             begin()
+
+        def on_flush(run):
+            # a batch of weight gradients (ops.Context.wq_flush): the main chain's segment ends here, the batch becomes a linear graph
+            # of its own (replayed on the side stream), the main chain goes on in a new segment
+            end()
+            kind[0] = 'side'
+            begin()
+            try:
+                run()
+            finally:
+                end()
+                kind[0] = 'main'
+                begin()
         with torch.cuda.stream(stream):
             begin()
             red.on_bucket = cut
             try:
-                totals, named = self._body(zero, reduce)
+                totals, named = self._body(zero, reduce, on_flush if self.wq_stream is not None else None)
             except BaseException:
                 try:                       # leave the stream out of capture mode before the error travels on
                     cur[0].capture_end()
@@ -401,7 +420,6 @@ class GraphedStep:
             finally:
                 red.on_bucket = None
             end()
-            segs.append((cur[0], None))
         torch.cuda.current_stream(dev).wait_stream(stream)
         return segs, totals, named, list(red.cut_rest)
 
@@ -423,12 +441,22 @@ class GraphedStep:
             self.lab.copy_(labels, non_blocking=True)
         segs, totals, named, rest = self.graphs[key]
         handles = []
-        for graph, bi in segs:
-            graph.replay()
+        main, side, used_side = torch.cuda.current_stream(self.dev), self.wq_stream, False
+        for graph, kind, bi in segs:
+            if graph is not None:
+                if kind == 'side':             # a batch of weight gradients: beside the next segments of the main chain
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        graph.replay()
+                    used_side = True
+                else:
+                    graph.replay()
             if bi is not None:             # this segment completed bucket bi: its all-reduce runs beside the next segments
-                handles.append(self.reducer._all_reduce(self.reducer.flat[bi]))
+                handles.append(self.reducer._all_reduce(self.reducer.flat[bi], side if used_side else None))
         for bi in rest:
-            handles.append(self.reducer._all_reduce(self.reducer.flat[bi]))
+            handles.append(self.reducer._all_reduce(self.reducer.flat[bi], side if used_side else None))
+        if used_side:
+            main.wait_stream(side)
         for h in handles:
             h.wait()
         if key[1] and self.overlap == 'after':

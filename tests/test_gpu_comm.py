@@ -128,8 +128,10 @@ def test_collectives_see_complete_buckets():
             self.stream = torch.cuda.Stream()
             self.snaps = {}
 
-        def allreduce_avg(self, flat):
+        def allreduce_avg(self, flat, also=None):
             self.stream.wait_stream(torch.cuda.current_stream())
+            if also is not None:                 # the weight-gradient queue's side stream contributed to this bucket too
+                self.stream.wait_stream(also)
             snap = self.snaps.setdefault(flat.data_ptr(), torch.empty_like(flat))
             with torch.cuda.stream(self.stream):
                 snap.copy_(flat)
@@ -171,7 +173,9 @@ def test_collectives_see_complete_buckets():
         comm.snaps.clear()
         step = train.GraphedStep(m, x, lab, w, red, overlap=mode)
         if mode == 'segments':
-            assert len(step.graphs[(True, True)][0]) == len(red.flat) + 1 or len(step.graphs[(True, True)][0]) == len(red.flat)
+            closing = [bi for _, _, bi in step.graphs[(True, True)][0] if bi is not None]      # segments that complete a bucket
+            assert len(closing) + len(step.graphs[(True, True)][3]) == len(red.flat), closing
+            assert any(kind == 'side' for _, kind, _ in step.graphs[(True, True)][0])        # weight gradients as graphs of their own
         for _ in range(2):
             for s in comm.snaps.values():
                 s.zero_()
