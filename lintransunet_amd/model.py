@@ -412,6 +412,10 @@ class MaskTransUnet(nn.Module):
         nblk = len(enc.block_list)
         for i, blk in enumerate(enc.block_list):
             s, s_skip = self._conv_in_act(t, blk.conv1, res=t_r, res_dup=t_r2, seeds=seeds, fork=2)
+            if ops.WQ_FLUSH_IN_ENCODER:
+                # backward reaches this point after conv2's (and the deeper block's conv1's) backward: their queued weight gradients go
+                # out as a batch beside this block's data gradients instead of piling up behind the last kernel of the step
+                s = ops.wgrad_flush_point(s)
             if i < nblk - 1:
                 t, t_r, t_r2 = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds, fork=3)
             else:

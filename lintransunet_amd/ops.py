@@ -244,6 +244,8 @@ class Context:
             return
         q['jobs'].append(fn)
         q['keep'].extend(t for t in tensors if t is not None)
+        if len(q['jobs']) >= WQ_MAX_JOBS:
+            self.wq_flush()
 
     def wq_flush(self):
         """issue the collected launches as one batch on the side stream, ordered behind everything issued so far on this stream"""
@@ -364,6 +366,8 @@ DEFER_WGRAD = False
 GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_linear_wgrad_group)
 import os as _os
 WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '128'))     # operand bytes of the layers' weight-gradient groups launched together
+WQ_MAX_JOBS = int(_os.environ.get('LTU_WQ_JOBS', '1000000'))      # weight-gradient queue: a batch goes out when this many launches are queued
+WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
 WQ_FLUSH_AT_TRANSFORMER = _os.environ.get('LTU_WQ_FLUSH', 'transformer') == 'transformer'     # weight-gradient queue: a batch per transformer
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
 

@@ -303,7 +303,7 @@ class GraphedStep:
         # weight-gradient queue (ops.Context.wq_install): with the step replayed as linear segments, the weight gradients of each
         # transformer / decoder level are captured as linear graphs of their own and replayed on a side stream beside the
         # data-gradient chain of the coarser, latency-bound levels (LTU_WQ=0: everything in line)
-        self.wq_stream = (torch.cuda.Stream(device=dev) if (self.overlap == 'segments' and os.environ.get('LTU_WQ', '1') != '0')
+        self.wq_stream = (torch.cuda.Stream(device=dev, priority=int(os.environ.get('LTU_WQ_PRIO', '0'))) if (self.overlap == 'segments' and os.environ.get('LTU_WQ', '1') != '0')
                           else None)
         self.graphs = {}
         self.pool = None
