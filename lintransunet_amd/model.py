@@ -163,14 +163,24 @@ class _WeightStore:
             chunks += [(i, c) for c in range((n + WPREP_CHUNK - 1) // WPREP_CHUNK)]
         self.nchunks = len(chunks)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(self.device)
+        # the records added before `mark_first()` (the encoder's convs) form part 0 of the work list, the rest part 1: the model
+        # refreshes part 1 on the side stream, beside the encoder (ops.Context.side_run)
+        nf = getattr(self, 'n_first', 0)
+        self.split = sum(1 for i, _ in chunks if i < nf)
 
     def stale(self):
         """parameter storage moved (e.g. .to(), load with assign): the table must be rebuilt"""
         return any(src.data_ptr() != p0 for src, p0 in zip(self.srcs, self.ptrs))
 
-    def refresh(self):
-        ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks,
-                      ops.F32 if self.dtype == torch.float32 else ops.BF16, torch.cuda.current_stream().cuda_stream)
+    def mark_first(self):
+        self.n_first = len(self.recs)
+
+    def refresh(self, part=None):
+        """part None: everything; 0: the operands of the first layers (see `mark_first`); 1: the rest"""
+        lo, hi = {None: (0, self.nchunks), 0: (0, self.split), 1: (self.split, self.nchunks)}[part]
+        if hi > lo:
+            ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr() + lo * 8, hi - lo,
+                          ops.F32 if self.dtype == torch.float32 else ops.BF16, torch.cuda.current_stream().cuda_stream)
 
 
 class MaskTransUnet(nn.Module):
@@ -250,6 +260,7 @@ class MaskTransUnet(nn.Module):
         for blk in enc.block_list:
             st.add_conv(blk.conv1)
             st.add_conv(blk.conv2)
+        st.mark_first()
         # a decoder level's conv1 and its mask head read the same upsampled tensor: one fused conv (head padded to 16 / 32 columns
         # so that the pair's data gradient keeps 32-channel chunks)
         nl = len(self.num_layers)
@@ -400,7 +411,11 @@ class MaskTransUnet(nn.Module):
             raise ValueError('H and W must be even')
         enc, dec = self.encode, self.decode
         store = self._weights(x.device)
-        store.refresh()                      # one launch: every cast / transposed / repacked weight of this step
+        # every cast / transposed / repacked weight of this step: the encoder's operands here, everything else in a second launch
+        # that a context with a side stream (train.GraphedStep) runs beside the encoder
+        lc = ops.current()
+        store.refresh(0)
+        lc.side_run(lambda: store.refresh(1))
 
         # Tensors with several consumers are produced with one output port per consumer (ops._ports): a block input feeds the
         # block's conv1 and its residual (whose gradient arrives in two parts, because the block output itself has two consumers:
@@ -422,6 +437,7 @@ class MaskTransUnet(nn.Module):
                 t, t_r = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds, fork=2)
             skips.append(s_skip)
 
+        lc.side_join()                       # the operands of everything behind the encoder are ready
         bt = dec.bridge_list[nl - 1].transformer
         t = self._token_transformer(bt.layers, bt.pos_encoders[0], t, p, seeds, x_res=t_r)
         masks = []

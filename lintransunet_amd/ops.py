@@ -230,11 +230,38 @@ class Context:
     # no graph contains a fork: a fork inside a replayed graph costs more than it gains on ROCm 7).
     # Operands and workspaces of a batch stay alive until `wq_join` (the main stream has waited for the side stream): nothing
     # the main chain allocates meanwhile can land on memory a batch still reads.
-    def wq_install(self, side_stream, on_flush=None):
+    def wq_install(self, side_stream, on_flush=None, on_join=None):
         """side_stream None uninstalls.  on_flush(run): called instead of issuing a batch on the side stream (run() issues it on the
-        current stream - the caller brackets it with its own capture)"""
-        self.wq = None if side_stream is None else {'side': side_stream, 'jobs': [], 'keep': [], 'on_flush': on_flush, 'running': False,
-                                                    'batches': 0}
+        current stream - the caller brackets it with its own capture); on_join(): called instead of making the current stream wait
+        for the side stream (`side_join`)"""
+        self.wq = None if side_stream is None else {'side': side_stream, 'jobs': [], 'keep': [], 'on_flush': on_flush, 'on_join': on_join,
+                                                    'running': False, 'batches': 0, 'side_pending': False}
+
+    # -- forward-side work on the same side stream: what the first kernels of the step do not need yet (the weight operands of
+    # everything behind the encoder, the label pyramid) runs beside the encoder; `side_join` is placed in front of its first consumer
+    def side_run(self, fn):
+        q = self.wq
+        if q is None or not WQ_SIDE_FWD:
+            fn()
+            return
+        q['side_pending'] = True
+        if q['on_flush'] is not None:
+            q['on_flush'](fn)
+            return
+        side = q['side']
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+
+    def side_join(self):
+        q = self.wq
+        if q is None or not q['side_pending']:
+            return
+        q['side_pending'] = False
+        if q['on_join'] is not None:
+            q['on_join']()
+        else:
+            torch.cuda.current_stream().wait_stream(q['side'])
 
     def wq_push(self, fn, tensors=()):
         """fn(keep): launches weight-gradient kernels on the current stream, appending the workspaces it allocates to `keep`"""
@@ -367,6 +394,7 @@ GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_li
 import os as _os
 WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '128'))     # operand bytes of the layers' weight-gradient groups launched together
 WQ_MAX_JOBS = int(_os.environ.get('LTU_WQ_JOBS', '1000000'))      # weight-gradient queue: a batch goes out when this many launches are queued
+WQ_SIDE_FWD = _os.environ.get('LTU_WQ_FWD', '1') == '1'      # forward-side work (weight operands behind the encoder, label pyramid) on the side stream
 WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
 WQ_FLUSH_AT_TRANSFORMER = _os.environ.get('LTU_WQ_FLUSH', 'transformer') == 'transformer'     # weight-gradient queue: a batch per transformer
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer

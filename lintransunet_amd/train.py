@@ -62,14 +62,14 @@ def label_pyramid(label, n_levels=5):
     return out
 
 
-def deep_supervision_loss(predict, masks, label, weights, specs=None, scale=1.0, level_scale=None):
+def deep_supervision_loss(predict, masks, label, weights, specs=None, scale=1.0, level_scale=None, pyr=None):
     """Per-level fused losses (utils/utils_3D_embed_full.py:66-82).  Returns (list of weighted level totals,
     list of {name: value}); `sum(totals)` is the reference's total_loss * scale.
     level_scale: optional fp32 device tensor [n_levels] that REPLACES `weights[lvl] * scale` at run time (a captured graph
     then follows the per-epoch weights of train3D.py:122-137 and the accumulation count without re-capture)."""
     n = len(weights)
     specs = specs or level_specs(n)
-    pyr = label_pyramid(label, n)
+    pyr = pyr or label_pyramid(label, n)      # pyr: the pyramid, already built (train_step builds it beside the encoder)
     totals, named = [], []
     for lvl in range(n):
         pred = predict if lvl == 0 else masks[-lvl]
@@ -91,8 +91,12 @@ def train_step(model, images, labels, weights, step_times=1, specs=None, reducer
     lc = ctx or ops.current()
     with ops.use(lc):
         lc.begin_step(images.device)
+        pyr = []
+        lc.side_run(lambda: pyr.extend(label_pyramid(labels, len(weights))))     # beside the encoder (joined inside the model's forward)
         predict, masks = model(images)
-        totals, named = deep_supervision_loss(predict, masks, labels, weights, specs, scale=1.0 / step_times, level_scale=level_scale)
+        lc.side_join()
+        totals, named = deep_supervision_loss(predict, masks, labels, weights, specs, scale=1.0 / step_times, level_scale=level_scale,
+                                              pyr=pyr)
         if reducer is not None:
             reducer.prepare(lc, reduce=reduce)
         one = lc.one(images.device)
@@ -316,11 +320,11 @@ class GraphedStep:
         self.weights = tuple(float(w) for w in weights)
         self.level_scale.copy_(torch.tensor([w / self.step_times for w in self.weights], dtype=torch.float32))
 
-    def _body(self, zero, reduce, on_flush=None):
+    def _body(self, zero, reduce, on_flush=None, on_join=None):
         self.counter.add_(1)
         if zero:
             self.reducer.zero_grad()
-        self.ctx.wq_install(self.wq_stream, on_flush)       # weight gradients in batches on a side stream / as graphs of their own
+        self.ctx.wq_install(self.wq_stream, on_flush, on_join)       # weight gradients in batches on a side stream / as graphs of their own
         try:
             return train_step(self.model, self.x, self.lab, self.weights, step_times=self.step_times, specs=self.specs,
                               reducer=self.reducer, ctx=self.ctx, level_scale=self.level_scale,
@@ -394,6 +398,11 @@ class GraphedStep:
             end(bi)
             begin()
 
+        def on_join():
+            end()
+            segs.append((None, 'join', None))
+            begin()
+
         def on_flush(run):
             # a batch of weight gradients (ops.Context.wq_flush): the main chain's segment ends here, the batch becomes a linear graph
             # of its own (replayed on the side stream), the main chain goes on in a new segment
@@ -410,7 +419,7 @@ class GraphedStep:
             begin()
             red.on_bucket = cut
             try:
-                totals, named = self._body(zero, reduce, on_flush if self.wq_stream is not None else None)
+                totals, named = self._body(zero, reduce, *((on_flush, on_join) if self.wq_stream is not None else (None, None)))
             except BaseException:
                 try:                       # leave the stream out of capture mode before the error travels on
                     cur[0].capture_end()
@@ -443,7 +452,9 @@ class GraphedStep:
         handles = []
         main, side, used_side = torch.cuda.current_stream(self.dev), self.wq_stream, False
         for graph, kind, bi in segs:
-            if graph is not None:
+            if kind == 'join':                 # the main chain needs what the side stream has produced so far
+                main.wait_stream(side)
+            elif graph is not None:
                 if kind == 'side':             # a batch of weight gradients: beside the next segments of the main chain
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
