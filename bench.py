@@ -362,12 +362,11 @@ def main():
     timer.on = False
     reducer.rebucket()                        # buckets in gradient-ready order (recorded by the eager step): each bucket's all-reduce
                                               # starts while backward still produces the next one
-    # per-family device time of the step (tools/family_timer.py): the C-ABI calls that go into the captured step graph are logged,
-    # then each family's launches are replayed alone from a graph of their own between one HIP event pair
+    # per-family device time of the step (lintransunet_amd/family_timer.py): the C-ABI calls that go into the captured step graph are
+    # logged; AFTER the timed region each family's launches are replayed alone from a graph of their own between one HIP event pair
     families, ft = None, None
     if not args.no_families and not args.no_graph:
-        sys.path.insert(0, os.path.join(ROOT, 'tools'))
-        from family_timer import FamilyTimer
+        from lintransunet_amd.family_timer import FamilyTimer
         ft = FamilyTimer()
     for c in timer.calls:
         chain_buffers(*c[1].shape)            # allocate / prepare outside the timed replay
@@ -375,7 +374,7 @@ def main():
     n_lin *= 2                                # one forward and one backward launch per recorded layer
     timer.calls = []
 
-    launch = 'eager'
+    launch, graph_mode, graphed = 'eager', None, None
     allreduce = 'hooks (overlapped with backward)' if (world > 1 or args.rehearse_comm) else 'none (1 rank)'
     step = eager_step
     if not args.no_graph:
@@ -405,12 +404,31 @@ def main():
                 print(f'[bench] rank {rank}: HIP-graph capture with all-reduce mode {mode!r} failed ({type(e).__name__}: {e})',
                       file=sys.stderr)
                 torch.cuda.synchronize()
+                # At N > 1 a silent step down the ladder would read as a scaling defect (the collectives of 'after' are fully
+                # exposed): the first multi-GPU run fails loudly instead, unless the caller asked for a mode or allows the fallback
+                if world > 1 and not args.allreduce and os.environ.get('LTU_ALLOW_FALLBACK', '0') != '1':
+                    print(f'[bench] rank {rank}: not falling back at world {world} (LTU_ALLOW_FALLBACK=1 allows it)', file=sys.stderr)
+                    raise
+        graph_mode = mode if launch == 'hip-graph replay' else None
 
-    if ft is not None and ft.calls and launch == 'hip-graph replay':
-        families = ft.table(ft.measure(), args.size, args.batch)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    diag = {}
+    if world > 1:
+        # self-diagnosis of the multi-rank step (the first N > 1 RCCL execution happens on the driver's node): after the warm-up
+        # steps every rank must hold the SAME averaged gradients - per-bucket checksums, MAX - MIN over ranks through the gloo
+        # control plane - or the run fails non-zero
+        sums = torch.stack([torch.stack([f.double().sum(), f.double().abs().sum()]) for f in reducer.flat]).cpu()
+        hi, lo = sums.clone(), sums.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        spread = ((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max().item()
+        diag['bucket_checksum_spread_over_ranks'] = spread
+        if not (spread == 0.0) or not bool(torch.isfinite(sums).all()) or float(sums[:, 1].min()) == 0.0:
+            print(f'[bench] rank {rank}: gradient buckets differ between ranks after the all-reduce (relative spread {spread:.3e}, '
+                  f'checksums {sums.tolist()}): the exchange is broken', file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         comm.barrier()
     torch.cuda.synchronize()
@@ -424,6 +442,34 @@ def main():
     timer.on = False
     if world > 1:
         dt = comm.max_float(dt)
+    if (world > 1 or args.rehearse_comm or os.environ.get('LTU_BENCH_LOCAL') == '1') and launch == 'hip-graph replay':
+        # what the exchange costs: the same replayed step without its collectives, and where in the step each bucket closes
+        for i in range(2):
+            graphed.replay_local(*batches[i % 2])
+        torch.cuda.synchronize()
+        if world > 1:
+            comm.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            graphed.replay_local(*batches[i % 2])
+        torch.cuda.synchronize()
+        if world > 1:
+            comm.barrier()
+        dt_local = time.perf_counter() - t1
+        if world > 1:
+            dt_local = comm.max_float(dt_local)
+        marks, total = graphed.bucket_timeline()
+        diag['ms_per_step_without_collectives'] = dt_local / args.steps * 1e3
+        diag['exposed_collective_ms'] = (dt - dt_local) / args.steps * 1e3
+        diag['buckets'] = [{'bucket': bi, 'MB': round(mb, 2), 'closes_at_ms': round(t, 3)} for bi, mb, t in marks]
+        diag['compute_ms_of_that_replay'] = round(total, 3)
+        # expectation: ring all-reduce, 2 (N-1)/N x bytes per GPU at 100-150 GB/s effective per link direction:
+        # every bucket but the last finishes under the remaining compute; ~0.3 ms of segment / launch overhead + the tail bucket's latency
+        diag['expected'] = 'exposed <= ~0.4 ms at 8 ranks (32 MB buckets + 0.5 MB tail): >= 7.7x weak scaling'
+    if ft is not None and ft.calls and launch == 'hip-graph replay':
+        families = ft.table(ft.measure(), args.size, args.batch)      # replays kernels on stale buffers: after the timed region
+        reducer.zero_grad()                                            # ... and the weight-gradient kernels among them accumulate
+        torch.cuda.synchronize()
 
     if rank == 0:
         patches = args.batch * world * args.steps
@@ -445,7 +491,11 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'MaskTransUnet train step (fwd + 5-level loss + bwd), {args.size}^3 single-channel patches, '
                                    f'{args.batch} per GPU, dropout 0.3, random-init weights' + (', 3 labels (multi-class losses)' if args.classes == 3 else ''), 'global_batch': args.batch * world,
-                       'patch': [args.size] * 3, 'parallelism': f'dp{world}', 'launch': launch,
+                       'patch': [args.size] * 3, 'parallelism': f'dp{world}',
+                       'launch': launch + (f' ({graph_mode}: linear graph segments, weight gradients as graphs of their own on a side stream)'
+                                           if graph_mode == 'segments' and graphed.wq_stream is not None else
+                                           f' ({graph_mode})' if graph_mode else ''),
+                       **({'multi_rank_diagnosis': diag} if diag else {}),
                        'allreduce': allreduce + (' [REHEARSAL: host-staged test communicator, ranks share one GPU - not a measurement]' if args.test_comm else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'tail_fwd_kernel + tail_bwd_kernel (row-block chain kernels: post-attention half of every transformer layer - with the next layer\'s q|k|v projection where the layers are adjacent - forward and backward)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

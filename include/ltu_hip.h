@@ -18,7 +18,11 @@
  *     LDS limit raised" latches for four kernels (atomic bit masks).
  *   - Dropout: (p, seed) select a counter-based hash mask (a murmur3 finalizer + a linear expansion to 64 bits per
  *     4-element group, csrc/common.h); the backward entry points regenerate
- *     the mask from the same (p, seed) instead of reading a stored one.  p = 0 disables.  `step` (nullable) is a
+ *     the mask from the same (p, seed) instead of reading a stored one.  Independence: the four keep decisions of a group are
+ *     PAIRWISE independent only (every pair of the four 16-bit words is a full-rank GF(2) image of the 32-bit hash; the third and
+ *     fourth word are deterministic functions of the first two), not 4-wise independent like nn.Dropout's Bernoulli draws; groups
+ *     are independent of each other.  tests/test_gpu_ops.py::test_dropout_group_pattern_histogram holds the joint 16-pattern
+ *     histogram of a group against Bernoulli^4.  p = 0 disables.  `step` (nullable) is a
  *     device-resident counter mixed into the seed at run time, so a captured HIP graph draws fresh masks per replay.
  *   - Return value: 0 = LTU_OK, negative = LTU_E_* argument error, positive = hipError_t.
  */
@@ -39,6 +43,8 @@ enum { LTU_OK = 0, LTU_E_DTYPE = -1, LTU_E_SHAPE = -2, LTU_E_ALIGN = -3, LTU_E_A
 enum { LTU_ACT_NONE = 0, LTU_ACT_LRELU = 1 };
 
 int ltu_version(void);
+/* bit 0: built with -DLTU_EXPERIMENTS (kernel variants that lost their measurements and ltu_selftest_last_arriver are compiled in) */
+int ltu_build_flags(void);
 /* Tuning / ablation knobs (grid sizes, split counts, kernel-variant switches; names = the LTU_* environment variables
  * listed in DESIGN.md).  Sets (clear = 0) or removes (clear != 0) a process-wide override that takes precedence over
  * the environment.  Results never depend on a knob beyond fp32 summation order.  Used by the tests to force code
@@ -49,6 +55,7 @@ int ltu_config_set(const char* name, int value, int clear);
  * multiple of 64.  Exists because the permlane-swap builtins of hipcc 7.2 miscompile (tests/test_gpu_ops.py keeps the inline-asm
  * replacement honest on the hardware). */
 int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, int n, int G, ltu_stream_t s);
+#ifdef LTU_EXPERIMENTS      /* exported by an experiments build only (make EXPERIMENTS=1); ltu_build_flags() & 1 tells */
 /* Self-test and price of an in-launch "last arriver" fold against the two-stage form the step uses (per-workgroup partial rows + a
  * second small launch): nwg workgroups with uneven load (workgroup i sums 1 + (7 i mod skew) chunks of rows_per_chunk rows of x
  * [rows][n], n <= 256) publish one partial row each; mode 0 folds them with a second launch, mode 1 inside the launch (write-through
@@ -58,6 +65,7 @@ int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, int n, int 
  * launches of it in one process; tools/bench_last_arriver.py times both forms. */
 int ltu_selftest_last_arriver(const float* x, float* part, float* out, unsigned* counter, float* sink, int nwg, int n,
                               int rows_per_chunk, int skew, int mode, ltu_stream_t s);
+#endif
 
 /* ---- window embedding: model/Unet_3Dblock.py:123-136 ------------------------------------------
  * x f32 [B,1,H,W,D] (reference layout) -> y T [B,H/2,W/2,D,8]; channel kh*2+kw, channels 4..7 = 0

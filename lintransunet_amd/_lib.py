@@ -31,9 +31,9 @@ WGRAD_GROUP_MAX = 32      # LTU_WGRAD_GROUP_MAX of include/ltu_hip.h
 # name -> argument types (return type is always int).  Mirrors include/ltu_hip.h one to one.
 SIGNATURES = {
     'ltu_version': [],
+    'ltu_build_flags': [],
     'ltu_config_set': [ctypes.c_char_p, I, I],
     'ltu_selftest_group_reduce': [P, P, P, I, I, P],
-    'ltu_selftest_last_arriver': [P, P, P, P, P, I, I, I, I, I, P],
     'ltu_window_embed': [P, P, I, I, I, I, I, P],
     'ltu_pack_conv_weight': [P, P, P, I, I, I, I, I, P],
     'ltu_unpack_conv_wgrad': [P, P, I, I, I, P],
@@ -116,6 +116,11 @@ SIGNATURES = {
     'ltu_comm_destroy': [P],
 }
 
+# exported by an experiments build only (make -C lintransunet_amd/csrc EXPERIMENTS=1): bound when present
+EXPERIMENT_SIGNATURES = {
+    'ltu_selftest_last_arriver': [P, P, P, P, P, I, I, I, I, I, P],
+}
+
 _lib = None
 
 
@@ -139,8 +144,17 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
         fn.restype = c_longlong if (name.endswith(('_ws_floats', '_ws_elems')) or name == 'ltu_layer_tail_blocks') else c_int
+    for name, args in EXPERIMENT_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = args, c_int
     _lib = lib
     return lib
+
+
+def experiments():
+    """True when the library was built with EXPERIMENTS=1 (rejected kernel variants and their self-tests compiled in)"""
+    return bool(load().ltu_build_flags() & 1)
 
 
 _ERR = {-1: 'LTU_E_DTYPE', -2: 'LTU_E_SHAPE', -3: 'LTU_E_ALIGN', -4: 'LTU_E_ARG'}

@@ -171,7 +171,8 @@ class RcclComm:
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device), _stdout_to_stderr():
             _lib.call('ltu_comm_init', ctypes.byref(h), uid.data_ptr(), self.world, self.rank)
-            self.stream = torch.cuda.Stream(device=self.device)
+            from . import ops                # a stream on a hardware queue other than the compute stream's (ops.concurrent_stream)
+            self.stream = ops.concurrent_stream(self.device, [torch.cuda.current_stream(self.device)])
         self.handle = h
         self.calls = 0          # collectives enqueued (eagerly or into a capture): the tests and tools count these
 

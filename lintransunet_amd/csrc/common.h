@@ -164,6 +164,10 @@ __device__ __forceinline__ float4 drop4(const DropCfg& d, uint64_t g4, float4 v)
   // map of h1, i.e. any two elements of a group are independent; tools checked keep rates, pair / lag correlations and the
   // conditional rates P(z | x, y), P(w | x, y, z) against a second murmur finalizer: indistinguishable at 4 M groups).  The second
   // finalizer cost two more quarter-rate multiplies per group: the masks were 0.24 ms of the training step.
+  // LIMIT: pairwise independent only - z and w are deterministic functions of (x, y), so the four decisions of a group are not
+  // 4-wise independent as nn.Dropout's are (different groups are).  The joint 16-pattern histogram of a group is held against
+  // Bernoulli^4 by tests/test_gpu_ops.py::test_dropout_group_pattern_histogram, so a change of the rotations cannot silently bias
+  // the per-group keep counts.
   const uint32_t h2 = h1 ^ ((h1 << 11) | (h1 >> 21)) ^ ((h1 << 19) | (h1 >> 13));
   v.x = (h1 & 0xFFFFu) >= d.thresh ? v.x * d.scale : 0.f;
   v.y = (h1 >> 16) >= d.thresh ? v.y * d.scale : 0.f;

@@ -736,7 +736,11 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   if (a.c0 % a.CC != 0 && a.c0 != a.C) return 1;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
+#ifdef LTU_EXPERIMENTS
   a.no_xcd_order = ltu_knob("LTU_HALO_NO_XCD", 0);
+#else
+  a.no_xcd_order = 0;
+#endif
   if (a.N <= 32 && a.C <= 32 && !ltu_knob("LTU_NO_HALO_WS", 0)) {      // few channels: weights stationary, persistent over bricks
     int wsb = -1;
     wsb = ltu_knob_pos("LTU_HALO_WS_BLOCKS", 512);

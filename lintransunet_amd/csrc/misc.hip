@@ -6,7 +6,14 @@
 #include <mutex>
 #include <stdlib.h>
 
-extern "C" int ltu_version(void) { return 3; }
+extern "C" int ltu_version(void) { return 4; }
+extern "C" int ltu_build_flags(void) {
+#ifdef LTU_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // ---- self-test of the cross-lane reductions (common.h) ----------------------------------------------------------------
 template <int G>
@@ -32,6 +39,7 @@ extern "C" int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, 
   return ltu_check_launch();
 }
 
+#ifdef LTU_EXPERIMENTS      // the in-launch last-arriver fold (DESIGN.md finding 15): slower than the second launch; experiments build only
 // ---- last-arriver fold: self-test and price of the in-launch second stage (finding 15) -----------------------
 // The step folds ~100 sets of per-workgroup partial sums with a second small launch each.  The alternative keeps the fold inside
 // the producing launch: every workgroup publishes its partial row, takes a ticket, and the workgroup whose ticket is the last
@@ -99,6 +107,7 @@ extern "C" int ltu_selftest_last_arriver(const float* x, float* part, float* out
   if (mode == 0) hipLaunchKernelGGL(selftest_fold_kernel, dim3(1), dim3(256), 0, st, part, out, nwg, n);
   return ltu_check_launch();
 }
+#endif
 
 // ---- knob overrides (ltu_config_set): a small table under a mutex; see common.h ------------------------------------------
 namespace {

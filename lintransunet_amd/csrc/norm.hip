@@ -682,8 +682,14 @@ static int stats_rows(long long S, int B, int* nchunks) {
 // vector width of the InstanceNorm kernels.  8 elements (16 bytes of bf16) is built and tested but OFF: at 34 / 17 / 4 MB the
 // statistics pass took 12.7 / 11.2 / 2.6 us against 6.5 / 4.9 / 1.3 (half the loop trips, the same epilogue) and the three-tensor
 // backward 41 / 32 / 13.5 against 37 / 25 / 12 (tools/sweep_in.sh): these passes already stream at 4-5 TB/s at 8 bytes per lane.
+// Both variants below (LTU_IN_VW8, LTU_IN_FOLD) lost their measurements and are compiled only into an experiments build
+// (make EXPERIMENTS=1 -> -DLTU_EXPERIMENTS); the product library carries the 8-byte two-stage kernels alone.
 static int in_vw(int dtype, int C) {
+#ifdef LTU_EXPERIMENTS
   return (dtype == LTU_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 && ltu_knob("LTU_IN_VW8", 0)) ? 8 : 4;
+#else
+  return 4;
+#endif
 }
 // Second stage folded by the apply kernel (in_fold_parts): chunk count per sample such that the partials of a sample stay within
 // IN_FOLD_MAX floats.  Returns false when the shape does not qualify (the two-stage path with its own fold launch runs then).
@@ -692,6 +698,9 @@ static bool in_fold_plan(long long S, int B, int C, int vw, const float* ws, int
   // 11.5 / 7.3 us against 27.9 / 20.3 / 10.2 / 8.0 with the fold launch, backward 40.1 / 29.6 / 15.4 / 9.4 against 36.8 / 25.5 / 11.8 /
   // 10.1: bounding the partials to a few KB per sample leaves the statistics kernels 4x fewer workgroups, which costs the
   // mid-sized tensors and the heavier backward statistics more than the 5 us launch this removes.
+#ifndef LTU_EXPERIMENTS
+  return false;
+#endif
   if (ws == nullptr || !ltu_knob("LTU_IN_FOLD", 0)) return false;
   if ((256 * vw) % C != 0 || 2 * C > IN_FOLD_LDS || C < 4) return false;
   long long want = IN_FOLD_MAX / (2 * C);
@@ -704,11 +713,18 @@ static bool in_fold_plan(long long S, int B, int C, int vw, const float* ws, int
   *rows = (int)r;
   return (long long)*nchunks * B * C * 2 <= LTU_NORM_WS_FLOATS;
 }
+#ifdef LTU_EXPERIMENTS
 #define IN_DISPATCH_VW(vw, ...)                    \
   do {                                             \
     if ((vw) == 8) { constexpr int VW = 8; __VA_ARGS__ } \
     else { constexpr int VW = 4; __VA_ARGS__ }     \
   } while (0)
+#else
+#define IN_DISPATCH_VW(vw, ...)                    \
+  do {                                             \
+    constexpr int VW = 4; __VA_ARGS__              \
+  } while (0)
+#endif
 
 static unsigned stream_grid(long long nvec) {
   long long blocks = (nvec + 255) / 256;
@@ -780,12 +796,14 @@ extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const voi
     const int rc = ltu_instnorm_stats(x, sums, ws, B, S, C, dtype, s);
     return rc != LTU_OK ? rc : ltu_instnorm_apply(x, sums, res, y, B, S, C, act, slope, p, seed, step, dtype, s);
   }
+#ifdef LTU_EXPERIMENTS
   LTU_DISPATCH_T(dtype, {
     IN_DISPATCH_VW(vw, {
       launch_in_stats<T, VW>(x, sums, ws, B, S, C, nchunks, rows, (hipStream_t)s);
       launch_in_apply<T, VW, true>(x, sums, res, y, B, S, C, act, slope, p, seed, step, ws, nchunks, (hipStream_t)s);
     });
   });
+#endif
   return ltu_check_launch();
 }
 
@@ -806,11 +824,14 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3
       const size_t lds = (size_t)(256 / (C / VW)) * C * 2 * sizeof(float);
       hipLaunchKernelGGL((instnorm_bwd_stats_kernel<T, VW>), dim3(nchunks, B), dim3(256), lds, st, (const T*)dy, (const T*)dy2,
                          (const T*)dy3, (const T*)x, sums, bsums, ws, S, C, rows, act, slope, p, seed, step);
+#ifdef LTU_EXPERIMENTS
       if (fold) {
         hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T, VW, true>),
                            dim3(per_sample_grid(S * C / VW, B, ltu_knob_pos("LTU_IN_FOLD_BLOCKS", 2048)), B), dim3(256), 0, st, (const T*)dy,
                            (const T*)dy2, (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, S, C, act, slope, p, seed, step, ws, nchunks);
-      } else {
+      } else
+#endif
+      {
         if (ws != nullptr) launch_reduce_parts(ws, nchunks, C * 2, B, bsums, nullptr, 0, st);
         if ((256 * VW) % C == 0)
           hipLaunchKernelGGL((instnorm_bwd_apply_fixedc_kernel<T, VW, false>), dim3(per_sample_grid(S * C / VW, B), B), dim3(256), 0, st,

@@ -748,7 +748,11 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   ta.dbg = ltu_knob("LTU_TAIL_DBG", 0);
   ta.wq = (const uint16_t*)wq_next; ta.bq[0] = bq0; ta.bq[1] = bq1; ta.bq[2] = bq2; ta.qkv_next = (uint16_t*)qkv_next;
   const bool qn = qkv_next != nullptr;
+#ifdef LTU_EXPERIMENTS
   const bool slim = d == 128 && !qn && ltu_knob("LTU_TAIL_FWD_OCC", 4) >= 5;
+#else
+  constexpr bool slim = false;               // the five-workgroups-per-CU layout lost its measurement: experiments build only
+#endif
   const unsigned blocks = cdiv(M, TL_ROWS);
   const size_t lds = (size_t)TL_ROWS * ((slim ? 1 : 2) * (d + 8) + (2 * d + 8)) * sizeof(uint16_t) + (size_t)(qn ? 11 : 8) * d * sizeof(float) +
                      (qkv != nullptr ? (size_t)TL_ROWS * (d / 32) * 2 * sizeof(float) : 0);
@@ -760,8 +764,10 @@ extern "C" int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, 
   if (d == 256) {
     if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<256, true, true, 4>, 512); else launch(&tail_fwd_kernel<256, true, false, 4>, 512); }
     else { if (qn) launch(&tail_fwd_kernel<256, false, true, 4>, 512); else launch(&tail_fwd_kernel<256, false, false, 4>, 512); }
+#ifdef LTU_EXPERIMENTS
   } else if (slim) {
     if (qkv != nullptr) launch(&tail_fwd_kernel<128, true, false, 5>, 256); else launch(&tail_fwd_kernel<128, false, false, 5>, 256);
+#endif
   } else {
     if (qkv != nullptr) { if (qn) launch(&tail_fwd_kernel<128, true, true, 4>, 256); else launch(&tail_fwd_kernel<128, true, false, 4>, 256); }
     else { if (qn) launch(&tail_fwd_kernel<128, false, true, 4>, 256); else launch(&tail_fwd_kernel<128, false, false, 4>, 256); }

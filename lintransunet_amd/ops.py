@@ -235,7 +235,7 @@ class Context:
         current stream - the caller brackets it with its own capture); on_join(): called instead of making the current stream wait
         for the side stream (`side_join`)"""
         self.wq = None if side_stream is None else {'side': side_stream, 'jobs': [], 'keep': [], 'on_flush': on_flush, 'on_join': on_join,
-                                                    'running': False, 'batches': 0, 'side_pending': False}
+                                                    'running': False, 'batches': 0, 'side_pending': False, 'after': []}
 
     # -- forward-side work on the same side stream: what the first kernels of the step do not need yet (the weight operands of
     # everything behind the encoder, the label pyramid) runs beside the encoder; `side_join` is placed in front of its first consumer
@@ -272,12 +272,12 @@ class Context:
         q['jobs'].append(fn)
         q['keep'].extend(t for t in tensors if t is not None)
         if len(q['jobs']) >= WQ_MAX_JOBS:
-            self.wq_flush()
+            self.flush_deferred()
 
     def wq_flush(self):
         """issue the collected launches as one batch on the side stream, ordered behind everything issued so far on this stream"""
         q = self.wq
-        if q is None or q['running'] or not q['jobs']:
+        if q is None or q['running'] or not (q['jobs'] or q['after']):
             return
         jobs, q['jobs'] = q['jobs'], []
         q['batches'] += 1
@@ -287,6 +287,11 @@ class Context:
             try:
                 for fn in jobs:
                     fn(q['keep'])
+                # parameters whose gradients were reported while the queue held their kernels back (train.GradReducer._hook parks
+                # them here): NOW their gradients are enqueued - a bucket that this completes is reduced behind this batch
+                after, q['after'] = q['after'], []
+                for hook, p in after:
+                    hook(p)
             finally:
                 q['running'] = False
         if q['on_flush'] is not None:
@@ -329,6 +334,38 @@ def use(ctx):
         yield ctx
     finally:
         _TLS.ctx = prev
+
+
+def concurrent_stream(device, avoid, tries=8, cycles=1000000, priority=0):
+    """A stream that REALLY runs beside every stream in `avoid`.  HIP maps its streams round-robin onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default; 8 doubles the step time on this runtime) and two streams that share a queue serialise:
+    every fourth stream of torch's pool lands on the current stream's queue (tools/probe_streams.py: 1.99x for those, 1.0x for the
+    rest), which silently removed the whole benefit of the weight-gradient side stream whenever a communicator had taken a stream
+    before it.  So candidates are probed: a spin kernel on each stream of `avoid` and on the candidate must take 1x, not 2x.
+    Synchronises the device; call outside captures."""
+    import time
+    device = torch.device(device)
+
+    def pair_ms(a, b):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        if b is not None:
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    with torch.cuda.device(device):
+        pair_ms(avoid[0], None)
+        base = min(pair_ms(avoid[0], None) for _ in range(3))
+        cands = []
+        for _ in range(tries):
+            c = torch.cuda.Stream(device=device, priority=priority)
+            cands.append(c)
+            if all(min(pair_ms(a, c) for _ in range(2)) < 1.5 * base for a in avoid):
+                return c
+    return cands[0]
 
 
 # module-level conveniences over the current context

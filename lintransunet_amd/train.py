@@ -108,6 +108,19 @@ def train_step(model, images, labels, weights, step_times=1, specs=None, reducer
     return totals, named
 
 
+def _default_comm(who):
+    """comm=None: LocalComm in a single-rank process, a GlooComm over a gloo default group (CPU tensors: tests, host control);
+    NEVER a silent LocalComm at world > 1 - a multi-rank process group on any other backend means the caller has GPU gradients to
+    exchange and must say how (round 3 advice: with comm=None such a run reduced and broadcast nothing, without an error)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == 'gloo':
+            return _comm.GlooComm()
+        raise RuntimeError(f'{who}: torch.distributed is initialised with {dist.get_world_size()} ranks on the {dist.get_backend()!r} backend but '
+                           'no communicator was given: pass comm=lintransunet_amd.comm.RcclComm(device, control=GlooComm(gloo_group)) '
+                           '(the gradient exchange goes through direct RCCL calls, the control plane through gloo)')
+    return _comm.LocalComm()
+
+
 class GradReducer:
     """Bucketed gradient all-reduce (mean over ranks) overlapped with backward.
 
@@ -125,8 +138,7 @@ class GradReducer:
         """comm: a communicator of lintransunet_amd.comm (RcclComm on the GPU, GlooComm on CPU tensors); None = LocalComm, or -
         when torch.distributed is initialised with a gloo group - a GlooComm over the default group"""
         if comm is None:
-            comm = (_comm.GlooComm() if (dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'gloo')
-                    else _comm.LocalComm())
+            comm = _default_comm('GradReducer')
         self.comm = comm
         # force_collectives: take the multi-rank code path (bucket plan, hooks, collectives) on a 1-rank communicator - the one-GPU
         # rehearsal of what every rank does at N > 1 (tools/check_dist_graph.py, bench.py --rehearse-comm)
@@ -230,6 +242,12 @@ class GradReducer:
         # all-reduce that comes too early).
         if p in self._seen:
             return
+        q = self.ctx.wq if self.ctx is not None else None
+        if q is not None and not q['running']:
+            # the context holds weight-gradient kernels back (ops.Context.wq_*): the report is parked and repeated by the batch that
+            # launches them, so a bucket closes - and is reduced - where its gradients really are enqueued, on the side stream
+            q['after'].append((self._hook, p))
+            return
         self._seen.add(p)
         self.ready_order.append(p)
         bi = self.bucket_of[p]
@@ -307,8 +325,15 @@ class GraphedStep:
         # weight-gradient queue (ops.Context.wq_install): with the step replayed as linear segments, the weight gradients of each
         # transformer / decoder level are captured as linear graphs of their own and replayed on a side stream beside the
         # data-gradient chain of the coarser, latency-bound levels (LTU_WQ=0: everything in line)
-        self.wq_stream = (torch.cuda.Stream(device=dev, priority=int(os.environ.get('LTU_WQ_PRIO', '0'))) if (self.overlap == 'segments' and os.environ.get('LTU_WQ', '1') != '0')
-                          else None)
+        self.wq_stream = None
+        if self.overlap == 'segments' and os.environ.get('LTU_WQ', '1') != '0':
+            # on a hardware queue of its own: beside the stream the step is replayed on (the current one) and beside the
+            # communicator's stream (ops.concurrent_stream probes; streams that share a queue serialise)
+            avoid = [torch.cuda.current_stream(dev)]
+            cs = getattr(reducer.comm, 'stream', None)
+            if isinstance(cs, torch.cuda.Stream):
+                avoid.append(cs)
+            self.wq_stream = ops.concurrent_stream(dev, avoid)
         self.graphs = {}
         self.pool = None
         self._capture((True, True))
@@ -475,6 +500,70 @@ class GraphedStep:
         self.totals, self.named = totals, named
         return totals, named
 
+    def replay_local(self, images=None, labels=None):
+        """the same micro-step WITHOUT its collectives (the (zero, no-reduce) graph, captured on first use): what the step costs when
+        nothing is exchanged.  step-with-collectives minus this = the exposed communication time bench.py reports at N > 1."""
+        if self.step_times != 1:
+            raise RuntimeError('replay_local is defined for step_times == 1')
+        key = (True, False)
+        if key not in self.graphs:
+            self._capture(key)
+        if images is not None:
+            self.x.copy_(images, non_blocking=True)
+            self.lab.copy_(labels, non_blocking=True)
+        segs, totals, named, _ = self.graphs[key]
+        main, side, used_side = torch.cuda.current_stream(self.dev), self.wq_stream, False
+        for graph, kind, _bi in segs:
+            if kind == 'join':
+                main.wait_stream(side)
+            elif graph is not None and kind == 'side':
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    graph.replay()
+                used_side = True
+            elif graph is not None:
+                graph.replay()
+        if used_side:
+            main.wait_stream(side)
+        return totals, named
+
+    def bucket_timeline(self):
+        """one instrumented replay of the reducing step: [(bucket, MB, ms after the start of the step at which the segment that
+        completes the bucket has finished - i.e. when its all-reduce can start), ...] and the step time; collectives are NOT issued
+        (the timeline of the compute side).  Used by bench.py at N > 1 and by tools/bucket_timeline.py."""
+        key = (True, True)
+        if key not in self.graphs:
+            self._capture(key)
+        segs, _, _, rest = self.graphs[key]
+        main, side, used_side = torch.cuda.current_stream(self.dev), self.wq_stream, False
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        e0, marks = ev(), []
+        e0.record(main)
+        for graph, kind, bi in segs:
+            on = main
+            if kind == 'join':
+                main.wait_stream(side)
+            elif graph is not None and kind == 'side':
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    graph.replay()
+                used_side, on = True, side
+            elif graph is not None:
+                graph.replay()
+            if bi is not None:
+                e = ev()
+                e.record(on)
+                marks.append((bi, e))
+        if used_side:
+            main.wait_stream(side)
+        e1 = ev()
+        e1.record(main)
+        e1.synchronize()
+        total = e0.elapsed_time(e1)
+        out = [(bi, self.reducer.flat[bi].numel() * 4 / 2 ** 20, e0.elapsed_time(e)) for bi, e in marks]
+        out += [(bi, self.reducer.flat[bi].numel() * 4 / 2 ** 20, total) for bi in rest]
+        return out, total
+
 
 UNUSED_PARAMETERS = tuple(f'decode.bridge_list.4.transformer.pos_encoders.{n}.proj.{k}'
                           for n in range(1, 8) for k in ('weight', 'bias'))
@@ -482,6 +571,8 @@ UNUSED_PARAMETERS = tuple(f'decode.bridge_list.4.transformer.pos_encoders.{n}.pr
 
 def broadcast_parameters(model, comm=None, src=0):
     """one-time parameter sync from rank `src` (replaces DataParallel's per-step replicate)"""
-    if comm is not None and comm.world > 1:
+    if comm is None:
+        comm = _default_comm('broadcast_parameters')
+    if comm.world > 1:
         for p in model.parameters():
             comm.broadcast(p.data, src)

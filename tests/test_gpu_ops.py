@@ -307,6 +307,8 @@ def instnorm_variant(request):
     statistics partials themselves (no fold launch), 16-byte bf16 vectors"""
     from lintransunet_amd import _lib
     knob = {'two_stage': None, 'fold_in_apply': b'LTU_IN_FOLD', 'vw8': b'LTU_IN_VW8'}[request.param]
+    if knob and not _lib.experiments():
+        pytest.skip('rejected variant: compiled into an experiments build only (make EXPERIMENTS=1)')
     if knob:
         _lib.call('ltu_config_set', knob, 1, 0)
     yield request.param
@@ -458,6 +460,31 @@ def test_dropout_mask_statistics(ops):
     assert abs(K[xyz, 3].mean().item() - 0.7) < 3e-3
     nxy = (K[:, 0] == 0) & (K[:, 1] == 0)
     assert abs(K[nxy, 2].mean().item() - 0.7) < 5e-3 and abs(K[nxy, 3].mean().item() - 0.7) < 5e-3
+
+
+@pytest.mark.parametrize('p', [0.3, 0.5])
+def test_dropout_group_pattern_histogram(ops, p):
+    """the four keep decisions of a group are pairwise independent by construction but the third and fourth are functions of the
+    first two (one 32-bit hash per group, csrc/common.h: drop4): the JOINT distribution of the 16 keep patterns of a group is
+    held against Bernoulli(1 - p)^4 - every pattern within 4 sigma (+ 2e-4 absolute for the 16-bit threshold rounding) at 8 M
+    groups, and the distribution of the per-group keep COUNT (what a row of activations feels) likewise"""
+    n = 1 << 25
+    u = torch.ones(n, device=DEV)
+    K = (ops.gelu_dropout(u, p, 424242) != 0).reshape(-1, 4).long()
+    pat = K[:, 0] + 2 * K[:, 1] + 4 * K[:, 2] + 8 * K[:, 3]
+    hist = torch.bincount(pat, minlength=16).double().cpu() / K.shape[0]
+    q = 1.0 - p
+    groups = K.shape[0]
+    for code in range(16):
+        k = bin(code).count('1')
+        want = q ** k * p ** (4 - k)
+        sigma = (want * (1 - want) / groups) ** 0.5
+        assert abs(hist[code].item() - want) < 4 * sigma + 2e-4, (code, hist[code].item(), want)
+    counts = torch.bincount(K.sum(1), minlength=5).double().cpu() / groups
+    from math import comb
+    for k in range(5):
+        want = comb(4, k) * q ** k * p ** (4 - k)
+        assert abs(counts[k].item() - want) < 4 * (want * (1 - want) / groups) ** 0.5 + 3e-4, (k, counts[k].item(), want)
 
 
 @pytest.mark.parametrize('M,d', [(4320, 256), (2048, 128), (21504, 256), (1024, 256)])
@@ -764,6 +791,9 @@ def test_trilinear_adjoint_row_pairs(ops, sd, shape):
 def test_conv3d_persistent_brick_orders(ops):
     """the persistent few-channel convs with contiguous brick runs per workgroup (XCD-aware, default) against the strided order
     (LTU_HALO_NO_XCD): the same bricks, bit-identical results; 720 ragged bricks on 512 workgroups"""
+    from lintransunet_amd import _lib
+    if not _lib.experiments():
+        pytest.skip('the strided order is compiled into an experiments build only (make EXPERIMENTS=1)')
     g = G(13)
     for Ci, Co in ((16, 16), (32, 32)):
         x = torch.randn(1, Ci, 36, 38, 60, generator=g).bfloat16()
@@ -996,6 +1026,8 @@ def test_last_arriver_reduce(nwg, n, skew):
     not used in the step because it does not pay: tools/bench_last_arriver.py, DESIGN.md section 5 finding 15.)"""
     from lintransunet_amd import _lib
     from lintransunet_amd.ops import _p, _s
+    if not _lib.experiments():
+        pytest.skip('ltu_selftest_last_arriver is exported by an experiments build only (make EXPERIMENTS=1)')
     rpc = 4
     rows = sum(1 + (7 * i) % skew for i in range(nwg)) * rpc
     g = G(77)

@@ -5,6 +5,10 @@ GraphedStep with the collectives after the replay and as linear segments with th
 (SURVEY 8e): every op of the network is per-sample, so mean over ranks of the per-rank gradients == gradient of the full batch.
 
     python tools/rehearse_two_ranks.py          (parent: spawns rank 0 / 1 on device 0, then compares with a 1-process full-batch run)
+    python tools/rehearse_two_ranks.py --rccl   (needs two GPUs: rank r on device r, the exchange through the PRODUCT communicator -
+                                                 RcclComm over a gloo control plane - plus a known-answer all-reduce: ranks
+                                                 contribute 1 and 3, every rank must read 2; tests/test_gpu_comm.py runs it
+                                                 wherever two devices are visible)
 """
 import os, socket, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,11 +45,25 @@ def rank_main():
     from lintransunet_amd import train, comm as C
     from oracle import step as O_step
     rank = int(os.environ['RANK'])
-    torch.cuda.set_device(0)
+    rccl = os.environ.get('LTU_REHEARSE_RCCL') == '1'
+    torch.cuda.set_device(rank if rccl else 0)
     dist.init_process_group('gloo')
     gloo = C.GlooComm()
 
-    comm = C.HostStagedComm(gloo)           # test-only: GPU bucket -> host -> gloo -> GPU (the product path uses RcclComm)
+    if rccl:
+        comm = C.RcclComm(torch.device('cuda', rank), control=gloo)       # the product path: direct RCCL calls behind the C-ABI
+        # known answer first: a wrong reduction op, dtype enum or count would show here, not as "gradients look plausible"
+        for n in (1, 1000, (1 << 22) + 3):
+            t = torch.full((n,), 1.0 + 2.0 * rank, device='cuda')
+            comm.allreduce_avg(t).wait()
+            torch.cuda.synchronize()
+            assert torch.equal(t, torch.full_like(t, 2.0)), (n, t[:4].tolist())
+        b = torch.full((1000,), float(rank + 5), device='cuda')
+        comm.broadcast(b, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(b, torch.full_like(b, 5.0))
+    else:
+        comm = C.HostStagedComm(gloo)       # test-only: GPU bucket -> host -> gloo -> GPU (the product path uses RcclComm)
     m = setup(2, 100 + rank)                # different initial weights per rank: the broadcast must fix that
     train.broadcast_parameters(m, comm)
     red = train.GradReducer(m, bucket_mb=0.25, unused=train.UNUSED_PARAMETERS, comm=comm)
@@ -80,6 +98,7 @@ def rank_main():
     tmax = comm.max_float(float(rank))
     assert tmax == 1.0
     comm.barrier()
+    comm.close()
     dist.destroy_process_group()
 
 
@@ -87,8 +106,13 @@ def parent():
     import torch
     os.makedirs(OUT, exist_ok=True)
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    procs = [subprocess.Popen([sys.executable, __file__, 'rank'], env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                                                                          MASTER_PORT=str(port))) for r in range(2)]
+    rccl = '--rccl' in sys.argv
+    if rccl and torch.cuda.device_count() < 2:
+        print('--rccl needs two visible GPUs')
+        sys.exit(2)
+    env = dict(os.environ, WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LTU_REHEARSE_RCCL='1' if rccl else '0')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = [subprocess.Popen([sys.executable, __file__, 'rank'], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0], rcs
     from lintransunet_amd import train
