@@ -185,7 +185,10 @@ struct ClassHaloArgs {
   int8_t cls_p[8][4];   // parity (ph, pw, pd) of each class
   ClsEntry ent[64];
 };
-int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled
+int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st);
+// sub-pixel un-embedding forward, second generation (upconv_ring.hip): LTU_OK / hipError, or 1 = shape not handled
+int launch_upconv_ring_bf16(const void* x, const void* wsub_f, const float* bias, void* y, int B, int H, int W, int D, int Ci, int Co,
+                            hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled
 
 // weight gradient of the sub-pixel un-embedding from LDS halo bricks (conv_halo.hip), two-stage through wgrad_reduce_kernel
 struct UpWgradArgs {

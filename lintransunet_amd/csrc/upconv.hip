@@ -26,7 +26,11 @@ extern "C" int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bi
                               int Co, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
   const size_t esz = dtype == LTU_BF16 ? 2 : 4;
-  if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {      // all 8 classes from one LDS halo brick
+  if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_UPRING", 0)) {          // all 8 classes from one LDS halo brick, compile-time tap pattern
+    const int hr = launch_upconv_ring_bf16(x, wsub_f, bias, y, B, H, W, D, Ci, Co, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
+  if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {      // the generic class kernel (run-time entry table)
     ClassHaloArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = wsub_f; a.bias = bias; a.o0 = y; a.o1 = y;
