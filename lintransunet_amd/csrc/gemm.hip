@@ -575,8 +575,13 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
     if (hr != 1) return hr;
   }
   const int Ho = (Hl - 1) / sh + 1, Wo = (Wl - 1) / sw + 1, Do = (Dl - 1) / sd + 1;
+  if (dtype == LTU_BF16 && sh == 2 && sw == 2 && C1 == 0 && use_halo() && !ltu_knob("LTU_NO_SDGRAD_RING", 0)) {
+    // every parity class of the input grid from one LDS halo brick of the output gradient, compile-time entry table
+    const int hr = launch_sdgrad_ring_bf16(grad, wd, dx0, B, Hl, Wl, Dl, C0, Co, sd, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
   if (dtype == LTU_BF16 && (sh == 2 || sw == 2 || sd == 2) && use_halo() && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {
-    // every parity class of the input grid from one LDS halo brick of the output gradient
+    // the generic class kernel (run-time entry table)
     ClassHaloArgs a;
     memset(&a, 0, sizeof(a));
     a.x = grad; a.w = wd; a.bias = nullptr; a.o0 = dx0; a.o1 = dx1 ? dx1 : dx0;

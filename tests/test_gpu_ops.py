@@ -115,6 +115,10 @@ def test_linear_bf16(ops, M, K, N, nw):
     (3, 16, 16, 4, 12, 8, (1, 1, 1), 0, False, None),
     (2, 16, 64, 9, 7, 10, (2, 2, 2), 0, False, None),    # class-halo data gradient: 8 parity classes, odd input dims
     (1, 40, 32, 8, 5, 17, (2, 2, 1), 0, False, None),    # 4 classes
+    (1, 32, 128, 17, 18, 21, (2, 2, 2), 0, False, None), # compile-time class kernel: four channel chunks, bricks ragged in every axis
+    (2, 64, 64, 10, 9, 8, (2, 2, 2), 0, False, None),    # ... two column tiles
+    (1, 16, 32, 12, 18, 19, (2, 2, 1), 0, False, None),  # ... stride 1 along d: half a column tile
+    (1, 64, 96, 9, 16, 6, (2, 2, 1), 0, False, None),    # ... three chunks
     (2, 128, 128, 8, 8, 8, (2, 2, 2), 0, False, None),   # strided forward on a tiny grid with K = 3456: K-split implicit GEMM + fold
     (1, 256, 128, 4, 4, 8, (1, 1, 1), 0, False, None),   # stride-1 halo conv on one brick row: channel-split + fold
     (1, 16, 16, 36, 38, 60, (1, 1, 1), 0, False, None),  # persistent few-channel kernels: 720 ragged bricks on 512 workgroups (the
