@@ -366,7 +366,8 @@ class MaskTransUnet(nn.Module):
             if n == 0:
                 g, g_res = ops.pos_conv(t.view(B, H, W, D, d), pos.proj.weight, pos.proj.bias, p, seeds.next() if p > 0 else 0, fork=2)
                 t, tres = g.view(B * N, d), g_res.view(B * N, d)
-        return tres.view(B, H, W, D, d)
+        # backward enters the transformer here: the weight gradients queued so far go out as a batch (ops.WQ_SCHEDULE 'start')
+        return ops.wgrad_flush_point(tres.view(B, H, W, D, d), 'out')
 
     def _roi_bridge(self, br, skip, mask, roi_size, p, seeds):
         """model/Unet_3Dblock.py:717-755"""
@@ -430,7 +431,7 @@ class MaskTransUnet(nn.Module):
             if ops.WQ_FLUSH_IN_ENCODER:
                 # backward reaches this point after conv2's (and the deeper block's conv1's) backward: their queued weight gradients go
                 # out as a batch beside this block's data gradients instead of piling up behind the last kernel of the step
-                s = ops.wgrad_flush_point(s)
+                s = ops.wgrad_flush_point(s, 'enc')
             if i < nblk - 1:
                 t, t_r, t_r2 = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds, fork=3)
             else:

@@ -433,7 +433,7 @@ WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '128'))     # opera
 WQ_MAX_JOBS = int(_os.environ.get('LTU_WQ_JOBS', '1000000'))      # weight-gradient queue: a batch goes out when this many launches are queued
 WQ_SIDE_FWD = _os.environ.get('LTU_WQ_FWD', '1') == '1'      # forward-side work (weight operands behind the encoder, label pyramid) on the side stream
 WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
-WQ_FLUSH_AT_TRANSFORMER = _os.environ.get('LTU_WQ_FLUSH', 'transformer') == 'transformer'     # weight-gradient queue: a batch per transformer
+WQ_SCHEDULE = _os.environ.get('LTU_WQ_SCHEDULE', 'end')     # weight-gradient queue: a batch where backward ENTERS ('start') / leaves ('end') a transformer
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
 
 
@@ -443,25 +443,35 @@ def _defer_job():
 
 class _WgradFlushPoint(torch.autograd.Function):
     """identity in forward; its backward runs when the gradient reaches this point, i.e. after everything downstream has
-    run its backward: the model puts one at the input of every token transformer"""
+    run its backward.  kind 'in' (the input of a token transformer / an encoder block): the transformer's grouped weight gradients
+    are handed over, and - schedule 'end' - the queue's batch goes out; kind 'out' (the OUTPUT of a token transformer, reached when
+    backward ENTERS it) - schedule 'start' - the batch goes out there instead: everything queued so far (the previous, larger
+    level's weight gradients) then runs beside this transformer's latency-bound layers rather than beside the machine-filling
+    decoder kernels in front of it."""
 
     @staticmethod
-    def forward(ctx, x):
-        ctx.lc = current()
+    def forward(ctx, x, kind):
+        ctx.lc, ctx.kind = current(), kind
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         lc = ctx.lc
-        lc.wgrad_group_flush()
-        if lc.wq is not None and WQ_FLUSH_AT_TRANSFORMER:
+        if ctx.kind == 'in':
+            lc.wgrad_group_flush()
+        if lc.wq is not None and (ctx.kind == 'enc' or WQ_SCHEDULE == 'both' or ctx.kind == ('in' if WQ_SCHEDULE == 'end' else 'out')):
+            lc.wgrad_group_flush()
             lc._fold_flush()
             lc.wq_flush()
-        return g
+        return g, None
 
 
-def wgrad_flush_point(x):
-    return _WgradFlushPoint.apply(x) if ((current().wq is not None or WGRAD_DEFER_MB > 0) and x.requires_grad) else x
+def wgrad_flush_point(x, kind='in'):
+    if not x.requires_grad:
+        return x
+    if kind == 'out' and (current().wq is None or WQ_SCHEDULE == 'end'):
+        return x
+    return _WgradFlushPoint.apply(x, kind) if (current().wq is not None or WGRAD_DEFER_MB > 0) else x
 
 
 def _wgrad_ws(M, N, K, like):
