@@ -370,6 +370,10 @@ extern "C" int ltu_linear_fwd(const void* a, int lda, const void* const* w, int 
   for (int i = 0; i < nw; ++i) { g.w[i] = w[i]; g.bias[i] = bias ? bias[i] : nullptr; }
   g.o0 = y; g.o1 = y; g.ldo0 = ldy; g.ldo1 = ldy;
   g.accum = accumulate;
+  if (dtype == LTU_BF16 && nw == 1 && !ltu_knob("LTU_NO_PW_SMALL", 0)) {      // few-channel streaming projections (the attention gates' 1x1x1 convs)
+    const int pr = launch_pw_small_bf16(a, lda, w[0], bias ? bias[0] : nullptr, y, ldy, M, N, K, accumulate, (hipStream_t)s);
+    if (pr != 1) return pr;
+  }
   if (dtype == LTU_BF16) return launch_nt_bf16(g, (hipStream_t)s);
   if (dtype != LTU_F32) return LTU_E_DTYPE;
   return launch_nt<float, float>(g, (hipStream_t)s);

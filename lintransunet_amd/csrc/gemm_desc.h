@@ -186,6 +186,9 @@ struct ClassHaloArgs {
   ClsEntry ent[64];
 };
 int launch_conv_class_halo_bf16(const ClassHaloArgs& a, hipStream_t st);
+// y [M][N] (+)= x [M][K] W^T + b for K, N <= 128 / 64 (pw_small.hip): LTU_OK / hipError, or 1 = shape not handled
+int launch_pw_small_bf16(const void* x, int lda, const void* w, const float* bias, void* y, int ldy, long long M, int N, int K, int accumulate,
+                         hipStream_t st);
 // data gradient of a stride-(2,2,sd) conv (sdgrad_ring.hip): LTU_OK / hipError, or 1 = shape not handled
 int launch_sdgrad_ring_bf16(const void* grad, const void* wd, void* dx, int B, int Hl, int Wl, int Dl, int N, int Co, int sd, hipStream_t st);
 // sub-pixel un-embedding forward, second generation (upconv_ring.hip): LTU_OK / hipError, or 1 = shape not handled

@@ -71,9 +71,27 @@ def test_linear(ops, M, K, N, nw):
         assert rel_err(a.grad, b.grad) < 1e-4
 
 
+@pytest.mark.parametrize('M,K,N', [(70003, 16, 16), (65536, 32, 16), (66001, 64, 64), (65599, 128, 32)])
+def test_linear_small_accumulate(M, K, N):
+    """ltu_linear_fwd with the accumulating epilogue on the few-channel streaming kernel (the attention gate's dskip += du1 . Wx):
+    y += x W^T against torch on the bf16-rounded operands"""
+    from lintransunet_amd import _lib
+    from lintransunet_amd.ops import _p, _ptr_array, _s
+    g = G(55)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.2).bfloat16().to(DEV)
+    y0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    y = y0.clone()
+    _lib.call('ltu_linear_fwd', _p(x), K, _ptr_array([w]), 1, _ptr_array([None]), _p(y), N, M, N, K, 1, 1, _s())
+    ref = y0.float() + x.float() @ w.float().t()
+    assert rel_err(y.float(), ref) < 6e-3
+
+
 @pytest.mark.parametrize('M,K,N,nw', [(400, 128, 64, 1), (1000, 64, 96, 3), (257, 256, 768, 3), (4100, 32, 32, 1), (300, 128, 8, 1),
                                       (2048, 128, 384, 3), (8640, 256, 128, 1), (1024, 384, 256, 1), (21504, 128, 128, 1),
-                                      (1000, 512, 200, 1), (777, 768, 264, 3), (5000, 64, 136, 1)])   # LDS-DMA ring kernels
+                                      (1000, 512, 200, 1), (777, 768, 264, 3), (5000, 64, 136, 1),    # LDS-DMA ring kernels
+                                      (70000, 16, 16, 1), (65537, 32, 16, 1), (66000, 16, 32, 1), (65536, 64, 64, 1), (65541, 128, 64, 1),
+                                      (70001, 64, 32, 1)])   # few-channel streaming projections (pw_small.hip: the attention gates' 1x1x1 convs)
 def test_linear_bf16(ops, M, K, N, nw):
     """bf16 matrix-core path (NT forward / data gradient, transposing-read TN weight gradient); bf16 rounding of
     inputs and outputs bounds the error at ~1e-2 of the tensor's max"""
