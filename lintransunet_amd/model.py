@@ -165,19 +165,22 @@ class _WeightStore:
         self.chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(self.device)
         # the records added before `mark_first()` (the encoder's convs) form part 0 of the work list, the rest part 1: the model
         # refreshes part 1 on the side stream, beside the encoder (ops.Context.side_run)
-        nf = getattr(self, 'n_first', 0)
-        self.split = sum(1 for i, _ in chunks if i < nf)
+        # part p = the chunks of the records added before the (p + 1)-th `mark()`: bounds[p] .. bounds[p + 1]
+        marks = list(getattr(self, 'marks', [])) + [len(rows)]
+        self.bounds = [0] + [sum(1 for i, _ in chunks if i < m) for m in marks]
 
     def stale(self):
         """parameter storage moved (e.g. .to(), load with assign): the table must be rebuilt"""
         return any(src.data_ptr() != p0 for src, p0 in zip(self.srcs, self.ptrs))
 
-    def mark_first(self):
-        self.n_first = len(self.recs)
+    def mark(self):
+        """the records added so far (since the previous mark) form one part of the work list; the pair records of `add_conv_pair`
+        are appended behind all others by `finalize` and therefore belong to the LAST part"""
+        self.marks = getattr(self, 'marks', []) + [len(self.recs)]
 
     def refresh(self, part=None):
-        """part None: everything; 0: the operands of the first layers (see `mark_first`); 1: the rest"""
-        lo, hi = {None: (0, self.nchunks), 0: (0, self.split), 1: (self.split, self.nchunks)}[part]
+        """part None: everything; p: the operands added between the p-th and the (p + 1)-th `mark()` (the last part: the rest)"""
+        lo, hi = (0, self.nchunks) if part is None else (self.bounds[part], self.bounds[part + 1])
         if hi > lo:
             ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr() + lo * 8, hi - lo,
                           ops.F32 if self.dtype == torch.float32 else ops.BF16, torch.cuda.current_stream().cuda_stream)
@@ -260,23 +263,9 @@ class MaskTransUnet(nn.Module):
         for blk in enc.block_list:
             st.add_conv(blk.conv1)
             st.add_conv(blk.conv2)
-        st.mark_first()
-        # a decoder level's conv1 and its mask head read the same upsampled tensor: one fused conv (head padded to 16 / 32 columns
-        # so that the pair's data gradient keeps 32-channel chunks)
-        nl = len(self.num_layers)
-        for i, blk in enumerate(dec.block_list):
-            lvl = nl - 2 - i
-            st.add_conv_pair(lvl, blk.conv1, dec.mask_conv_list[lvl], 16 if lvl == 0 else 32)
-            st.add_conv(blk.conv2)
-        # bf16 GEMM operands need channel counts in multiples of 8: 4C = 12 output channels (3 labels) are padded to 16
-        st.add_conv(dec.final_block, cop=self._final_cop())
-        for ag in dec.att_conv_list:
-            st.add_linear(id(ag.W_x[0]), [ag.W_x[0].weight])
-            st.add_linear(id(ag.W_g[0]), [ag.W_g[0].weight])
-        for br in dec.bridge_list:
-            if not hasattr(br, 'transformer'):
-                continue
-            tr = br.transformer
+        st.mark()                            # part 0: the encoder (refreshed on the main stream at the start of the step)
+        # part 1: the ROI bridges - needed last in the forward pass; refreshed beside the bottleneck transformer
+        def add_transformer(tr):
             if hasattr(tr, 'down_embed'):
                 st.add_conv(tr.down_embed.module_list[0][0])
                 st.add_upconv(tr.up_embed.module_list[0][1])
@@ -287,6 +276,24 @@ class MaskTransUnet(nn.Module):
                 st.add_linear((id(lay), 'o'), [lin[3].weight], group='collect', frag=True)
                 st.add_linear((id(lay), 'f1'), [lay.linear1.weight], group='collect', frag=True)
                 st.add_linear((id(lay), 'f2'), [lay.linear2.weight], group='collect', frag=True)
+        nl = len(self.num_layers)
+        for br in dec.bridge_list[:nl - 1]:
+            if hasattr(br, 'transformer'):
+                add_transformer(br.transformer)
+        st.mark()
+        # part 2 (the rest): the bottleneck transformer, the decoder's convs, heads and gates - refreshed beside the encoder's
+        # deeper levels.  A decoder level's conv1 and its mask head read the same upsampled tensor: one fused conv (head padded to
+        # 16 / 32 columns so that the pair's data gradient keeps 32-channel chunks)
+        add_transformer(dec.bridge_list[nl - 1].transformer)
+        for i, blk in enumerate(dec.block_list):
+            lvl = nl - 2 - i
+            st.add_conv_pair(lvl, blk.conv1, dec.mask_conv_list[lvl], 16 if lvl == 0 else 32)
+            st.add_conv(blk.conv2)
+        # bf16 GEMM operands need channel counts in multiples of 8: 4C = 12 output channels (3 labels) are padded to 16
+        st.add_conv(dec.final_block, cop=self._final_cop())
+        for ag in dec.att_conv_list:
+            st.add_linear(id(ag.W_x[0]), [ag.W_x[0].weight])
+            st.add_linear(id(ag.W_g[0]), [ag.W_g[0].weight])
         st.finalize()
         self._store = st
         return st
@@ -416,7 +423,6 @@ class MaskTransUnet(nn.Module):
         # that a context with a side stream (train.GraphedStep) runs beside the encoder
         lc = ops.current()
         store.refresh(0)
-        lc.side_run(lambda: store.refresh(1))
 
         # Tensors with several consumers are produced with one output port per consumer (ops._ports): a block input feeds the
         # block's conv1 and its residual (whose gradient arrives in two parts, because the block output itself has two consumers:
@@ -428,6 +434,10 @@ class MaskTransUnet(nn.Module):
         nblk = len(enc.block_list)
         for i, blk in enumerate(enc.block_list):
             s, s_skip = self._conv_in_act(t, blk.conv1, res=t_r, res_dup=t_r2, seeds=seeds, fork=2)
+            if i == 0:
+                # the operands of the bottleneck transformer and the decoder: beside the encoder's deeper (latency-bound) levels - not
+                # beside its first, bandwidth-bound one, whose kernels a streaming side kernel slowed down 2-5x
+                lc.side_run(lambda: store.refresh(2))
             if ops.WQ_FLUSH_IN_ENCODER:
                 # backward reaches this point after conv2's (and the deeper block's conv1's) backward: their queued weight gradients go
                 # out as a batch beside this block's data gradients instead of piling up behind the last kernel of the step
@@ -438,7 +448,8 @@ class MaskTransUnet(nn.Module):
                 t, t_r = self._conv_in_act(s, blk.conv2, stride=(2, 2, i % 2 + 1), p=p, seeds=seeds, fork=2)
             skips.append(s_skip)
 
-        lc.side_join()                       # the operands of everything behind the encoder are ready
+        lc.side_join()                       # the operands of the bottleneck transformer and the decoder are ready
+        lc.side_run(lambda: store.refresh(1))      # the ROI bridges' operands: beside the bottleneck transformer
         bt = dec.bridge_list[nl - 1].transformer
         t = self._token_transformer(bt.layers, bt.pos_encoders[0], t, p, seeds, x_res=t_r)
         masks = []
@@ -454,6 +465,7 @@ class MaskTransUnet(nn.Module):
             skip = ops.attention_gate(skips[-i], t_gate, ag.W_x[0].weight, ag.W_x[0].bias, ag.W_g[0].weight, ag.W_g[0].bias,
                                       ag.psi[0].weight, ag.psi[0].bias, store.lin[id(ag.W_x[0])], store.lin[id(ag.W_g[0])])
             if self.is_roi_list[lvl]:
+                lc.side_join()               # (first bridge only: the bridges' operands are ready)
                 skip = self._roi_bridge(dec.bridge_list[lvl], skip, m.detach(), self.roi_size_list[lvl], p, seeds)
             t = ops.instnorm_act(t1, act=ops.ACT_LRELU)
             t = self._conv_in_act(t, blk.conv2, x1=skip, p=p, seeds=seeds)
