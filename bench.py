@@ -477,12 +477,14 @@ def main():
         # HBM traffic of the same kernel family from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): counters need their
         # own rocprofv3 --pmc passes, so this is the committed offline collection of tools/pmc_step.sh, not a live number
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_step.json')
-        if os.path.exists(pmc):
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_step.json')))
+        pmc = pmcs[-1] if pmcs else ''
+        if pmc:
             fam = json.load(open(pmc))['families'].get('transformer layer chain kernels (forward + backward)')
             if fam and fam['dispatches_per_step']:
                 traffic = (fam['hbm_read_GB_per_step'] + fam['hbm_write_GB_per_step']) * 1e9 / fam['dispatches_per_step']
-                traffic_src = 'profiles/r03_pmc_step.json (offline rocprofv3 --pmc passes of the same step)'
+                traffic_src = f'profiles/{os.path.basename(pmc)} (offline rocprofv3 --pmc passes of the same step)'
         ms_step = dt / args.steps * 1e3
         roof_ms = ROOF_MS_PER_PATCH.get(args.size)
         out = {

@@ -41,9 +41,10 @@ FAMILIES = [
     ('linear attention core', r'linattn_'),
     ('3x3x3 conv forward / data gradient (LDS halo)', r'conv3_halo_bf16|conv3_halo_ws'),
     ('3x3x3 conv weight gradient (LDS halo) + fold', r'conv3_wgrad_halo|wgrad_reduce_kernel'),
-    ('class convolutions (sub-pixel un-embedding, strided dgrad)', r'conv_class_ring|upconv_wgrad'),
+    ('class convolutions (sub-pixel un-embedding, strided dgrad)', r'conv_class_ring|upconv_wgrad|upconv_ring|sdgrad_ring'),
     ('implicit-GEMM convs (strided forward, gather weight gradient)', r'igemm_nt|wgrad_tn'),
     ('InstanceNorm', r'instnorm_'),
+    ('attention gates (1x1x1 convs, gate kernels)', r'pw_small|gate_'),
 ]
 
 

@@ -8,6 +8,8 @@ cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
 rows = db.execute(f"select name, start, end, {qcol or '0'} from kernels order by start").fetchall()
 starts = [i for i, r in enumerate(rows) if 'weight_prep_chunk_kernel' in r[0]]
+# a step refreshes its weight operands in up to three launches (encoder / decoder / bridges): the first of each group starts the step
+starts = [i for k, i in enumerate(starts) if k == 0 or rows[i][1] - rows[starts[k - 1]][1] > 3000000]
 i0, i1 = starts[-which - 1], starts[-which]
 step = rows[i0:i1]
 short = lambda n: re.sub(r'\(.*', '', n).replace('void ', '')[:60]

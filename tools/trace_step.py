@@ -7,6 +7,8 @@ db = sqlite3.connect(args[0])
 which = int(sys.argv[sys.argv.index('--which') + 1]) if '--which' in sys.argv else 2
 rows = db.execute('select name, start, end from kernels order by start').fetchall()
 starts = [i for i, r in enumerate(rows) if 'weight_prep_chunk_kernel' in r[0]]
+# a step refreshes its weight operands in up to three launches (encoder / decoder / bridges): the first of each group starts the step
+starts = [i for k, i in enumerate(starts) if k == 0 or rows[i][1] - rows[starts[k - 1]][1] > 3000000]
 i0, i1 = starts[-which - 1], starts[-which]
 step = rows[i0:i1]
 short = lambda n: re.sub(r'\(.*', '', n).replace('void ', '')[:70]
