@@ -324,7 +324,8 @@ int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, in
                    uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dx, and dw [C][27] +=, db [C] += (zero-filled by the caller); dy2 (nullable): gradient of a second consumer, summed on load.
  * ws: ltu_dwconv_bwd_ws_floats(...) floats for the per-workgroup partial sums of dw / db, folded in a fixed order; NULL falls
- * back to float atomics (the two gradients then differ in the last bits from run to run). */
+ * back to float atomics (the two gradients then differ in the last bits from run to run).  dx NULL: only dw / db are computed;
+ * dw NULL: only dx (the two halves are independent launches: the weight gradient can be issued later, off the data-gradient chain). */
 long long ltu_dwconv_bwd_ws_floats(int B, int H, int W, int D, int C, int dtype);
 int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dw, float* db, float* ws, int B,
                    int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);

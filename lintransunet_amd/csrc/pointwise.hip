@@ -1039,8 +1039,12 @@ extern "C" int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, co
                               int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
   LTU_DISPATCH_T(dtype, {
-    launch_dwconv_halo<T, 1>(dy, dy2, nullptr, nullptr, w, nullptr, dx, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s);
-    launch_dwconv_halo<T, 2>(x, nullptr, dy, dy2, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s, ws);
+    // either half may be left out (dx NULL: weight / bias gradient only; dwt NULL: data gradient only): the weight gradient is off
+    // the data-gradient chain and the caller may issue it later, on another stream
+    if (dx != nullptr)
+      launch_dwconv_halo<T, 1>(dy, dy2, nullptr, nullptr, w, nullptr, dx, nullptr, nullptr, B, H, W, D, C, p, seed, step, (hipStream_t)s);
+    if (dwt != nullptr)
+      launch_dwconv_halo<T, 2>(x, nullptr, dy, dy2, w, nullptr, nullptr, dwt, db, B, H, W, D, C, p, seed, step, (hipStream_t)s, ws);
   });
   return ltu_check_launch();
 }

@@ -1363,9 +1363,18 @@ class _PosConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        ws = torch.empty(_lib.load().ltu_dwconv_bwd_ws_floats(B, H, W, D, C, _dt(x)), device=x.device, dtype=torch.float32)
-        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), _p(dw), _p(db), _p(ws), B, H, W, D, C, float(p), seed,
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), 0, 0, 0, B, H, W, D, C, float(p), seed,
                   lc.step_ptr(), _dt(x), _s())
+
+        def launch(keep):                    # the weight / bias gradient: off the data-gradient chain
+            ws = torch.empty(_lib.load().ltu_dwconv_bwd_ws_floats(B, H, W, D, C, _dt(x)), device=x.device, dtype=torch.float32)
+            keep.append(ws)
+            _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), 0, _p(dw), _p(db), _p(ws), B, H, W, D, C, float(p), seed,
+                      lc.step_ptr(), _dt(x), _s())
+        if fw and fb:
+            lc.wq_push(launch, (g, g2, x))
+        else:
+            launch([])
         return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None, None
 
 
