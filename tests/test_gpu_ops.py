@@ -141,6 +141,10 @@ def test_linear_bf16(ops, M, K, N, nw):
     (1, 256, 128, 4, 4, 8, (1, 1, 1), 0, False, None),   # stride-1 halo conv on one brick row: channel-split + fold
     (1, 16, 16, 36, 38, 60, (1, 1, 1), 0, False, None),  # persistent few-channel kernels: 720 ragged bricks on 512 workgroups (the
     (1, 32, 32, 36, 38, 60, (1, 1, 1), 0, False, None),  # double-buffered brick loop runs more than once), 16 and 32 channels
+    (1, 16, 16, 17, 30, 41, (1, 1, 1), 16, False, None), # conv_fc_ring.hip: 16 + 16 concat -> 16, bricks ragged in every axis
+    (2, 32, 32, 18, 33, 44, (1, 1, 1), 0, False, None),  # ... 32 -> 32, more bricks than workgroups
+    (1, 32, 24, 21, 34, 37, (1, 1, 1), 0, False, None),  # ... 24 outputs
+    (1, 8, 24, 21, 34, 37, (1, 1, 1), 24, False, None),  # ... 8 + 24 concat
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
@@ -181,6 +185,7 @@ def test_conv3d_bf16(ops, case):
 @pytest.mark.parametrize('case', [
     # B, Ci, Ca, Cb, n1, H, W, D
     (2, 32, 16, 2, 16, 9, 7, 12),      # level-0 shape class: weight-stationary kernel, data gradient from a 16+16 concat
+    (1, 32, 16, 2, 16, 18, 33, 41),    # the same on a grid of 240 ragged bricks: conv_fc_ring.hip, forward into two outputs
     (1, 64, 32, 2, 32, 8, 8, 16),      # generic halo kernel, 64-column tile
     (1, 256, 128, 3, 32, 4, 4, 8),     # deep level: channel-split forward, 160-channel gradient concat
 ])
