@@ -433,6 +433,10 @@ class MaskTransUnet(nn.Module):
         skips = []
         nblk = len(enc.block_list)
         for i, blk in enumerate(enc.block_list):
+            if i == 0 and ops.WQ_FLUSH_IN_ENCODER:
+                # backward reaches this point after the first block's conv1: its weight gradient goes out beside the stem's
+                # InstanceNorm backward instead of behind the last kernel of the step (only the stem's own weight gradient is left there)
+                t = ops.wgrad_flush_point(t, 'enc')
             s, s_skip = self._conv_in_act(t, blk.conv1, res=t_r, res_dup=t_r2, seeds=seeds, fork=2)
             if i == 0:
                 # the operands of the bottleneck transformer and the decoder: beside the encoder's deeper (latency-bound) levels - not

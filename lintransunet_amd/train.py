@@ -347,10 +347,12 @@ class GraphedStep:
 
     def _body(self, zero, reduce, on_flush=None, on_join=None):
         self.counter.add_(1)
-        if zero:
-            self.reducer.zero_grad()
         self.ctx.wq_install(self.wq_stream, on_flush, on_join)       # weight gradients in batches on a side stream / as graphs of their own
         try:
+            if zero:
+                # nothing accumulates into the gradient buffers before backward: the fills run on the side stream, beside the
+                # encoder (joined with the other forward-side work in front of the bottleneck transformer)
+                self.ctx.side_run(self.reducer.zero_grad)
             return train_step(self.model, self.x, self.lab, self.weights, step_times=self.step_times, specs=self.specs,
                               reducer=self.reducer, ctx=self.ctx, level_scale=self.level_scale,
                               reduce=reduce and self.overlap in ('graph', 'segments'))
