@@ -364,7 +364,24 @@ class GraphedStep:
         return (tuple(p.data_ptr() for p in ps), tuple(0 if p.grad is None else p.grad.data_ptr() for p in ps),
                 tuple(f.data_ptr() for f in self.reducer.flat))
 
+    # Width of the weight-gradient kernels while they run on the side stream: half the machine.  At their stand-alone width (256
+    # workgroups) they crowd the main chain's kernels out of the CUs (every main-chain kernel of backward ran 1.3-2x longer beside
+    # them); at 128 the side stream is still far from being the critical path (64: it becomes it, 14.7 ms).  tools/sweep_side_grids.sh:
+    # 13.58 -> 13.29 ms.  The knobs are process-wide, so they are set around the capture only (a captured graph keeps its grids).
+    SIDE_WIDTH = {'LTU_WGROUP_BLOCKS': 128, 'LTU_UPW_BLOCKS': 128}
+
     def _capture(self, key):
+        from . import _lib
+        narrow = [k for k in self.SIDE_WIDTH if self.wq_stream is not None and k not in os.environ]
+        for k in narrow:
+            _lib.config_set(k, self.SIDE_WIDTH[k])
+        try:
+            self._capture_inner(key)
+        finally:
+            for k in narrow:
+                _lib.config_set(k, None)
+
+    def _capture_inner(self, key):
         zero, reduce = key
         dev = self.dev
         if not self.graphs:            # first capture (or re-capture): warm up allocator pools, arena size, weight store, RCCL
