@@ -192,6 +192,8 @@ int launch_pw_small_bf16(const void* x, int lda, const void* w, const float* bia
                          hipStream_t st);
 // data gradient of a stride-(2,2,sd) conv (sdgrad_ring.hip): LTU_OK / hipError, or 1 = shape not handled
 int launch_sdgrad_ring_bf16(const void* grad, const void* wd, void* dx, int B, int Hl, int Wl, int Dl, int N, int Co, int sd, hipStream_t st);
+// data gradient of the sub-pixel un-embedding (updgrad_ring.hip): LTU_OK / hipError, or 1 = shape not handled
+int launch_updgrad_ring_bf16(const void* grad, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co, hipStream_t st);
 // sub-pixel un-embedding forward, second generation (upconv_ring.hip): LTU_OK / hipError, or 1 = shape not handled
 int launch_upconv_ring_bf16(const void* x, const void* wsub_f, const float* bias, void* y, int B, int H, int W, int D, int Ci, int Co,
                             hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled

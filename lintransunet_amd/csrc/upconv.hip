@@ -80,6 +80,10 @@ extern "C" int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bi
 extern "C" int ltu_upconv_dgrad(const void* grad, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co,
                                 float* ws, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
+  if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_UPDGRAD_RING", 0)) {      // class-planar halo kernel (updgrad_ring.hip)
+    const int hr = launch_updgrad_ring_bf16(grad, wsub_d, dx, B, H, W, D, Ci, Co, (hipStream_t)s);
+    if (hr != 1) return hr;
+  }
   IGemmArgs g;
   memset(&g, 0, sizeof(g));
   g.nb = B; g.rh = H; g.rw = W; g.rd = D;

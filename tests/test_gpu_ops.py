@@ -269,7 +269,9 @@ def test_conv3d(ops, case):
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
 @pytest.mark.parametrize('B,Ci,Co,H,W,D', [(2, 16, 8, 3, 4, 2), (1, 32, 16, 5, 3, 4), (1, 128, 32, 4, 3, 5), (2, 64, 72, 5, 6, 9),
-                                          (1, 128, 64, 4, 4, 4)])     # last: K = 64*Co = 4096 on a tiny grid -> K-split data gradient
+                                          (1, 128, 64, 4, 4, 4),      # K = 64*Co = 4096 on a tiny grid -> K-split data gradient
+                                          (1, 128, 32, 5, 9, 11), (2, 256, 64, 6, 8, 9), (1, 256, 128, 4, 10, 8)])   # ring kernels: ragged bricks,
+                                                                                                                      # two column halves, four chunks
 def test_upconv_subpixel(ops, dtype, tol, B, Ci, Co, H, W, D):
     """nearest x2 + conv3x3x3 computed as 8 parity-class 2x2x2 convs with pre-summed weights == the plain formulation"""
     g = G(13)
