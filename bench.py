@@ -467,7 +467,8 @@ def main():
         # every bucket but the last finishes under the remaining compute; ~0.3 ms of segment / launch overhead + the tail bucket's latency
         diag['expected'] = 'exposed <= ~0.4 ms at 8 ranks (32 MB buckets + 0.5 MB tail): >= 7.7x weak scaling'
     if ft is not None and ft.calls and launch == 'hip-graph replay':
-        families = ft.table(ft.measure(), args.size, args.batch)      # replays kernels on stale buffers: after the timed region
+        with graphed.capture_knobs():              # the recorded calls' workspaces were sized under the capture's launch-geometry knobs
+            families = ft.table(ft.measure(), args.size, args.batch)      # replays kernels on stale buffers: after the timed region
         reducer.zero_grad()                                            # ... and the weight-gradient kernels among them accumulate
         torch.cuda.synchronize()
 

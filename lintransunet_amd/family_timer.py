@@ -94,7 +94,12 @@ class FamilyTimer:
         fams = {}
         for name, a, keep in self.calls:
             fams.setdefault(family_of(name), []).append((name, a))
+        import os, sys
+        only = os.environ.get('LTU_FAMILY_ONLY')
         for fam, lst in fams.items():
+            if only and fam != only:
+                continue
+            print(f'[family_timer] replaying {fam}: {len(lst)} calls', file=sys.stderr, flush=True)
             def issue():
                 st = torch.cuda.current_stream().cuda_stream
                 for name, a in lst:

@@ -370,16 +370,27 @@ class GraphedStep:
     # 13.58 -> 13.29 ms.  The knobs are process-wide, so they are set around the capture only (a captured graph keeps its grids).
     SIDE_WIDTH = {'LTU_WGROUP_BLOCKS': 128, 'LTU_UPW_BLOCKS': 128}
 
-    def _capture(self, key):
+    def capture_knobs(self):
+        """context manager: the process-wide launch-geometry knobs this step was captured under.  Anything that re-issues the step's
+        recorded C-ABI calls (family_timer: their workspaces were sized under these knobs) has to run inside it."""
+        import contextlib
         from . import _lib
-        narrow = [k for k in self.SIDE_WIDTH if self.wq_stream is not None and k not in os.environ]
-        for k in narrow:
-            _lib.config_set(k, self.SIDE_WIDTH[k])
-        try:
-            self._capture_inner(key)
-        finally:
+
+        @contextlib.contextmanager
+        def cm():
+            narrow = [k for k in self.SIDE_WIDTH if self.wq_stream is not None and k not in os.environ]
             for k in narrow:
-                _lib.config_set(k, None)
+                _lib.config_set(k, self.SIDE_WIDTH[k])
+            try:
+                yield
+            finally:
+                for k in narrow:
+                    _lib.config_set(k, None)
+        return cm()
+
+    def _capture(self, key):
+        with self.capture_knobs():
+            self._capture_inner(key)
 
     def _capture_inner(self, key):
         zero, reduce = key

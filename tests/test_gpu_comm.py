@@ -222,3 +222,22 @@ def test_bench_with_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
     assert out['config']['launch'].startswith('hip-graph replay') and 'segments' in out['config']['allreduce']
+
+
+def test_bench_default_path_with_family_table():
+    """the driver's invocation shape of bench.py on one GPU (HIP-graph replay as linear segments + side-stream weight gradients, the
+    chain-kernel roofline object AND the per-family table, whose replay re-issues every recorded C-ABI call of the step: it runs
+    under the launch-geometry knobs of the capture - sized differently, the replayed weight-gradient kernels overran their
+    workspaces and the benchmark died of a GPU fault in round 4), small patch, no CPU baseline"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--size', '64', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['config']['launch'].startswith('hip-graph replay (segments')
+    fams = {f['family']: f for f in out['roofline']['families']}
+    assert {'transformer', 'conv3', 'instnorm'} <= set(fams) and all(f['ms_per_step'] > 0 for f in fams.values())
