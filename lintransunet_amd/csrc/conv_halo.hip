@@ -762,6 +762,10 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
     else hipLaunchKernelGGL((conv3_halo_ws_bf16_kernel<16>), dim3(nblk), dim3(256), 0, st, a, (int)bricks);
     return ltu_check_launch();
   }
+  if ((a.C >= 64 || a.N > 32) && !ltu_knob("LTU_NO_CONV_RING", 0)) {     // second generation for grids that fill the machine (conv_ring.hip)
+    const int hr = launch_conv_ring_bf16(a, st);
+    if (hr != 1) return hr;
+  }
   int cps = 0;
   a.ksplit = a.part != nullptr && !ltu_knob("LTU_NO_HALO_SPLIT", 0) ? halo_split(bricks, a.N, a.C, a.CC, &cps) : 1;
   a.cps = cps;

@@ -145,6 +145,12 @@ def test_linear_bf16(ops, M, K, N, nw):
     (2, 32, 32, 18, 33, 44, (1, 1, 1), 0, False, None),  # ... 32 -> 32, more bricks than workgroups
     (1, 32, 24, 21, 34, 37, (1, 1, 1), 0, False, None),  # ... 24 outputs
     (1, 8, 24, 21, 34, 37, (1, 1, 1), 24, False, None),  # ... 8 + 24 concat
+    (1, 64, 64, 20, 33, 41, (1, 1, 1), 0, False, None),  # conv_ring.hip: two chunks, 64-column tile, 240 ragged bricks
+    (1, 32, 32, 21, 34, 37, (1, 1, 1), 32, False, None), # ... 32 + 32 concat -> 32 (half a column tile), data gradient 32 -> 64 into two tensors
+    (1, 96, 160, 12, 33, 41, (1, 1, 1), 0, False, None), # ... three chunks, 128-column tiles (the second one ragged)
+    (2, 64, 72, 9, 32, 40, (1, 1, 1), 64, False, None),  # ... 64 + 64 concat -> 72
+    (1, 64, 64, 32, 60, 68, (1, 1, 1), 0, False, None),  # ... eight-wave variant: 8x8x8 bricks (288 of them, ragged in w and d)
+    (1, 32, 40, 16, 62, 70, (1, 1, 1), 32, False, None), # ... the same with a 32 + 32 concat and 40 outputs (run at any grid size by the knob below)
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
@@ -186,6 +192,7 @@ def test_conv3d_bf16(ops, case):
     # B, Ci, Ca, Cb, n1, H, W, D
     (2, 32, 16, 2, 16, 9, 7, 12),      # level-0 shape class: weight-stationary kernel, data gradient from a 16+16 concat
     (1, 32, 16, 2, 16, 18, 33, 41),    # the same on a grid of 240 ragged bricks: conv_fc_ring.hip, forward into two outputs
+    (1, 64, 32, 2, 32, 18, 33, 41),    # conv_ring.hip: 64 -> 32 + 32 pair on 240 bricks, data gradient from the 32 + 32 gradient concat
     (1, 64, 32, 2, 32, 8, 8, 16),      # generic halo kernel, 64-column tile
     (1, 256, 128, 3, 32, 4, 4, 8),     # deep level: channel-split forward, 160-channel gradient concat
 ])
