@@ -31,6 +31,10 @@ cp gpurun_out/pmc_valu.txt gpurun_out/${R}_pmc_valu.txt
   echo; echo "== the same with the first-generation class kernel (LTU_NO_UPRING=1)"; LTU_NO_UPRING=1 python3 tools/bench_class.py 2 39 23 64 128 32  2 24 14 32 256 64  2 15 9 32 256 128  2 8 8 8 256 256 2>/dev/null
   echo; echo "== bench_sdgrad.py (data gradient of the stride-2 convs)"; python3 tools/bench_sdgrad.py 2>/dev/null
   echo; echo "== the same with the first-generation class kernel (LTU_NO_SDGRAD_RING=1)"; LTU_NO_SDGRAD_RING=1 python3 tools/bench_sdgrad.py 2>/dev/null
+  echo; echo "== bench_updgrad.py (data gradient of the un-embedding)"; python3 tools/bench_updgrad.py 2>/dev/null
+  echo; echo "== the same through the 64-tap gather implicit GEMM (LTU_NO_UPDGRAD_RING=1)"; LTU_NO_UPDGRAD_RING=1 python3 tools/bench_updgrad.py 2>/dev/null
+  echo; echo "== bench_conv.py at the 32x32x128 level: generic convs in the ring style"; python3 tools/bench_conv.py 2 32 32 128 64 0 64  2 32 32 128 32 32 32  2 16 16 64 128 0 160 2>/dev/null
+  echo; echo "== the same with the first-generation halo kernel (LTU_NO_CONV_RING=1)"; LTU_NO_CONV_RING=1 python3 tools/bench_conv.py 2 32 32 128 64 0 64  2 32 32 128 32 32 32  2 16 16 64 128 0 160 2>/dev/null
   echo; echo "== bench_gate_proj.py (attention gates' 1x1x1 convs)"; python3 tools/bench_gate_proj.py 2>/dev/null
   echo; echo "== the same through the implicit GEMM (LTU_NO_PW_SMALL=1)"; LTU_NO_PW_SMALL=1 python3 tools/bench_gate_proj.py 2>/dev/null
   echo; echo "== bench_dwconv.py (positional depthwise conv)"; python3 tools/bench_dwconv.py 2>/dev/null
