@@ -429,7 +429,7 @@ def _w_transposed(ws, rows, cols, dtype):
 DEFER_WGRAD = False
 GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_linear_wgrad_group)
 import os as _os
-WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '128'))     # operand bytes of the layers' weight-gradient groups launched together
+WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '400'))     # operand bytes of the layers' weight-gradient groups launched together
 WQ_MAX_JOBS = int(_os.environ.get('LTU_WQ_JOBS', '1000000'))      # weight-gradient queue: a batch goes out when this many launches are queued
 WQ_SIDE_FWD = _os.environ.get('LTU_WQ_FWD', '1') == '1'      # forward-side work (weight operands behind the encoder, label pyramid) on the side stream
 WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
