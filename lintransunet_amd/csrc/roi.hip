@@ -676,6 +676,78 @@ __global__ void __launch_bounds__(256) tri_adj1d_pair_kernel(const T* __restrict
   else tri_adj1d_pair_body<T, HAS2, 8>(ib, ib2, ob0, ob1, os, w0, w1, inner, nvec);
 }
 
+// Short rows (the depth pass: inner = C elements, 4-16 vectors): one pair of output rows per workgroup leaves 4-16 of its 256
+// lanes busy (the 64x64x128 x 32 depth pass: 262 144 workgroups, 154 us for 167 MB).  Here a workgroup carries 256 / nvec
+// pairs; every lane reads its own pair's table entry.  The union lists are padded with (row o[0], weight 0) entries, so the
+// loads are unconditional (8 per tensor, all requested before the first add); a pair whose union is longer than 8 does its
+// two rows singly from the per-row table.
+template <typename T, bool HAS2>
+__global__ void __launch_bounds__(256) tri_adj1d_pair_rows_kernel(const T* __restrict__ in, const T* __restrict__ in2, T* __restrict__ out,
+                                                                  int L_fine, int L_coarse, int inner, int nvec, long long total,
+                                                                  const TriEntry* __restrict__ table, const TriPair* __restrict__ ptable) {
+  constexpr int NV = TriVec<T>::NV;
+  const int rpb = 256 / nvec;
+  const int sub = (int)threadIdx.x / nvec, v = (int)threadIdx.x - sub * nvec;
+  const long long idx = (long long)blockIdx.x * rpb + sub;
+  if (sub >= rpb || idx >= total) return;
+  const unsigned npair = ((unsigned)L_coarse + 1u) >> 1;
+  const long long outer = idx / npair;
+  const int pr = (int)(idx - outer * npair);
+  const int l0 = 2 * pr, l1 = l0 + 1;
+  const T* ib = in + outer * L_fine * inner + v * NV;
+  const T* ib2 = HAS2 ? in2 + outer * L_fine * inner + v * NV : nullptr;
+  T* ob0 = out + (outer * L_coarse + l0) * inner + v * NV;
+  const TriPair* tp = ptable + pr;
+  const int n = tp->n;
+  if (n < 0) {
+    for (int which = 0; which < 2; ++which) {
+      const int l = which == 0 ? l0 : l1;
+      if (l >= L_coarse) break;
+      const TriEntry* te = table + l;
+      float acc[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) acc[e] = 0.f;
+      for (int k = 0; k < 8; ++k) {
+        float q[NV];
+        TriVec<T>::load(ib + (long long)te->o[k] * inner, q);
+        if constexpr (HAS2) {
+          float q2[NV];
+          TriVec<T>::load(ib2 + (long long)te->o[k] * inner, q2);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) q[e] += q2[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] += q[e] * te->w[k];
+      }
+      TriVec<T>::store(ob0 + (long long)which * inner, acc);
+    }
+    return;
+  }
+  int os[8];
+  float w0[8], w1[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { os[q] = tp->o[q]; w0[q] = tp->w0[q]; w1[q] = tp->w1[q]; }
+  float q[8][NV], q2[8][NV];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    TriVec<T>::load(ib + (long long)os[k] * inner, q[k]);
+    if constexpr (HAS2) TriVec<T>::load(ib2 + (long long)os[k] * inner, q2[k]);
+  }
+  float a0[NV], a1[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const float x = HAS2 ? q[k][e] + q2[k][e] : q[k][e];
+      a0[e] += x * w0[k];
+      a1[e] += x * w1[k];
+    }
+  TriVec<T>::store(ob0, a0);
+  if (l1 < L_coarse) TriVec<T>::store(ob0 + inner, a1);
+}
+
 static float tri_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 static float tri_inv(int in, int out) { return (float)(out - 1) / (float)(in - 1 > 0 ? in - 1 : 1); }
 
@@ -686,6 +758,16 @@ static void launch_tri_adj1d(const T* in, const T* in2, T* out, long long outer,
   unsigned gx = (unsigned)((nv + 255) / 256);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
+  if (ptable != nullptr && L_fine != L_coarse && nv <= 64 && inner < (1 << 20) && !ltu_knob("LTU_TRI_NO_ROWS", 0)) {
+    const long long total = outer * ((L_coarse + 1) / 2);
+    const int rpb = 256 / (int)nv;
+    const dim3 rgrid((unsigned)((total + rpb - 1) / rpb));
+    if (in2 != nullptr)
+      hipLaunchKernelGGL((tri_adj1d_pair_rows_kernel<T, true>), rgrid, dim3(256), 0, st, in, in2, out, L_fine, L_coarse, (int)inner, (int)nv, total, table, ptable);
+    else
+      hipLaunchKernelGGL((tri_adj1d_pair_rows_kernel<T, false>), rgrid, dim3(256), 0, st, in, (const T*)nullptr, out, L_fine, L_coarse, (int)inner, (int)nv, total, table, ptable);
+    return;
+  }
   if (ptable != nullptr && L_fine != L_coarse) {
     const dim3 pgrid((unsigned)(outer * ((L_coarse + 1) / 2)), gx);
     if (in2 != nullptr) hipLaunchKernelGGL((tri_adj1d_pair_kernel<T, true>), pgrid, dim3(256), 0, st, in, in2, out, L_fine, L_coarse, inner, table, ptable);

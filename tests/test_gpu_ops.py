@@ -812,10 +812,13 @@ def _with_knob(name, value, fn):
         _lib.call('ltu_config_set', name, 0, 1)
 
 
-@pytest.mark.parametrize('sd,shape', [(2, (2, 8, 5, 7, 6)), (1, (1, 16, 9, 4, 8)), (2, (1, 8, 3, 3, 3))])
+@pytest.mark.parametrize('sd,shape', [(2, (2, 8, 5, 7, 6)), (1, (1, 16, 9, 4, 8)), (2, (1, 8, 3, 3, 3)), (2, (2, 32, 4, 5, 7)),
+                                      (2, (1, 128, 2, 3, 5)), (2, (1, 520, 2, 2, 3))])
 def test_trilinear_adjoint_row_pairs(ops, sd, shape):
     """the separable adjoint with two adjacent output rows per workgroup (merged candidate table) against one row per workgroup
-    (LTU_TRI_NO_PAIR): the same terms in the same order, so bit-identical; odd lengths leave a last pair with one row"""
+    (LTU_TRI_NO_PAIR): the same terms in the same order, so bit-identical; odd lengths leave a last pair with one row.  Short rows
+    (the depth pass: C elements) take several pairs per workgroup (tri_adj1d_pair_rows_kernel); LTU_TRI_NO_ROWS is the one-pair
+    kernel: bit-identical as well (the padded union entries carry weight 0)"""
     g = G(12)
     x = torch.randn(shape, generator=g)
     out = []
@@ -830,6 +833,7 @@ def test_trilinear_adjoint_row_pairs(ops, sd, shape):
             return xq.grad.float().clone()
         a, b = run(), _with_knob(b'LTU_TRI_NO_PAIR', 1, run)
         assert torch.equal(a, b), dt
+        assert torch.equal(a, _with_knob(b'LTU_TRI_NO_ROWS', 1, run)), dt
         out.append(a)
     assert rel_err(out[1], out[0]) < 1.5e-2
 
