@@ -261,60 +261,91 @@ __global__ void weight_prep_kernel(const WPrep* __restrict__ table) {
 // 8 consecutive DESTINATION elements per thread for the dense-weight kinds (0 copy, 1 transpose, 8 / 9 fragment order): the eight
 // source values are requested together and leave as ONE 16-byte (bf16) store.  The element-at-a-time loop (a 4-byte load and a
 // 2-byte store per iteration) ran the once-per-step preparation of 84 MB of masters at ~1.3 TB/s.
-template <typename TW>
-__device__ __forceinline__ bool weight_prep_vec8(const WPrep& d, unsigned base, unsigned tid, unsigned nthr) {
-  if (sizeof(TW) != 2 || !(d.kind == 0 || d.kind == 1 || d.kind == 8 || d.kind == 9)) return false;
-  const unsigned n = (unsigned)d.R * (unsigned)d.C, R = (unsigned)d.R, C = (unsigned)d.C;
+__device__ __forceinline__ bool wp8_ok(const WPrep& d, int tw_size) {
+  if (tw_size != 2 || !(d.kind == 0 || d.kind == 1 || d.kind == 8 || d.kind == 9)) return false;
+  const unsigned n = (unsigned)d.R * (unsigned)d.C, R = (unsigned)d.R;
   if (n % 8 || (reinterpret_cast<uintptr_t>(d.dst) & 15)) return false;
   if (d.kind == 1 && (R % 8 || ((d.p0 | d.p1) % 8))) return false;
-  uint16_t* dst = reinterpret_cast<uint16_t*>(d.dst);
-  const bool src16 = (reinterpret_cast<uintptr_t>(d.src) & 15) == 0;      // masters inside a flat gradient bucket start anywhere
-  for (unsigned v = tid; v < LTU_WPREP_CHUNK / 8; v += nthr) {
-    const unsigned i = base + v * 8;
-    if (i >= n) break;
-    float f[8];
-    size_t o = i;                                        // destination element of f[0]
-    if (d.kind == 0) {
-      if (src16) {
-        const float4 a = *reinterpret_cast<const float4*>(d.src + i), b = *reinterpret_cast<const float4*>(d.src + i + 4);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = d.src[i + j];
-      }
-    } else if (d.kind == 1) {                            // dst[c * p0 + p1 + r] = src[r * C + c], i = c * R + r, 8 consecutive r
-      const unsigned c = i / R, r = i - c * R;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = d.src[(size_t)(r + j) * C + c];
-      o = (size_t)c * d.p0 + d.p1 + r;
-    } else {                                             // fragment order: i = ((ct * KS + ks) * 64 + l) * 8 + j
-      const unsigned KS = (d.kind == 8 ? C : R) >> 4;
-      const unsigned l = (i >> 3) & 63u, t = i >> 9;
-      const unsigned ks = t % KS, ct = t / KS;
-      const unsigned oo = ct * 32u + (l & 31u), r = ks * 16u + 8u * (l >> 5);
-      if (d.kind == 8 && src16 && C % 4 == 0) {
-        const float4 a = *reinterpret_cast<const float4*>(d.src + (size_t)oo * C + r), b = *reinterpret_cast<const float4*>(d.src + (size_t)oo * C + r + 4);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-      } else if (d.kind == 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = d.src[(size_t)oo * C + r + j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = d.src[(size_t)(r + j) * C + oo];
-      }
-    }
-    *reinterpret_cast<uint4*>(dst + o) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-  }
   return true;
 }
+// the eight source values of destination elements i .. i + 7 of record d (i a multiple of 8); returns the destination offset of f[0]
+__device__ __forceinline__ size_t wp8_load(const WPrep& d, unsigned i, float (&f)[8]) {
+  const unsigned R = (unsigned)d.R, C = (unsigned)d.C;
+  const bool src16 = (reinterpret_cast<uintptr_t>(d.src) & 15) == 0;      // masters inside a flat gradient bucket start anywhere
+  size_t o = i;
+  if (d.kind == 0) {
+    if (src16) {
+      const float4 a = *reinterpret_cast<const float4*>(d.src + i), b = *reinterpret_cast<const float4*>(d.src + i + 4);
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = d.src[i + j];
+    }
+  } else if (d.kind == 1) {                            // dst[c * p0 + p1 + r] = src[r * C + c], i = c * R + r, 8 consecutive r
+    const unsigned c = i / R, r = i - c * R;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = d.src[(size_t)(r + j) * C + c];
+    o = (size_t)c * d.p0 + d.p1 + r;
+  } else {                                             // fragment order: i = ((ct * KS + ks) * 64 + l) * 8 + j
+    const unsigned KS = (d.kind == 8 ? C : R) >> 4;
+    const unsigned l = (i >> 3) & 63u, t = i >> 9;
+    const unsigned ks = t % KS, ct = t / KS;
+    const unsigned oo = ct * 32u + (l & 31u), r = ks * 16u + 8u * (l >> 5);
+    if (d.kind == 8 && src16 && C % 4 == 0) {
+      const float4 a = *reinterpret_cast<const float4*>(d.src + (size_t)oo * C + r), b = *reinterpret_cast<const float4*>(d.src + (size_t)oo * C + r + 4);
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else if (d.kind == 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = d.src[(size_t)oo * C + r + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = d.src[(size_t)(r + j) * C + oo];
+    }
+  }
+  return o;
+}
 
-template <typename TW>
-__global__ void weight_prep_chunk_kernel(const WPrep* __restrict__ table, const int2* __restrict__ chunks) {
-  const int2 c = chunks[blockIdx.x];
-  const WPrep d = table[c.x];
-  const unsigned t0 = (unsigned)c.y * LTU_WPREP_CHUNK;
-  if (weight_prep_vec8<TW>(d, t0, threadIdx.x, blockDim.x)) return;
-  weight_prep_range<TW>(d, t0 + threadIdx.x, t0 + LTU_WPREP_CHUNK, blockDim.x);
+// A workgroup takes WP_NC chunks per trip and requests all their source values (2 x WP_NC vectors of eight per thread) before
+// its first store.  WP_NC = 4 for the long lists only: the ROI bridges' operands (9 000 chunks) are refreshed on a side stream beside
+// the bottleneck transformer, whose 5-25 us kernels were held back by 110 us behind one-chunk workgroups and by 75 us behind
+// four-chunk ones (the refresh itself 130 -> 152 us, off the chain); a short list (the encoder's 430 chunks, on the chain) would
+// no longer fill the machine: 14 -> 33 us.  gridDim.x may be smaller than the number of trips (LTU_WPREP_BLOCKS; narrowing the side
+// launches to 32 / 64 / 128 workgroups made them the critical path: +1.0 / +0.25 / +0.1 ms per step).  The step time itself is
+// the same with either trip size (interleaved A/B, +-0.03 ms).
+template <typename TW, int WP_NC>
+__global__ void __launch_bounds__(256) weight_prep_chunk_kernel(const WPrep* __restrict__ table, const int2* __restrict__ chunks, int nchunks) {
+  constexpr int PER = LTU_WPREP_CHUNK / 8 / 256;            // vectors of eight per thread and chunk
+  static_assert(PER * 256 * 8 == LTU_WPREP_CHUNK, "chunk size");
+  for (int c0 = blockIdx.x * WP_NC; c0 < nchunks; c0 += gridDim.x * WP_NC) {
+    float f[WP_NC][PER][8];
+    uint16_t* dp[WP_NC][PER];
+#pragma unroll
+    for (int k = 0; k < WP_NC; ++k) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) dp[k][u] = nullptr;
+      if (c0 + k >= nchunks) continue;
+      const int2 c = chunks[c0 + k];
+      const WPrep d = table[c.x];
+      const unsigned t0 = (unsigned)c.y * LTU_WPREP_CHUNK;
+      if (!wp8_ok(d, (int)sizeof(TW))) {
+        weight_prep_range<TW>(d, t0 + threadIdx.x, t0 + LTU_WPREP_CHUNK, blockDim.x);
+        continue;
+      }
+      const unsigned n = (unsigned)d.R * (unsigned)d.C;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const unsigned i = t0 + (threadIdx.x + u * 256u) * 8u;
+        if (i < n) dp[k][u] = reinterpret_cast<uint16_t*>(d.dst) + wp8_load(d, i, f[k][u]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WP_NC; ++k)
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+        if (dp[k][u] != nullptr)
+          *reinterpret_cast<uint4*>(dp[k][u]) = make_uint4(pack_bf16x2(f[k][u][0], f[k][u][1]), pack_bf16x2(f[k][u][2], f[k][u][3]),
+                                                           pack_bf16x2(f[k][u][4], f[k][u][5]), pack_bf16x2(f[k][u][6], f[k][u][7]));
+  }
 }
 
 extern "C" int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s) {
@@ -328,8 +359,16 @@ extern "C" int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stre
 extern "C" int ltu_weight_prep_chunks(const void* table, const int* chunks, int nchunks, int out_dtype, ltu_stream_t s) {
   if (nchunks <= 0) return LTU_OK;
   LTU_DISPATCH_T(out_dtype, {
-    hipLaunchKernelGGL((weight_prep_chunk_kernel<T>), dim3(nchunks), dim3(256), 0, (hipStream_t)s, (const WPrep*)table,
-                       (const int2*)chunks);
+    const int nc = nchunks >= ltu_knob_pos("LTU_WPREP_NC4_MIN", 6000) ? 4 : 1;
+    const int trips = (nchunks + nc - 1) / nc;
+    int blocks = ltu_knob_pos("LTU_WPREP_BLOCKS", trips);
+    if (blocks > trips) blocks = trips;
+    if (nc == 4)
+      hipLaunchKernelGGL((weight_prep_chunk_kernel<T, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const WPrep*)table,
+                         (const int2*)chunks, nchunks);
+    else
+      hipLaunchKernelGGL((weight_prep_chunk_kernel<T, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const WPrep*)table,
+                         (const int2*)chunks, nchunks);
   });
   return ltu_check_launch();
 }

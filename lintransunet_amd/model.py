@@ -13,6 +13,8 @@ The parameter containers are plain torch modules (they provide names, initialisa
 optimizer/DDP plumbing); their own forward() is never called - all arithmetic goes through
 `ops` (libltu_hip.so).  The module fails loudly on CPU tensors: there is no fallback path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -62,6 +64,9 @@ class _SeedStream:
 
 
 WPREP_CHUNK = 4096          # LTU_WPREP_CHUNK of include/ltu_hip.h
+# width (workgroups) of the operand refreshes that run on the side stream beside the encoder / the bottleneck transformer (0: full;
+# 32 / 64 / 128 made the refreshes the critical path: +1.0 / +0.25 / +0.1 ms per step)
+SIDE_REFRESH_BLOCKS = int(os.environ.get('LTU_SIDE_REFRESH_BLOCKS', '0'))
 
 
 class _WeightStore:
@@ -178,12 +183,20 @@ class _WeightStore:
         are appended behind all others by `finalize` and therefore belong to the LAST part"""
         self.marks = getattr(self, 'marks', []) + [len(self.recs)]
 
-    def refresh(self, part=None):
-        """part None: everything; p: the operands added between the p-th and the (p + 1)-th `mark()` (the last part: the rest)"""
+    def refresh(self, part=None, blocks=None):
+        """part None: everything; p: the operands added between the p-th and the (p + 1)-th `mark()` (the last part: the rest).
+        blocks: width of the launch (workgroups) - a refresh that runs on the side stream beside the step stays narrow, so that the
+        step's own kernels find free workgroup slots (SIDE_REFRESH_BLOCKS)"""
         lo, hi = (0, self.nchunks) if part is None else (self.bounds[part], self.bounds[part + 1])
         if hi > lo:
-            ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr() + lo * 8, hi - lo,
-                          ops.F32 if self.dtype == torch.float32 else ops.BF16, torch.cuda.current_stream().cuda_stream)
+            if blocks:
+                ops._lib.config_set('LTU_WPREP_BLOCKS', blocks)
+            try:
+                ops._lib.call('ltu_weight_prep_chunks', self.table.data_ptr(), self.chunks.data_ptr() + lo * 8, hi - lo,
+                              ops.F32 if self.dtype == torch.float32 else ops.BF16, torch.cuda.current_stream().cuda_stream)
+            finally:
+                if blocks:
+                    ops._lib.config_set('LTU_WPREP_BLOCKS', None)
 
 
 class MaskTransUnet(nn.Module):
@@ -441,7 +454,7 @@ class MaskTransUnet(nn.Module):
             if i == 0:
                 # the operands of the bottleneck transformer and the decoder: beside the encoder's deeper (latency-bound) levels - not
                 # beside its first, bandwidth-bound one, whose kernels a streaming side kernel slowed down 2-5x
-                lc.side_run(lambda: store.refresh(2))
+                lc.side_run(lambda: store.refresh(2, SIDE_REFRESH_BLOCKS))
             if ops.WQ_FLUSH_IN_ENCODER:
                 # backward reaches this point after conv2's (and the deeper block's conv1's) backward: their queued weight gradients go
                 # out as a batch beside this block's data gradients instead of piling up behind the last kernel of the step
@@ -453,7 +466,7 @@ class MaskTransUnet(nn.Module):
             skips.append(s_skip)
 
         lc.side_join()                       # the operands of the bottleneck transformer and the decoder are ready
-        lc.side_run(lambda: store.refresh(1))      # the ROI bridges' operands: beside the bottleneck transformer
+        lc.side_run(lambda: store.refresh(1, SIDE_REFRESH_BLOCKS))      # the ROI bridges' operands: beside the bottleneck transformer
         bt = dec.bridge_list[nl - 1].transformer
         t = self._token_transformer(bt.layers, bt.pos_encoders[0], t, p, seeds, x_res=t_r)
         masks = []
