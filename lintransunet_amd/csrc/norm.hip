@@ -667,6 +667,208 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
   }
 }
 
+// ---- small tensors: statistics + apply in ONE launch ---------------------------------------------------------------------------
+// At the coarsest level (4x4x32 x 256 per sample: 256 KB) the three launches of a normalisation (partial sums, fold, apply) are
+// 4.7-6 us each - launch ramp and dependent L2 round trips, not bytes - and so are the three of its backward (7-16 + 5 + 5-8 us).
+// Here one workgroup owns (sample, 16-byte channel group): it holds its part of the tensor in registers (all loads requested before
+// the first use), reduces through LDS and writes the result - no partials, no second kernel: 5.6 us forward, 10.7 us backward in
+// the step.  The 16 bytes per voxel row mean every 128-byte line is fetched by 8 workgroups, which is what limits the scheme to
+// the smallest level: at 1 MB per sample (8x8x64 x 128: 32 workgroups of 1 024 threads pulling 512 KB of lines each through one
+// CU's L1) the launch took 14-18 us forward and 23-40 us backward - no better than the three it replaces - so the default limit
+// is 256 KB (LTU_IN_SMALL_KB).  Same shift (first voxel), same statistics layout and the same dropout indexing as the streaming
+// kernels; the order of the fp32 sums differs (tests: tolerance, not bit equality).
+template <typename T, int VW>
+__device__ __forceinline__ uint4 in_raw_load(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+template <typename T, int VW>
+__device__ __forceinline__ void in_raw_cvt(const uint4 r, float (&f)[VW]) {
+  if constexpr (sizeof(T) == 2) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  } else {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+  }
+}
+// block sums of 2 VW values per thread: lds [nwaves][2 VW] + [2 VW]; every thread returns with the totals in a[]
+template <int NV>
+__device__ __forceinline__ void in_block_sums(float (&a)[NV], float* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    // pinned: hipcc otherwise contracts the caller's last multiply into the first add of the reduction (fma(d, d, neighbour)), the
+    // lanes of a wave then hold totals that differ in the last bit, and two instantiations of one kernel disagree with each other
+    asm volatile("" : "+v"(a[k]));
+    a[k] = wave_sum(a[k]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) lds[wave * NV + k] = a[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += lds[w * NV + threadIdx.x];
+    lds[nw * NV + threadIdx.x] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) a[k] = lds[nw * NV + k];
+}
+
+// grid (C / VW, B); block 256 or 1024; NIT = ceil(S / blockDim.x)
+template <typename T, int VW, int NIT, bool APPLY>
+__global__ void __launch_bounds__(1024) instnorm_small_fwd_kernel(const T* __restrict__ x, float* __restrict__ sums, const T* __restrict__ res,
+                                                                  T* __restrict__ y, int S, int C, int act, float slope, float p,
+                                                                  uint64_t seed, const uint64_t* step) {
+  __shared__ float lds[17 * 2 * VW];
+  const int b = blockIdx.y, c0 = blockIdx.x * VW, nthr = blockDim.x;
+  const long long eb = (long long)b * S * C + c0;         // element index of (b, voxel 0, c0)
+  uint4 xr[NIT], rr[NIT];
+  const uint4 sr = in_raw_load<T, VW>(x + eb);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (int)threadIdx.x + it * nthr;
+    xr[it] = r < S ? in_raw_load<T, VW>(x + eb + (long long)r * C) : sr;       // a row past the end contributes x - shift = 0
+    if constexpr (APPLY) rr[it] = (res != nullptr && r < S) ? in_raw_load<T, VW>(res + eb + (long long)r * C) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  float shift[VW], a[2 * VW];
+  in_raw_cvt<T, VW>(sr, shift);
+#pragma unroll
+  for (int k = 0; k < 2 * VW; ++k) a[k] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    float t[VW];
+    in_raw_cvt<T, VW>(xr[it], t);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { const float d = t[k] - shift[k]; a[2 * k] += d; a[2 * k + 1] += d * d; }
+  }
+  in_block_sums<2 * VW>(a, lds);
+  if (threadIdx.x < VW) {
+    float* sp = sums + ((long long)b * C + c0 + threadIdx.x) * 3;
+    sp[0] = shift[threadIdx.x]; sp[1] = a[2 * threadIdx.x]; sp[2] = a[2 * threadIdx.x + 1];
+  }
+  if constexpr (APPLY) {
+    const float invS = 1.f / (float)S;
+    const DropCfg dc = make_drop(p, seed, step);
+    float mean[VW], rstd[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const float m1 = a[2 * k] * invS;
+      const float var = fmaxf(a[2 * k + 1] * invS - m1 * m1, 0.f);
+      mean[k] = shift[k] + m1;
+      rstd[k] = rsqrtf(var + IN_EPS);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = (int)threadIdx.x + it * nthr;
+      if (r >= S) break;
+      const long long e = eb + (long long)r * C;
+      float t[VW], rs[VW], mk[VW], o[VW];
+      in_raw_cvt<T, VW>(xr[it], t);
+      in_raw_cvt<T, VW>(rr[it], rs);
+      dropmaskv<VW>(dc, e, mk);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        float h = (t[k] - mean[k]) * rstd[k];
+        if (act == LTU_ACT_LRELU) h = h > 0.f ? h : h * slope;
+        o[k] = h * mk[k] + rs[k];
+      }
+      stv<T, VW>(y + e, o);
+    }
+  }
+}
+
+template <typename T, int VW, int NIT>
+__global__ void __launch_bounds__(1024) instnorm_small_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dy3,
+                                                                  const T* __restrict__ x, const float* __restrict__ sums,
+                                                                  float* __restrict__ bsums, T* __restrict__ dx, int S, int C, int act,
+                                                                  float slope, float p, uint64_t seed, const uint64_t* step) {
+  __shared__ float lds[17 * 2 * VW];
+  const int b = blockIdx.y, c0 = blockIdx.x * VW, nthr = blockDim.x;
+  const long long eb = (long long)b * S * C + c0;
+  const float invS = 1.f / (float)S;
+  const DropCfg dc = make_drop(p, seed, step);
+  uint4 xr[NIT], g1[NIT], g2[NIT], g3[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (int)threadIdx.x + it * nthr;
+    const long long e = eb + (long long)(r < S ? r : 0) * C;
+    xr[it] = in_raw_load<T, VW>(x + e);
+    g1[it] = in_raw_load<T, VW>(dy + e);
+    if (dy2 != nullptr) g2[it] = in_raw_load<T, VW>(dy2 + e);
+    if (dy3 != nullptr) g3[it] = in_raw_load<T, VW>(dy3 + e);
+  }
+  float mean[VW], rstd[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) {
+    const InStat st = in_stat(sums + ((long long)b * C + c0 + k) * 3, invS);
+    mean[k] = st.mean; rstd[k] = st.rstd;
+  }
+  float gg[NIT][VW], a[2 * VW];
+#pragma unroll
+  for (int k = 0; k < 2 * VW; ++k) a[k] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (int)threadIdx.x + it * nthr;
+    float xv[VW], t[VW], mk[VW];
+    in_raw_cvt<T, VW>(xr[it], xv);
+    in_raw_cvt<T, VW>(g1[it], gg[it]);
+    if (dy2 != nullptr) {
+      in_raw_cvt<T, VW>(g2[it], t);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) gg[it][k] += t[k];
+    }
+    if (dy3 != nullptr) {
+      in_raw_cvt<T, VW>(g3[it], t);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) gg[it][k] += t[k];
+    }
+    dropmaskv<VW>(dc, eb + (long long)(r < S ? r : 0) * C, mk);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const float h = (xv[k] - mean[k]) * rstd[k];
+      float v = gg[it][k] * mk[k];
+      if (act == LTU_ACT_LRELU && h <= 0.f) v *= slope;
+      if (r >= S) v = 0.f;
+      gg[it][k] = v;
+      a[2 * k] += v;
+      a[2 * k + 1] += v * h;
+    }
+  }
+  in_block_sums<2 * VW>(a, lds);
+  if (threadIdx.x < 2 * VW) bsums[((long long)b * C + c0) * 2 + threadIdx.x] = a[threadIdx.x];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (int)threadIdx.x + it * nthr;
+    if (r >= S) break;
+    float xv[VW], o[VW];
+    in_raw_cvt<T, VW>(xr[it], xv);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const float h = (xv[k] - mean[k]) * rstd[k];
+      o[k] = rstd[k] * (gg[it][k] - a[2 * k] * invS - h * a[2 * k + 1] * invS);
+    }
+    stv<T, VW>(dx + eb + (long long)r * C, o);
+  }
+}
+
+// the fused small-tensor path applies when a sample is at most LTU_IN_SMALL_KB KB (default 256), S <= 4096 and the channels split into
+// 16-byte groups; returns the thread count (256 / 1024) and the trip count per thread, or 0
+static int in_small_plan(int dtype, long long S, int C, int* nit) {
+  const int vw = dtype == LTU_BF16 ? 8 : 4, esz = dtype == LTU_BF16 ? 2 : 4;
+  if (C % vw || S > 4096 || S < 1 || S * C * esz > (long long)ltu_knob_pos("LTU_IN_SMALL_KB", 256) * 1024 || ltu_knob("LTU_NO_IN_SMALL", 0)) return 0;
+  const int nthr = S <= 1024 ? 256 : 1024;
+  const int n = (int)((S + nthr - 1) / nthr);
+  *nit = n <= 1 ? 1 : n <= 2 ? 2 : 4;
+  return nthr;
+}
+#define IN_SMALL_DISPATCH(nit, ...)                       \
+  do {                                                    \
+    if ((nit) == 1) { constexpr int NIT = 1; __VA_ARGS__ } \
+    else if ((nit) == 2) { constexpr int NIT = 2; __VA_ARGS__ } \
+    else { constexpr int NIT = 4; __VA_ARGS__ }           \
+  } while (0)
+
 // ------------------------------------------------------------------------------------------------ host side
 static int stats_rows(long long S, int B, int* nchunks) {
   int chunks = -1;
@@ -756,9 +958,24 @@ static void launch_in_apply(const void* x, float* sums, const void* res, void* y
 
 extern "C" int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  {
+    int nit = 0;
+    const int nthr = in_small_plan(dtype, S, C, &nit);
+    if (nthr) {
+      LTU_DISPATCH_T(dtype, {
+        constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+        IN_SMALL_DISPATCH(nit, {
+          hipLaunchKernelGGL((instnorm_small_fwd_kernel<T, VW, NIT, false>), dim3(C / VW, B), dim3(nthr), 0, (hipStream_t)s, (const T*)x, sums,
+                             (const T*)nullptr, (T*)nullptr, (int)S, C, 0, 0.f, 0.f, (uint64_t)0, (const uint64_t*)nullptr);
+        });
+      });
+      return ltu_check_launch();
+    }
+  }
   int nchunks;
   const int rows = stats_rows(S, B, &nchunks);
   const int vw = in_vw(dtype, C);
+  (void)vw;
   LTU_DISPATCH_T(dtype, {
     if ((long long)nchunks * B * C * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
     IN_DISPATCH_VW(vw, { launch_in_stats<T, VW>(x, sums, ws, B, S, C, nchunks, rows, (hipStream_t)s); });
@@ -790,6 +1007,20 @@ extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* 
 extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const void* res, void* y, int B, long long S, int C, int act,
                                 float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  {
+    int nit = 0;
+    const int nthr = in_small_plan(dtype, S, C, &nit);
+    if (nthr) {
+      LTU_DISPATCH_T(dtype, {
+        constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+        IN_SMALL_DISPATCH(nit, {
+          hipLaunchKernelGGL((instnorm_small_fwd_kernel<T, VW, NIT, true>), dim3(C / VW, B), dim3(nthr), 0, (hipStream_t)s, (const T*)x, sums,
+                             (const T*)res, (T*)y, (int)S, C, act, slope, p, seed, step);
+        });
+      });
+      return ltu_check_launch();
+    }
+  }
   const int vw = in_vw(dtype, C);
   int nchunks = 0, rows = 0;
   if (!in_fold_plan(S, B, C, vw, ws, &nchunks, &rows)) {
@@ -812,6 +1043,20 @@ extern "C" int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3
                                 long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype,
                                 ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  {
+    int nit = 0;
+    const int nthr = in_small_plan(dtype, S, C, &nit);
+    if (nthr) {
+      LTU_DISPATCH_T(dtype, {
+        constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+        IN_SMALL_DISPATCH(nit, {
+          hipLaunchKernelGGL((instnorm_small_bwd_kernel<T, VW, NIT>), dim3(C / VW, B), dim3(nthr), 0, (hipStream_t)s, (const T*)dy, (const T*)dy2,
+                             (const T*)dy3, (const T*)x, sums, bsums, (T*)dx, (int)S, C, act, slope, p, seed, step);
+        });
+      });
+      return ltu_check_launch();
+    }
+  }
   const int vw = in_vw(dtype, C);
   int nchunks = 0, rows = 0;
   const bool fold = in_fold_plan(S, B, C, vw, ws, &nchunks, &rows);

@@ -344,7 +344,7 @@ def _instnorm_variants():
         exp = _lib.experiments()
     except Exception:
         exp = False
-    return ['two_stage'] + (['fold_in_apply', 'vw8'] if exp else [])
+    return ['two_stage', 'streaming'] + (['fold_in_apply', 'vw8'] if exp else [])
 
 
 @pytest.fixture(params=_instnorm_variants())
@@ -352,8 +352,10 @@ def instnorm_variant(request):
     """the InstanceNorm launch variants behind run-time knobs (ltu_config_set): the default, the apply kernels folding the
     statistics partials themselves (no fold launch), 16-byte bf16 vectors"""
     from lintransunet_amd import _lib
-    knob = {'two_stage': None, 'fold_in_apply': b'LTU_IN_FOLD', 'vw8': b'LTU_IN_VW8'}[request.param]
-    if knob and not _lib.experiments():
+    # 'two_stage': the default dispatch (samples of <= 1 MB take the one-launch kernels, the rest partial sums + fold + apply);
+    # 'streaming': the three-launch kernels at every size
+    knob = {'two_stage': None, 'streaming': b'LTU_NO_IN_SMALL', 'fold_in_apply': b'LTU_IN_FOLD', 'vw8': b'LTU_IN_VW8'}[request.param]
+    if knob in (b'LTU_IN_FOLD', b'LTU_IN_VW8') and not _lib.experiments():
         pytest.skip('rejected variant: compiled into an experiments build only (make EXPERIMENTS=1)')
     if knob:
         _lib.call('ltu_config_set', knob, 1, 0)
@@ -397,6 +399,47 @@ def test_instnorm_fwd_one_call(ops, instnorm_variant, dtype, B, S, C):
     gg = go.float() * torch.where(xh > 0, 1.0, 0.01)
     want = torch.stack((gg.sum(1), (gg * xh).sum(1)), -1)
     assert rel_err(bs, want) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,S,C', [(2, 8 * 8 * 64, 128), (2, 4 * 4 * 32, 256), (1, 3000, 16), (3, 77, 8), (2, 1025, 32)])
+def test_instnorm_small_against_streaming(ops, dtype, B, S, C):
+    """the one-launch InstanceNorm of small samples (a workgroup per (sample, 16-byte channel group), the tensor held in registers)
+    against the streaming three-launch kernels (LTU_NO_IN_SMALL): forward with residual and dropout (the same mask: the hash is
+    indexed by element), statistics-only call, backward with three gradient ports"""
+    from lintransunet_amd import _lib
+    g = G(43)
+    x = (torch.randn(B, S, C, generator=g) * 2 + 0.7).to(DEV).to(dtype)
+    res = torch.randn(B, S, C, generator=g).to(DEV).to(dtype)
+    gos = [torch.randn(B, S, C, generator=g).to(DEV).to(dtype) for _ in range(3)]
+    dt = 0 if dtype == torch.float32 else 1
+    ws = torch.empty(_lib.load().ltu_norm_ws_floats(), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    step = torch.tensor([5], dtype=torch.int64, device=DEV)
+
+    def run():
+        s0, s1 = torch.zeros(B, C, 3, device=DEV), torch.zeros(B, C, 3, device=DEV)
+        y = torch.empty_like(x)
+        _lib.call('ltu_instnorm_stats', x.data_ptr(), s0.data_ptr(), ws.data_ptr(), B, S, C, dt, st)
+        _lib.call('ltu_instnorm_fwd', x.data_ptr(), s1.data_ptr(), ws.data_ptr(), res.data_ptr(), y.data_ptr(), B, S, C, 1, 0.01, 0.3, 4242,
+                  step.data_ptr(), dt, st)
+        bs, dx = torch.zeros(B, C, 2, device=DEV), torch.empty_like(x)
+        _lib.call('ltu_instnorm_bwd', gos[0].data_ptr(), gos[1].data_ptr(), gos[2].data_ptr(), x.data_ptr(), s1.data_ptr(), bs.data_ptr(),
+                  ws.data_ptr(), dx.data_ptr(), B, S, C, 1, 0.01, 0.3, 4242, step.data_ptr(), dt, st)
+        bs1, dx1 = torch.zeros(B, C, 2, device=DEV), torch.empty_like(x)
+        _lib.call('ltu_instnorm_bwd', gos[0].data_ptr(), 0, 0, x.data_ptr(), s1.data_ptr(), bs1.data_ptr(), ws.data_ptr(), dx1.data_ptr(),
+                  B, S, C, 0, 0.0, 0.0, 0, 0, dt, st)
+        torch.cuda.synchronize()
+        return s0, s1, y.float(), bs, dx.float(), bs1, dx1.float()
+    a = _with_knob(b'LTU_IN_SMALL_KB', 1024, run)      # (the default limit is 256 KB per sample: the 1 024-thread variant is tested too)
+    b = _with_knob(b'LTU_NO_IN_SMALL', 1, run)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert torch.equal(a[0][..., 0], b[0][..., 0]) and torch.equal(a[0], a[1])
+    assert rel_err(a[0], b[0]) < 1e-5 and rel_err(a[1], b[1]) < 1e-5
+    assert torch.equal((a[2] - res.float()) == 0, (b[2] - res.float()) == 0)          # the same dropout mask
+    assert rel_err(a[2], b[2]) < tol
+    assert rel_err(a[3], b[3]) < 2e-4 and rel_err(a[5], b[5]) < 2e-4
+    assert rel_err(a[4], b[4]) < 2 * tol and rel_err(a[6], b[6]) < 2 * tol
 
 
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
