@@ -59,3 +59,37 @@ for graph, kind, bi in segs:
 main.wait_stream(side)
 torch.cuda.synchronize()
 print('host us per segment:', ' '.join('%s%.0f' % ('S' if s[1] == 'side' else 'J' if s[1] == 'join' else 'm', t[0]) for s, t in zip(segs, times)))
+
+
+# per-main-segment GPU time (events at the end of every main segment), with and without the side batches in between
+def run(with_side):
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True)]
+    evs[0].record(main)
+    for graph, kind, bi in segs:
+        if kind == 'join':
+            main.wait_stream(side)
+        elif graph is not None:
+            if kind == 'side':
+                if with_side:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        graph.replay()
+            else:
+                graph.replay()
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(main)
+                evs.append(e)
+    main.wait_stream(side)
+    torch.cuda.synchronize()
+    return [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(len(evs) - 1)]
+
+
+for _ in range(2):
+    a, b = run(True), run(False)
+a = [min(x) for x in zip(*[run(True) for _ in range(5)])]
+b = [min(x) for x in zip(*[run(False) for _ in range(5)])]
+print('main segments, us (with side batches | main chain alone | difference):')
+for i, (x, y) in enumerate(zip(a, b)):
+    print('  segment %2d: %7.0f | %7.0f | %+6.0f' % (i, x, y, x - y))
+print('  total      : %7.0f | %7.0f | %+6.0f' % (sum(a), sum(b), sum(a) - sum(b)))
