@@ -9,7 +9,7 @@ head = f"""`bench.py`: 128³ single-channel patches, 2 per GPU (BASELINE config 
 bwd, no optimizer step, inputs resident in HBM, step replayed from the captured graphs (round 4: linear segments on the compute stream +
 weight-gradient batches on a side stream, §4a); `value` = patches/s of the whole job.
 **{d['value']:.1f} patches/s on one MI355X in the committed profile (`profiles/r04_bench.json`: {d['ms_per_step']:.2f} ms per step, 20 timed
-replays after 5; the boxes of this round gave 12.55-13.1 ms for the same code, so every change was judged by interleaved runs on ONE
+replays after 5; the boxes of this round gave 12.4-12.9 ms for the same code, so every change was judged by interleaved runs on ONE
 box, `tools/ab_env.sh` / `tools/ab_libs.sh`), from 137.2 at the end of round 3, 124.3 in round 2 and 96.3 in round 1**; whole-step mixed
 roofline (SURVEY §8d: 2.39 ms per patch at 100 %) ⇒ `step_frac` = {d['roofline']['step_frac']:.3f}.  `cpu_baseline`: the oracle, fp32, dropout on,
 128³ B = 1, 16 host threads, 1 warm-up + 2 timed steps: {d['cpu_baseline']['value']:.3f} patches/s ({d['cpu_baseline']['sample'].split('(')[-1].rstrip(')')})."""
