@@ -94,8 +94,9 @@ int ltu_cast_f32(const float* in, void* out, long long n, int out_dtype, ltu_str
  * W[ks*16 + 8*(lane/32) + j][ct*32 + lane%32] (kind 9, KS = R/16: outputs = columns); R*C destination elements. */
 int ltu_weight_prep(const void* table, int n, int out_dtype, ltu_stream_t s);
 /* The same with the work dealt out in chunks of LTU_WPREP_CHUNK destination elements: chunks = nchunks device-resident
- * { int record; int first_element / LTU_WPREP_CHUNK } pairs, one workgroup each (a model has hundreds of records of very
- * different sizes).  Destination element counts per kind: 0/1/4: R*C; 2/3: p0*27*p1; 5/6: 64*p0*p1; 7: cnt*27*p1. */
+ * { int record; int first_element / LTU_WPREP_CHUNK } pairs (a model has hundreds of records of very different sizes); the grid
+ * walks the list, one chunk per workgroup and trip (four for lists of >= 6 000 chunks), at most LTU_WPREP_BLOCKS workgroups wide
+ * when that knob is set.  Destination element counts per kind: 0/1/4: R*C; 2/3: p0*27*p1; 5/6: 64*p0*p1; 7: cnt*27*p1. */
 #define LTU_WPREP_CHUNK 4096
 int ltu_weight_prep_chunks(const void* table, const int* chunks, int nchunks, int out_dtype, ltu_stream_t s);
 
