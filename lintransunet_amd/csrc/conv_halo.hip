@@ -745,6 +745,10 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
     const int hr = launch_conv_fc_ring_bf16(a, st);
     if (hr != 1) return hr;
   }
+  if (a.C == 16 && a.N <= 32 && !ltu_knob("LTU_NO_C16_RING", 0)) {      // second generation at 16 channels (conv_c16_ring.hip)
+    const int hr = launch_conv_c16_ring_bf16(a, st);
+    if (hr != 1) return hr;
+  }
   if (a.N <= 32 && a.C <= 32 && !ltu_knob("LTU_NO_HALO_WS", 0)) {      // few channels: weights stationary, persistent over bricks
     int wsb = -1;
     wsb = ltu_knob_pos("LTU_HALO_WS_BLOCKS", 512);

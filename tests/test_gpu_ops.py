@@ -151,6 +151,10 @@ def test_linear_bf16(ops, M, K, N, nw):
     (2, 64, 72, 9, 32, 40, (1, 1, 1), 64, False, None),  # ... 64 + 64 concat -> 72
     (1, 64, 64, 32, 60, 68, (1, 1, 1), 0, False, None),  # ... eight-wave variant: 8x8x8 bricks (288 of them, ragged in w and d)
     (1, 32, 40, 16, 62, 70, (1, 1, 1), 32, False, None), # ... the same with a 32 + 32 concat and 40 outputs (run at any grid size by the knob below)
+    (1, 8, 16, 20, 33, 41, (1, 1, 1), 8, False, None),   # conv_c16_ring.hip: 8 + 8 concat -> 16 on 150 ragged bricks, data gradient into two tensors
+    (2, 16, 24, 18, 33, 44, (1, 1, 1), 0, False, None),  # ... 16 -> 24, more bricks than workgroups per CU pair
+    (1, 16, 8, 21, 34, 37, (1, 1, 1), 0, False, None),   # ... 16 -> 8 (a head)
+    (1, 16, 16, 21, 34, 37, (1, 1, 1), 16, False, None), # ... data gradient 16 -> 16 + 16 (the forward is conv_fc_ring.hip's)
 ])
 def test_conv3d_bf16(ops, case):
     B, Ci, Co, H, W, D, stride, C1, ups, cop = case
