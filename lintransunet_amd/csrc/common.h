@@ -192,6 +192,23 @@ __device__ __forceinline__ float gelu_cdf(float x, float& e) {
   const float half_erfc = 0.5f * poly * e;
   return x >= 0.f ? 1.f - half_erfc : half_erfc;
 }
+// two elements at a time: the multiplies and fmas become v_pk_mul_f32 / v_pk_fma_f32 (full rate on gfx950: half the issue slots of
+// the scalar form; v_rcp / v_exp stay per element).  Same operations in the same order as gelu_cdf: bit-identical results.
+typedef float ltu_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ltu_f2 gelu_cdf2(ltu_f2 x, ltu_f2& e) {
+  const ltu_f2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const ltu_f2 a = 0.3275911f * z + 1.f;
+  ltu_f2 t;
+  t.x = __builtin_amdgcn_rcpf(a.x); t.y = __builtin_amdgcn_rcpf(a.y);
+  const ltu_f2 mz = -z * z;
+  e.x = __expf(mz.x); e.y = __expf(mz.y);
+  const ltu_f2 poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const ltu_f2 half_erfc = 0.5f * poly * e;
+  ltu_f2 r;
+  r.x = x.x >= 0.f ? 1.f - half_erfc.x : half_erfc.x;
+  r.y = x.y >= 0.f ? 1.f - half_erfc.y : half_erfc.y;
+  return r;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
   float e;
   return x * gelu_cdf(x, e);

@@ -373,11 +373,14 @@ __global__ void __launch_bounds__(D >= 256 ? 512 : 256, OCC) tail_fwd_kernel(con
         const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
         float hh[8], gg[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float e;
-          const float cdf = gelu_cdf(uu[k], e);
-          hh[k] = uu[k] * cdf * mm[k];
-          gg[k] = (cdf + uu[k] * 0.39894228040143267794f * e) * mm[k];
+        for (int k = 0; k < 8; k += 2) {                // pairs: packed fp32 multiplies / fmas (gelu_cdf2)
+          const ltu_f2 x2 = {uu[k], uu[k + 1]}, m2 = {mm[k], mm[k + 1]};
+          ltu_f2 e2;
+          const ltu_f2 cdf = gelu_cdf2(x2, e2);
+          const ltu_f2 h2 = x2 * cdf * m2;
+          const ltu_f2 g2v = (cdf + x2 * 0.39894228040143267794f * e2) * m2;
+          hh[k] = h2.x; hh[k + 1] = h2.y;
+          gg[k] = g2v.x; gg[k + 1] = g2v.y;
         }
         h0 = make_float4(hh[0], hh[1], hh[2], hh[3]); h1 = make_float4(hh[4], hh[5], hh[6], hh[7]);
         if (ta.u_mode) {
