@@ -535,6 +535,46 @@ def fx_heldout_full():
     print(f'heldout_full.npz: {os.path.getsize(os.path.join(HERE, "heldout_full.npz")) / 1e6:.1f} MB')
 
 
+def fx_heldout_full128():
+    """The same trained checkpoint at the BENCHMARKED patch size (round-4 verdict, weak #2): the network is fully convolutional and
+    the ROI grids are fixed-size, so the 64x64x32-trained full-configuration checkpoint of tests/golden/heldout_full.npz (no new
+    training; the deltas are read from that fixture) runs at 128^3.  The REFERENCE loads it strict=True and runs a train-mode forward on
+    one held-out 128^3 patch (~20 s on the CPU); the oracle is asserted equal.  The fixture holds only the reference's outputs:
+    Dice, 16 384 sampled probabilities, the ROI boxes - the weights stay in heldout_full.npz."""
+    Z = np.load(os.path.join(HERE, 'heldout_full.npz'))
+    sd = heldout_full_state(Z)
+    cfg = O_net.NetConfig()
+    Model = get_model_dict('MaskTransUnet')
+    model = Model(num_layers=cfg.num_layers, roi_size_list=cfg.roi_size_list, is_roi_list=cfg.is_roi_list,
+                  dim_input=1, dim_output=2, kernel_size=3)
+    model.load_state_dict(sd, strict=True)
+    kill_dropout(model)
+    model.train()
+    boxes = []
+    for m in model.modules():
+        if isinstance(m, R_ub.ROIBridge):
+            orig = m.get_mask_boundary2
+            m.get_mask_boundary2 = (lambda o: (lambda mask: (boxes.append(o(mask)), boxes[-1])[1]))(orig)
+    seed, size = 999005, (128, 128, 128)
+    x, lab = heldout_batch(1, seed, size)
+    with torch.no_grad():
+        predict, masks = model(x)
+    dice = R_loss.DiceClassLoss()(predict, lab.long())
+    o_boxes = []
+    with torch.no_grad():
+        o_pred, _ = O_net.forward(sd, cfg, x, True, o_boxes)
+    close(o_pred, predict, 'heldout_full128.out')
+    flat = predict.flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 16384).long()
+    out = {'seed': np.int64(seed), 'size': np.array(size), 'dice': np.float64(dice.item()), 'out_idx': idx.numpy(),
+           'out_sample': np32(flat[idx]), 'fg_fraction': np.float64(lab.float().mean().item())}
+    for i, b in enumerate(boxes):
+        out[f'box{i}'] = np32(b)
+    np.savez_compressed(os.path.join(HERE, 'heldout_full128.npz'), **out)
+    print(f'heldout_full128.npz: patch Dice loss {dice.item():.6f} (foreground Dice {1 - dice.item():.4f}), foreground fraction '
+          f'{lab.float().mean().item():.4f}, boxes {[b.tolist() for b in boxes]}')
+
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
@@ -562,6 +602,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'heldout_full':  # needs gpurun_out/heldout_full_delta.npz (tools/train_heldout.py full)
         fx_heldout_full()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'heldout_full128':  # the same checkpoint at the benchmarked 128^3 (reads heldout_full.npz)
+        fx_heldout_full128()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'infer512':     # only the config-5 window fixture (~1 min)
         fx_infer512()

@@ -154,3 +154,57 @@ def test_heldout_full_patch_dice(golden_dir, dtype, tag, seed):
         assert err <= 1e-3
     else:
         assert l2 <= 3e-2
+
+
+# --------------------------------------------------------------------------- the same checkpoint at the BENCHMARKED size, 128^3
+# tests/golden/heldout_full128.npz (make_golden.py heldout_full128): the REFERENCE ran the trained full-configuration checkpoint of
+# heldout_full.npz on one held-out 128^3 patch (foreground Dice 0.978).  The gate of north_star at the size bench.py times, with
+# decisive (trained) masks instead of the random-weight goldens whose Dice is nearly degenerate.
+
+def test_oracle_on_trained_full_checkpoint_128(golden_dir):
+    """CPU: the oracle reproduces the reference's 128^3 held-out Dice, sampled probabilities and boxes"""
+    from oracle import losses as O_loss
+    G = np.load(os.path.join(golden_dir, 'heldout_full128.npz'))
+    W = np.load(os.path.join(golden_dir, 'heldout_full.npz'))
+    cfg = O_net.NetConfig()
+    x, lab = heldout_batch(1, int(G['seed']), tuple(int(v) for v in G['size']))
+    boxes = []
+    with torch.no_grad():
+        pred, _ = O_net.forward(_full_weights(W), cfg, x, True, boxes)
+    assert abs(O_loss.dice_class(pred, lab.long()).item() - float(G['dice'])) <= 1e-6
+    got = pred.flatten()[torch.from_numpy(G['out_idx'])]
+    assert (got - torch.from_numpy(G['out_sample'])).abs().max().item() <= 1e-5
+    for i, b in enumerate(boxes):
+        assert torch.equal(b, torch.from_numpy(G[f'box{i}'])), i
+    assert float(G['dice']) < 0.05          # foreground Dice > 0.95 at the benchmarked size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_heldout_full_patch_dice_128(golden_dir, dtype):
+    """|dDice| <= 1e-4 against the reference at 128^3 in fp32 AND in the benchmarked bf16 storage, ROI boxes bit-equal in both"""
+    from lintransunet_amd import losses as L
+    from lintransunet_amd.model import get_model_dict
+    G = np.load(os.path.join(golden_dir, 'heldout_full128.npz'))
+    W = np.load(os.path.join(golden_dir, 'heldout_full.npz'))
+    cfg = O_net.NetConfig()
+    model = get_model_dict('MaskTransUnet')(cfg.num_layers, cfg.roi_size_list, cfg.is_roi_list, 1, 2, dropout=0.0, act_dtype=dtype)
+    model.load_state_dict(_full_weights(W), strict=True)
+    model = model.to(DEV).train()
+    x, lab = heldout_batch(1, int(G['seed']), tuple(int(v) for v in G['size']))
+    with torch.no_grad():
+        predict, masks = model(x.to(DEV))
+    dice = L.DiceClassLoss()(predict.detach(), lab.to(DEV)).item()
+    flat = predict.detach().cpu().flatten()[torch.from_numpy(G['out_idx'])].double()
+    ref = torch.from_numpy(G['out_sample']).double()
+    err = (flat - ref).abs().max().item() / ref.abs().max().item()
+    l2 = ((flat - ref).norm() / ref.norm()).item()
+    print(f'[heldout full 128^3 {dtype}] Dice loss {dice:.6f} vs reference {float(G["dice"]):.6f} (d {dice - float(G["dice"]):+.2e}); '
+          f'sampled max-rel err {err:.2e}, rel-L2 {l2:.2e}')
+    for i, b in enumerate(model.last_boxes):
+        assert torch.equal(b.cpu(), torch.from_numpy(G[f'box{i}'])), f'box{i}'
+    assert abs(dice - float(G['dice'])) <= 1e-4
+    if dtype == torch.float32:
+        assert err <= 1e-3
+    else:
+        assert l2 <= 3e-2
