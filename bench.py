@@ -344,7 +344,7 @@ def main():
                   _p(q['qkv_next']) if nxt else 0, 1, _s())
         _lib.call('ltu_layer_tail_bwd', _p(q['dy']), _p(q['dy2']), _p(z2), _p(z1), _p(u), _p(q['stat'][1]), _p(q['stat'][0]), _p(q['gamma']),
                   _p(q['gamma']), _p(q['wt'][0]), _p(q['wt'][1]), _p(q['wt'][2]), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(q['lnws'][0]),
-                  _p(q['lnws'][1]), M, d, 0.3, 11, 12, 13, 0, 1, 1, _s())
+                  _p(q['lnws'][1]), q['lnws'][0].numel(), M, d, 0.3, 11, 12, 13, 0, 1, 1, _s())
 
     def eager_step(i):
         reducer.zero_grad()
@@ -467,8 +467,9 @@ def main():
         # every bucket but the last finishes under the remaining compute; ~0.3 ms of segment / launch overhead + the tail bucket's latency
         diag['expected'] = 'exposed <= ~0.4 ms at 8 ranks (32 MB buckets + 0.5 MB tail): >= 7.7x weak scaling'
     if ft is not None and ft.calls and launch == 'hip-graph replay':
-        with graphed.capture_knobs():              # the recorded calls' workspaces were sized under the capture's launch-geometry knobs
-            families = ft.table(ft.measure(), args.size, args.batch)      # replays kernels on stale buffers: after the timed region
+        # replays the recorded C-ABI calls (widths and workspace capacities are among their arguments) on stale buffers: after the
+        # timed region
+        families = ft.table(ft.measure(), args.size, args.batch)
         reducer.zero_grad()                                            # ... and the weight-gradient kernels among them accumulate
         torch.cuda.synchronize()
 

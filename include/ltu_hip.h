@@ -24,6 +24,12 @@
  *     are independent of each other.  tests/test_gpu_ops.py::test_dropout_group_pattern_histogram holds the joint 16-pattern
  *     histogram of a group against Bernoulli^4.  p = 0 disables.  `step` (nullable) is a
  *     device-resident counter mixed into the seed at run time, so a captured HIP graph draws fresh masks per replay.
+ *   - Workspaces: every entry point that takes a caller-owned workspace / scratch buffer also takes its CAPACITY (the argument
+ *     right behind the pointer, in floats unless it says elements) and returns LTU_E_ARG WITHOUT launching anything when the
+ *     geometry it is about to launch needs more.  The *_ws_floats() queries tell what a call needs; launch geometry may depend on
+ *     tuning knobs (ltu_config_set / environment), so a query and a launch made under different knob values can disagree - the
+ *     capacity check turns that into an error code instead of a write past the end.  The two entry points whose width the caller
+ *     chooses per launch (ltu_linear_wgrad_group, ltu_upconv_wgrad) take that width as an argument of both the query and the launch.
  *   - Return value: 0 = LTU_OK, negative = LTU_E_* argument error, positive = hipError_t.
  */
 #ifndef LTU_HIP_H
@@ -144,7 +150,8 @@ int ltu_layer_tail_fwd(const void* a, const void* x, const void* wo, const void*
 long long ltu_layer_tail_blocks(long long M);
 int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z2, const void* z1, const void* u, const float* stat2,
                        const float* stat1, const float* g2, const float* g1, const void* w2t, const void* w1t, const void* wot,
-                       void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1, long long M, int d, float p,
+                       void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1, long long lnws_floats /* each */,
+                       long long M, int d, float p,
                        uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step, int u_mode, int dtype, ltu_stream_t s);
 
 /* ---- deferred second stage of the two-stage reductions ------------------------------------------
@@ -166,14 +173,18 @@ int ltu_reduce_batch(const ltu_reduce_job* jobs, int njobs, ltu_stream_t s);   /
  * summed by a second kernel (no atomics, one launch for all nw blocks); without it fp32 atomics are used. */
 long long ltu_wgrad_ws_floats(long long M, int N, int K);
 int ltu_linear_wgrad(const void* g, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw, int M, int N,
-                     int K, float* ws, ltu_reduce_job* defer, int dtype, ltu_stream_t s);
+                     int K, float* ws, long long ws_floats, ltu_reduce_job* defer, int dtype, ltu_stream_t s);
 /* Several of the above in ONE launch + ONE fold: the weight / bias gradients of the four projections of a transformer layer
  * (model/trans_block.py:144,156,166,187,189: q,k,v as one job with nw = 3, out, linear1, linear2).  Together they offer 8-32
  * output tiles, so a few row splits per tile fill the chip and the fp32 partial tiles shrink 4x against four separate calls.
  * The host side may also hand in the jobs of SEVERAL layers of one transformer at once (small levels, where a layer's group is
  * launch-latency-bound): all jobs of a group share one split count, so they should have the same M.
- * jobs: host array (<= LTU_WGRAD_GROUP_MAX); ws: ltu_linear_wgrad_group_ws_floats() floats (0 = this group is not handled:
- * use ltu_linear_wgrad per job; bf16 storage, N and K multiples of 128, M a multiple of 32 and >= 1024). */
+ * jobs: host array (<= LTU_WGRAD_GROUP_MAX); blocks: the workgroup budget of the launch (<= 0: the library default, 256 = one per
+ * CU; train.GraphedStep passes 128 for launches that run on its side stream beside the main chain).  The geometry (tile types,
+ * per-job split counts, workspace layout) is a function of the jobs' shapes and `blocks` only; the size query and the launch take
+ * the same `blocks`, and the launch is told the capacity of ws (ws_floats) and returns LTU_E_ARG without launching when its
+ * geometry needs more.  ltu_linear_wgrad_group_ws_floats() == 0: this group is not handled - use ltu_linear_wgrad per job (handled:
+ * bf16 storage, N and K multiples of 128, M a multiple of 32 and >= 1024). */
 #define LTU_WGRAD_GROUP_MAX 32
 typedef struct ltu_wgrad_job {
   const void* grad;    /* g [M][ldg] */
@@ -182,12 +193,12 @@ typedef struct ltu_wgrad_job {
   float* db[3];        /* nw bias-gradient blocks (nullable) */
   int ldg, lda, nw, M, N, K;
 } ltu_wgrad_job;
-long long ltu_linear_wgrad_group_ws_floats(const ltu_wgrad_job* jobs, int njobs);
-int ltu_linear_wgrad_group(const ltu_wgrad_job* jobs, int njobs, float* ws, int dtype, ltu_stream_t s);
+long long ltu_linear_wgrad_group_ws_floats(const ltu_wgrad_job* jobs, int njobs, int blocks);
+int ltu_linear_wgrad_group(const ltu_wgrad_job* jobs, int njobs, int blocks, float* ws, long long ws_floats, int dtype, ltu_stream_t s);
 
 /* Workspace (floats) that ltu_upconv_wgrad needs for M = B*H*W*D coarse voxels (bf16 path; sub-pixel un-embedding of
- * model/Unet_3Dblock.py:419-432). */
-long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci);
+ * model/Unet_3Dblock.py:419-432) at a workgroup budget of `blocks` (<= 0: the library default; the launch takes the same value). */
+long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci, int blocks);
 
 /* ---- 3x3x3 convolution, padding 1: model/Unet_3Dblock.py:310,314,375,421,523,528,588,1328,1353 --
  * x0 [B,Hi,Wi,Di,C0] (+ optional x1 [..,C1]: the channel concat of Unet_3Dblock.py:553 without
@@ -195,7 +206,8 @@ long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci);
  * nearest-neighbour x2 upsampling of x0 (nn.Upsample of Unet_3Dblock.py:421), (Hi,Wi,Di) are then
  * the physical dims.  y [B,Ho,Wo,Do,Co]. */
 int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* bias, void* y, int B, int Hi, int Wi,
-                   int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, float* ws, int dtype, ltu_stream_t s);
+                   int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, float* ws, long long ws_floats, int dtype,
+                   ltu_stream_t s);
 /* ws of ltu_conv3d_fwd / ltu_conv3d_dgrad (optional, bf16 stride-1 convs only): floats of workspace that let a conv over a
  * small grid (the deep U-Net levels) split its input channels over several workgroups per tile; 0 when the shape does not
  * split.  (B,H,W,D) = the conv's output grid, C = input channels of the call (Co for the data gradient), Co = its outputs. */
@@ -208,54 +220,59 @@ long long ltu_igemm_ws_floats(long long M, int N, int K);
  * Data gradient of the pair: g0 [..,N0] and g1 [..,N1] read as one virtual concat against wd [C][27][N0+N1] -> dx [..,C]
  * (no separate add of two input gradients).  ws as for ltu_conv3d_fwd with Co = N0+N1 (C = N0+N1, Co = C for the gradient). */
 int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* bias, void* y0, void* y1, int B, int H, int W, int D, int C,
-                        int N0, int N1, float* ws, int dtype, ltu_stream_t s);
+                        int N0, int N1, float* ws, long long ws_floats, int dtype, ltu_stream_t s);
 int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void* wd, void* dx, int B, int H, int W, int D, int C, int N0,
-                          int N1, float* ws, int dtype, ltu_stream_t s);
+                          int N1, float* ws, long long ws_floats, int dtype, ltu_stream_t s);
 /* weight gradients of the pair (+=) straight into the two PyTorch-layout gradients dwa [co_a][ci][3][3][3], dwb [co_b][ci][3][3][3]
  * and dba / dbb; ws: ltu_wgrad_ws_floats(B*H*W*D, N0+N1, 27*C) floats (one pass over x for both) or NULL. */
 int ltu_conv3d_pair_wgrad(const void* g0, const void* g1, const void* x, float* dwa, float* dba, float* dwb, float* dbb, int B,
-                          int H, int W, int D, int C, int N0, int N1, int co_a, int co_b, int ci, float* ws, int dtype,
-                          ltu_stream_t s);
+                          int H, int W, int D, int C, int N0, int N1, int co_a, int co_b, int ci, float* ws, long long ws_floats,
+                          int dtype, ltu_stream_t s);
 /* data gradient: g [B,Ho,Wo,Do,Co], wd [C0+C1][27][Co] -> dx0 [B,Hl,Wl,Dl,C0] (+ dx1 [..,C1]); (Hl,Wl,Dl)
  * are the LOGICAL input dims (= 2x physical when the forward used ups: pool with ltu_sumpool2). */
 int ltu_conv3d_dgrad(const void* g, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl, int C0,
-                     int C1, int Co, int sh, int sw, int sd, float* ws, int dtype, ltu_stream_t s);
+                     int C1, int Co, int sh, int sw, int sd, float* ws, long long ws_floats, int dtype, ltu_stream_t s);
 /* weight gradient (+=, the caller zero-fills): torch_co == 0: into the packed layout dwf [Co][27][C0+C1];
  * torch_co != 0: straight into a PyTorch-layout gradient [torch_co][torch_ci][3][3][3] (padded rows/channels dropped).
  * db[Co] += column sums of g.
  * ws: optional workspace of ltu_wgrad_ws_floats(B*Ho*Wo*Do, Co, 27*(C0+C1)) floats (two-stage reduction, see above). */
 int ltu_conv3d_wgrad(const void* g, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi, int Wi,
                      int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co, int torch_ci, float* ws,
-                     int dtype, ltu_stream_t s);
+                     long long ws_floats, int dtype, ltu_stream_t s);
 /* ---- nearest x2 upsampling + 3x3x3 conv as a sub-pixel conv: model/Unet_3Dblock.py:419-432 (UpEmbedBlock) ------------
  * Same result as ltu_conv3d_* with ups = 1 at 64/216 of the multiply-adds: the 8 output parity classes are 2x2x2-tap
  * convs on the low-res grid with pre-summed weights (ltu_weight_prep kinds 5 / 6).  x [B,H,W,D,Ci] -> y [B,2H,2W,2D,Co]. */
 int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bias, void* y, int B, int H, int W, int D, int Ci, int Co,
                    int dtype, ltu_stream_t s);
-int ltu_upconv_dgrad(const void* g, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co, float* ws, int dtype,
-                     ltu_stream_t s);
+int ltu_upconv_dgrad(const void* g, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co, float* ws,
+                     long long ws_floats, int dtype, ltu_stream_t s);
 /* dweff: zero-filled scratch [8][Co][8][Ci] fp32; dw_torch [co_real][ci_real][3][3][3] += and db[Co] += ;
- * ws: optional ltu_wgrad_ws_floats(B*H*W*D, Co, 8*Ci) floats (bf16 two-stage reduction) */
+ * ws: optional ltu_upconv_wgrad_ws_floats(B*H*W*D, Co, Ci, blocks) floats (bf16 two-stage reduction); blocks: workgroup budget of the
+ * launch (<= 0: the library default), the value the size query was given */
 int ltu_upconv_wgrad(const void* g, const void* x, float* dweff, float* db, float* dw_torch, int co_real, int ci_real, float* ws,
-                     int B, int H, int W, int D, int Ci, int Co, int dtype, ltu_stream_t s);
+                     long long ws_floats, int blocks, int B, int H, int W, int D, int Ci, int Co, int dtype, ltu_stream_t s);
 /* y[b,h,w,d,c] = sum of the 2x2x2 children of x [B,2H,2W,2D,C] (adjoint of nearest x2 upsampling) */
 int ltu_sumpool2(const void* x, void* y, int B, int H, int W, int D, int C, int dtype, ltu_stream_t s);
 
 /* ---- linear attention core: model/trans_block.py:41-67 -----------------------------------------
  * qkv [B*N][3d] (q | k | v; head h = columns h*32..h*32+31 of each third) -> out [B*N][d].
  * Saved for backward: ctx [B*H][32][32], colstats [B*H][64] (column max | column sum of exp),
- * qstat [B*N][H][2] (row max, 1/(rowsum*sqrt(32))).  part_ws: B * (ns + ns/16 + 2) * H * 1088 floats,
- * ns = ltu_linattn_splits(B,N), an upper bound of the split count over d (the backward needs B * ns * H * 1024). */
+ * qstat [B*N][H][2] (row max, 1/(rowsum*sqrt(32))).  part_ws: ltu_linattn_ws_floats(B, N, d) floats (= B * (ns + ns/16 + 2) * H * 1088
+ * for the split count ns the launches pick; the backward needs B * ns * H * 1024 of them); ltu_linattn_splits(B, N) is an upper
+ * bound of ns over d. */
 int ltu_linattn_splits(int B, int N);
-int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws, int B, int N,
-                    int d, int dtype, ltu_stream_t s);
+long long ltu_linattn_ws_floats(int B, int N, int d);
+int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws, long long ws_floats, int B,
+                    int N, int d, int dtype, ltu_stream_t s);
 /* phase A of ltu_linattn_fwd alone: ctx [B*H][32][32] and colstats [B*H][64] (same workspace); phase B then runs inside
  * ltu_layer_tail_fwd (its qkv / ctx / qstat arguments) */
-int ltu_linattn_ctx(const void* qkv, float* ctx, float* colstats, float* part_ws, int B, int N, int d, int dtype, ltu_stream_t s);
+int ltu_linattn_ctx(const void* qkv, float* ctx, float* colstats, float* part_ws, long long ws_floats, int B, int N, int d, int dtype,
+                    ltu_stream_t s);
 /* dqkv [B*N][3d] from dout [B*N][d]; dctx [B*H][32][32] is a scratch output; tvec [B*H][32] is reserved (may be NULL: the term it
  * held is formed inside the per-token kernel since round 2) */
 int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const float* colstats, const float* qstat,
-                    void* dqkv, float* dctx, float* tvec, float* part_ws, int B, int N, int d, int dtype, ltu_stream_t s);
+                    void* dqkv, float* dctx, float* tvec, float* part_ws, long long ws_floats, int B, int N, int d, int dtype,
+                    ltu_stream_t s);
 
 /* ---- InstanceNorm3d (+LeakyReLU, residual, dropout): model/Unet_3Dblock.py:312-339,526-556,593 ----
  * x [B][S][C].  sums [B][C][3] = {shift, sum(x-shift), sum((x-shift)^2)} (zero-filled by the caller).
@@ -263,19 +280,19 @@ int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const f
 /* `ws` (nullable) is a scratch buffer of at least ltu_norm_ws_floats() floats: with it the per-block partial sums are folded by a
  * second small kernel instead of fp32 atomics (same results up to summation order).  One buffer can serve every call on a stream. */
 long long ltu_norm_ws_floats(void);
-int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s);
+int ltu_instnorm_stats(const void* x, float* sums, float* ws, long long ws_floats, int B, long long S, int C, int dtype, ltu_stream_t s);
 int ltu_instnorm_apply(const void* x, const float* sums, const void* res, void* y, int B, long long S, int C, int act,
                        float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* stats + apply in ONE call (what the model's forward uses): when the shape qualifies (bf16 or fp32, C a power of two, a few KB
  * of partial sums per sample) the statistics kernel leaves its per-chunk partials in `ws` and every workgroup of the apply kernel
  * folds them itself - no fold launch in between; workgroup 0 of each sample publishes sums[b][c][1..2] for the backward pass.
  * Otherwise exactly ltu_instnorm_stats followed by ltu_instnorm_apply. */
-int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const void* res, void* y, int B, long long S, int C, int act, float slope,
-                     float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+int ltu_instnorm_fwd(const void* x, float* sums, float* ws, long long ws_floats, const void* res, void* y, int B, long long S, int C, int act,
+                     float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dx from dy (+ dy2 + dy3, nullable: the gradients of further consumers of y, summed on load instead of by a stand-alone add pass:
  * the skip tensors of the U-Net and the transformer inputs have two or three consumers); bsums [B][C][2] zero-filled scratch */
 int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3, const void* x, const float* sums, float* bsums, float* ws,
-                     void* dx, int B, long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step,
+                     long long ws_floats, void* dx, int B, long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step,
                      int dtype, ltu_stream_t s);
 
 /* ---- residual LayerNorm: model/trans_block.py:205-206,209-210 -----------------------------------
@@ -285,9 +302,11 @@ int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, const float* b
                       int d, float eps, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 /* dz (gradient of x) and dr = dz*dropmask (dr may alias dz when p = 0); dgamma/dbeta += (zero-filled) */
 /* dy2 (nullable): a second upstream gradient, summed with dy on load (the layer output feeds both the next projection and the next
- * residual; folding the sum here saves autograd's separate add pass) */
+ * residual; folding the sum here saves autograd's separate add pass);
+ * ws (nullable: atomics): at least 2 * d * ceil(M / rows) floats of partial (gamma, beta) rows with rows >= ceil(M / 1024), i.e. 2048 * d
+ * floats always suffice (ltu_norm_ws_floats() too) */
 int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                      float* dgamma, float* dbeta, float* ws, ltu_reduce_job* defer, long long M, int d, float p, uint64_t seed,
+                      float* dgamma, float* dbeta, float* ws, long long ws_floats, ltu_reduce_job* defer, long long M, int d, float p, uint64_t seed,
                       const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- GELU(erf) + dropout: model/trans_block.py:208 ---------------------------------------------- */
@@ -315,7 +334,7 @@ int ltu_gate_fwd(const void* u1, const void* u2, const float* sums1, const float
 /* -> dskip (direct path), du1, du2, dpsi_w[C] +=, dpsi_b[1] +=; ds_ws f32 [B*S], bs1/bs2 [B][C][2] zero-filled scratch */
 int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* sums1, const float* sums2,
                  const float* psi_w, const void* skip, const float* a_in, void* dskip, float* ds_ws, float* dpsi_w,
-                 float* dpsi_b, float* bs1, float* bs2, float* ws, void* du1, void* du2, int B, long long S, int C,
+                 float* dpsi_b, float* bs1, float* bs2, float* ws, long long ws_floats, void* du1, void* du2, int B, long long S, int C,
                  int dtype, ltu_stream_t s);   /* ws: ltu_norm_ws_floats() floats (two-stage reduction) or NULL (atomics) */
 
 /* ---- positional depthwise conv: model/trans_block.py:86-96 on the grid of Unet_3Dblock.py:267-270 ----
@@ -328,8 +347,8 @@ int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, in
  * back to float atomics (the two gradients then differ in the last bits from run to run).  dx NULL: only dw / db are computed;
  * dw NULL: only dx (the two halves are independent launches: the weight gradient can be issued later, off the data-gradient chain). */
 long long ltu_dwconv_bwd_ws_floats(int B, int H, int W, int D, int C, int dtype);
-int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dw, float* db, float* ws, int B,
-                   int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
+int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dw, float* db, float* ws,
+                   long long ws_floats, int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s);
 
 /* ---- dynamic ROI: model/Unet_3Dblock.py:821-873, 37-49 (box), 51-82 (index maps), 985-1117 (warps) ----
  * prob f32 [B,H,W,D,C]: foreground = (1 - prob[...,0]) >= thr.  Writes box [B][6] = (x0,y0,0,x1,y1,D-1)
@@ -352,8 +371,8 @@ int ltu_trilinear_up(const void* in, const void* in2, void* out, int adjoint, in
 /* The adjoint in separable form (one 1-D transposed interpolation per upsampled axis: at most 5 candidates per output instead of
  * ~64 gathers).  ws: ltu_trilinear_adjoint_ws_elems(...) elements of the storage type; intermediates are rounded to it. */
 long long ltu_trilinear_adjoint_ws_elems(int B, int H, int W, int D, int C, int sd);
-int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, int B, int H, int W, int D, int C, int sd, int dtype,
-                          ltu_stream_t s);
+int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, long long ws_elems, int B, int H, int W, int D, int C, int sd,
+                          int dtype, ltu_stream_t s);
 
 /* ---- deep-supervision losses of one level: loss/criterions.py:35-70,416-442,696-735;
  *      loss/multi_criterions.py:58-110,594-615 ------------------------------------------------------
@@ -366,7 +385,7 @@ int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, i
  * weights, read at run time (the per-epoch level weight of train3D.py:122-137 divided by the accumulation count of
  * utils/utils_3D_embed_full.py:85, so a captured graph follows both without re-capture). */
 long long ltu_loss_ws_floats(int B, long long S, int C);
-int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
+int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, long long sums_floats, float* values, float* coef, int B, long long S, int C,
                  float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s);
 int ltu_loss_bwd(const float* p, const uint8_t* label, const float* coef, const float* gscale, float* dp, int B,
                  long long S, int C, ltu_stream_t s);

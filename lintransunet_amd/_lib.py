@@ -8,7 +8,8 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libltu_hip.so')
+# LTU_LIB: another in-tree build of the same sources (e.g. `make EXPERIMENTS=1` output kept beside the product library for A/B runs)
+LIB_PATH = os.path.join(_HERE, os.environ.get('LTU_LIB', 'libltu_hip.so'))
 
 P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_uint64
 
@@ -41,21 +42,21 @@ SIGNATURES = {
     'ltu_cast_f32': [P, P, L, I, P],
     'ltu_linear_fwd': [P, I, P, I, P, P, I, I, I, I, I, I, P],
     'ltu_wgrad_ws_floats': [L, I, I],
-    'ltu_upconv_wgrad_ws_floats': [L, I, I],
-    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, P, I, P],
+    'ltu_upconv_wgrad_ws_floats': [L, I, I, I],
+    'ltu_linear_wgrad': [P, I, P, I, P, P, I, I, I, I, P, L, P, I, P],
     'ltu_layer_tail_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, U, U, U, P, I, P, P, P, I, P, P, P, P, P, I, P],
     'ltu_layer_tail_blocks': [L],
-    'ltu_layer_tail_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, U, U, P, I, I, P],
+    'ltu_layer_tail_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, F, U, U, U, P, I, I, P],
     'ltu_reduce_batch': [P, I, P],
-    'ltu_linear_wgrad_group_ws_floats': [P, I],
-    'ltu_linear_wgrad_group': [P, I, P, I, P],
-    'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
+    'ltu_linear_wgrad_group_ws_floats': [P, I, I],
+    'ltu_linear_wgrad_group': [P, I, I, P, L, I, P],
+    'ltu_conv3d_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
     'ltu_conv3d_ws_floats': [I, I, I, I, I, I],
-    'ltu_conv3d_pair_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, P, I, P],
-    'ltu_conv3d_pair_dgrad': [P, P, P, P, I, I, I, I, I, I, I, P, I, P],
-    'ltu_conv3d_pair_wgrad': [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P],
-    'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P],
-    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, P],
+    'ltu_conv3d_pair_fwd': [P, P, P, P, P, I, I, I, I, I, I, I, P, L, I, P],
+    'ltu_conv3d_pair_dgrad': [P, P, P, P, I, I, I, I, I, I, I, P, L, I, P],
+    'ltu_conv3d_pair_wgrad': [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
+    'ltu_conv3d_dgrad': [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
+    'ltu_conv3d_wgrad': [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
     'ltu_affine_sample': [P, P, P, I, I, I, I, P],
     'ltu_zoom_sample': [P, P, P, I, I, I, I, P],
     'ltu_adjust_contrast': [P, P, P, P, I, L, P],
@@ -64,13 +65,14 @@ SIGNATURES = {
     'ltu_weight_prep_chunks': [P, P, I, I, P],
     'ltu_sumpool2': [P, P, I, I, I, I, I, I, P],
     'ltu_upconv_fwd': [P, P, P, P, I, I, I, I, I, I, I, P],
-    'ltu_upconv_dgrad': [P, P, P, I, I, I, I, I, I, P, I, P],
+    'ltu_upconv_dgrad': [P, P, P, I, I, I, I, I, I, P, L, I, P],
     'ltu_igemm_ws_floats': [L, I, I],
-    'ltu_upconv_wgrad': [P, P, P, P, P, I, I, P, I, I, I, I, I, I, I, P],
+    'ltu_upconv_wgrad': [P, P, P, P, P, I, I, P, L, I, I, I, I, I, I, I, I, P],
     'ltu_linattn_splits': [I, I],
-    'ltu_linattn_fwd': [P, P, P, P, P, P, I, I, I, I, P],
-    'ltu_linattn_ctx': [P, P, P, P, I, I, I, I, P],
-    'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    'ltu_linattn_ws_floats': [I, I, I],
+    'ltu_linattn_fwd': [P, P, P, P, P, P, L, I, I, I, I, P],
+    'ltu_linattn_ctx': [P, P, P, P, L, I, I, I, I, P],
+    'ltu_linattn_bwd': [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
     'ltu_window_gather': [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     'ltu_vote_accumulate': [P, P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_vote_finalize': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
@@ -80,12 +82,12 @@ SIGNATURES = {
     'ltu_crop_flip': [P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_adamw': [P, P, P, P, L, F, F, F, F, F, L, F, P],
     'ltu_norm_ws_floats': [],
-    'ltu_instnorm_stats': [P, P, P, I, L, I, I, P],
+    'ltu_instnorm_stats': [P, P, P, L, I, L, I, I, P],
     'ltu_instnorm_apply': [P, P, P, P, I, L, I, I, F, F, U, P, I, P],
-    'ltu_instnorm_fwd': [P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
-    'ltu_instnorm_bwd': [P, P, P, P, P, P, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_instnorm_fwd': [P, P, P, L, P, P, I, L, I, I, F, F, U, P, I, P],
+    'ltu_instnorm_bwd': [P, P, P, P, P, P, P, L, P, I, L, I, I, F, F, U, P, I, P],
     'ltu_layernorm_fwd': [P, P, P, P, P, P, L, I, F, F, U, P, I, P],
-    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U, P, I, P],
+    'ltu_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, L, P, L, I, F, U, P, I, P],
     'ltu_gelu_dropout_fwd': [P, P, L, F, U, P, I, P],
     'ltu_gelu_dropout_bwd': [P, P, P, L, F, U, P, I, P],
     'ltu_head_softmax_fwd': [P, P, L, I, I, I, P],
@@ -94,18 +96,18 @@ SIGNATURES = {
     'ltu_final_softmax_bwd': [P, P, P, I, I, I, I, I, I, I, P],
     'ltu_onehot_argmax': [P, P, L, I, P],
     'ltu_gate_fwd': [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
-    'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    'ltu_gate_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, L, I, I, P],
     'ltu_dwconv_fwd': [P, P, P, P, I, I, I, I, I, F, U, P, I, P],
     'ltu_dwconv_bwd_ws_floats': [I, I, I, I, I, I],
-    'ltu_dwconv_bwd': [P, P, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P],
+    'ltu_dwconv_bwd': [P, P, P, P, P, P, P, P, L, I, I, I, I, I, F, U, P, I, P],
     'ltu_roi_plan_size': [I, I, I, I, P, P, P],
     'ltu_roi_plan': [P, I, I, I, I, I, I, F, P, P, P, P, P],
     'ltu_roi_resample': [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     'ltu_trilinear_up': [P, P, P, I, I, I, I, I, I, I, I, P],
     'ltu_trilinear_adjoint_ws_elems': [I, I, I, I, I, I],
-    'ltu_trilinear_adjoint': [P, P, P, P, I, I, I, I, I, I, I, P],
+    'ltu_trilinear_adjoint': [P, P, P, P, L, I, I, I, I, I, I, I, P],
     'ltu_loss_ws_floats': [I, L, I],
-    'ltu_loss_fwd': [P, P, P, P, P, I, L, I, F, F, P, P, P],
+    'ltu_loss_fwd': [P, P, P, L, P, P, I, L, I, F, F, P, P, P],
     'ltu_loss_bwd': [P, P, P, P, P, I, L, I, P],
     'ltu_label_maxpool': [P, P, I, I, I, I, I, P],
     'ltu_comm_load': [ctypes.c_char_p],

@@ -774,6 +774,7 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
   a.ksplit = a.part != nullptr && !ltu_knob("LTU_NO_HALO_SPLIT", 0) ? halo_split(bricks, a.N, a.C, a.CC, &cps) : 1;
   a.cps = cps;
   if (a.ksplit < 2) a.part = nullptr;
+  else if ((long long)a.ksplit * a.B * a.H * a.W * a.D * a.N > a.part_floats) return LTU_E_ARG;      // the workspace is shorter than this split needs
   const unsigned gz = (unsigned)a.ksplit;
   // TS = taps per weight stage.  A stage's weights are requested one stage ahead and every stage ends in a barrier: with 3 taps
   // (12 MFMAs per wave) a stage is shorter than the L2 round trip of the next one's weights.  9 taps per stage (3 for the 128-column
@@ -1024,6 +1025,7 @@ int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
   const int nsplit = (int)((bricks + a.bricks_per_split - 1) / a.bricks_per_split);
   a.npad = a.N;
   a.kpad = 27 * a.C;
+  if ((long long)nsplit * a.npad * ((long long)a.kpad + 1) > a.part_floats) return LTU_E_ARG;
   a.bpart = a.part + (long long)nsplit * a.npad * a.kpad;
   *nsplit_out = nsplit;
   if (a.CC == 16 && !ltu_knob("LTU_WHALO_NO_PACK", 0))
@@ -1669,15 +1671,11 @@ __global__ void __launch_bounds__(256) upconv_wgrad_class_bf16_kernel(const UpWg
   }
 }
 
-static int upw_blocks() {
-  int v = -1;
-  v = ltu_knob_pos("LTU_UPW_BLOCKS", 256);
-  return v;
-}
+static int upw_blocks(int blocks) { return blocks > 0 ? blocks : ltu_knob_pos("LTU_UPW_BLOCKS", 256); }
 static bool upw_shape_ok(int Ci, int Co, int H, int W, int D) { return Ci % 32 == 0 && Co % 8 == 0 && H >= 2 && W >= 2 && D >= 2; }
-long long upconv_wgrad_class_ws_floats(int Ci, int Co) {
+long long upconv_wgrad_class_ws_floats(int Ci, int Co, int blocks) {
   if (Ci % 32 || Co % 8) return 0;
-  long long ns = upw_blocks() / ((long long)(Ci / 32) * cdiv(Co, 32));
+  long long ns = upw_blocks(blocks) / ((long long)(Ci / 32) * cdiv(Co, 32));
   if (ns < 1) ns = 1;
   return ns * Co * (27LL * Ci + 1);
 }
@@ -1687,13 +1685,14 @@ int launch_upconv_wgrad_class_bf16(UpWgradArgs a, int* nsplit_out, hipStream_t s
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;
   const int nchunk = a.Ci / 32, ntile = cdiv(a.Co, 32);
-  long long ns = upw_blocks() / ((long long)nchunk * ntile);
+  long long ns = upw_blocks(a.blocks) / ((long long)nchunk * ntile);
   if (ns < 1) ns = 1;
   if (ns > bricks) ns = bricks;
   a.bricks = (int)bricks;
   a.bricks_per_split = (int)((bricks + ns - 1) / ns);
   const int nsplit = (int)((bricks + a.bricks_per_split - 1) / a.bricks_per_split);
   a.kpad = 27 * a.Ci;
+  if ((long long)nsplit * a.Co * ((long long)a.kpad + 1) > a.part_floats) return LTU_E_ARG;
   a.bpart = a.part + (long long)nsplit * a.Co * a.kpad;
   *nsplit_out = nsplit;
   hipLaunchKernelGGL(upconv_wgrad_class_bf16_kernel, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);

@@ -412,7 +412,7 @@ extern "C" long long ltu_wgrad_ws_floats(long long M, int N, int K) {
 }
 
 extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int lda, float* const* dw, float* const* db, int nw,
-                                int M, int N, int K, float* ws, ltu_reduce_job* defer, int dtype, ltu_stream_t s) {
+                                int M, int N, int K, float* ws, long long ws_floats, ltu_reduce_job* defer, int dtype, ltu_stream_t s) {
   if (defer != nullptr) defer->part = nullptr;
   if (nw < 1 || nw > 3 || N % nw != 0 || K % 4 != 0 || lda % 4 != 0 || ldg % 4 != 0 || N % 4 != 0) return LTU_E_SHAPE;
   WGradArgs wa;
@@ -421,7 +421,7 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
     // one launch over all weight blocks, two-stage reduction through the workspace
     dense_desc(wa.g, M, N, K);
     wa.g.a0 = a; wa.g.a1 = a; wa.g.lda0 = lda; wa.g.lda1 = lda;
-    wa.grad = grad; wa.ldg = ldg; wa.part = ws;
+    wa.grad = grad; wa.ldg = ldg; wa.part = ws; wa.part_floats = ws_floats;
     wa.nseg_w = nw;
     for (int i = 0; i < nw; ++i) { wa.dwseg[i] = dw[i]; wa.dbseg[i] = db ? db[i] : nullptr; }
     wa.dw = dw[0]; wa.db = db ? db[0] : nullptr;
@@ -454,12 +454,13 @@ extern "C" int ltu_linear_wgrad(const void* grad, int ldg, const void* a, int ld
   return LTU_OK;
 }
 
-extern "C" long long ltu_linear_wgrad_group_ws_floats(const ltu_wgrad_job* jobs, int njobs) {
-  return tn_ring_group_ws_floats(jobs, njobs);
+extern "C" long long ltu_linear_wgrad_group_ws_floats(const ltu_wgrad_job* jobs, int njobs, int blocks) {
+  return tn_ring_group_ws_floats(jobs, njobs, blocks);
 }
-extern "C" int ltu_linear_wgrad_group(const ltu_wgrad_job* jobs, int njobs, float* ws, int dtype, ltu_stream_t s) {
+extern "C" int ltu_linear_wgrad_group(const ltu_wgrad_job* jobs, int njobs, int blocks, float* ws, long long ws_floats, int dtype,
+                                      ltu_stream_t s) {
   if (dtype != LTU_BF16) return LTU_E_DTYPE;
-  const int rc = launch_tn_ring_group_bf16(jobs, njobs, ws, (hipStream_t)s);
+  const int rc = launch_tn_ring_group_bf16(jobs, njobs, blocks, ws, ws_floats, (hipStream_t)s);
   return rc == 1 ? LTU_E_SHAPE : rc;
 }
 
@@ -492,8 +493,8 @@ static int conv_fwd_desc(IGemmArgs& g, int B, int Hi, int Wi, int Di, int C0, in
 }
 
 extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, const float* bias, void* y, int B, int Hi,
-                              int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, float* ws, int dtype,
-                              ltu_stream_t s) {
+                              int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, float* ws, long long ws_floats,
+                              int dtype, ltu_stream_t s) {
   IGemmArgs g;
   int Ho, Wo, Do;
   int rc = conv_fwd_desc(g, B, Hi, Wi, Di, C0, C1, Co, sh, sw, sd, ups, &Ho, &Wo, &Do);
@@ -509,11 +510,11 @@ extern "C" int ltu_conv3d_fwd(const void* x0, const void* x1, const void* wf, co
       a.B = B; a.H = Hi; a.W = Wi; a.D = Di;
       a.C = C0 + C1; a.c0 = C0; a.lda0 = C0; a.lda1 = C1 > 0 ? C1 : C0;
       a.N = Co; a.n0 = Co; a.ldo0 = Co; a.ldo1 = Co;
-      a.part = ws;
+      a.part = ws; a.part_floats = ws_floats;
       const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
       if (hr != 1) return hr;
     }
-    g.part = ws;                           // strided / upsampling convs on small grids split their K loop
+    g.part = ws; g.part_floats = ws_floats;     // strided / upsampling convs on small grids split their K loop
     return launch_nt_bf16(g, (hipStream_t)s);
   }
   if (dtype != LTU_F32) return LTU_E_DTYPE;
@@ -528,7 +529,7 @@ extern "C" long long ltu_igemm_ws_floats(long long M, int N, int K) { return ige
 
 extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1, float* dwf, float* db, int B, int Hi,
                                 int Wi, int Di, int C0, int C1, int Co, int sh, int sw, int sd, int ups, int torch_co,
-                                int torch_ci, float* ws, int dtype, ltu_stream_t s) {
+                                int torch_ci, float* ws, long long ws_floats, int dtype, ltu_stream_t s) {
   WGradArgs wa;
   memset(&wa, 0, sizeof(wa));
   int Ho, Wo, Do;
@@ -537,14 +538,14 @@ extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1
   if (Co % 4 != 0) return LTU_E_SHAPE;
   wa.g.a0 = x0; wa.g.a1 = x1 ? x1 : x0;
   wa.grad = grad; wa.ldg = Co; wa.dw = dwf; wa.db = db; wa.t_co = torch_co; wa.t_ci = torch_ci;
-  wa.part = dtype == LTU_BF16 ? ws : nullptr; wa.nseg_w = 1;
+  wa.part = dtype == LTU_BF16 ? ws : nullptr; wa.part_floats = ws_floats; wa.nseg_w = 1;
   if (dtype == LTU_BF16 && ws != nullptr && sh == 1 && sw == 1 && sd == 1 && !ups && use_halo()) {
     WHaloArgs h;
     memset(&h, 0, sizeof(h));
     h.x0 = x0; h.x1 = x1 ? x1 : x0; h.grad = grad;
     h.B = B; h.H = Hi; h.W = Wi; h.D = Di;
     h.C = C0 + C1; h.c0 = C0; h.lda0 = C0; h.lda1 = C1 > 0 ? C1 : C0;
-    h.N = Co; h.ldg = Co; h.part = ws;
+    h.N = Co; h.ldg = Co; h.part = ws; h.part_floats = ws_floats;
     int nsplit = 0;
     const int hr = launch_conv_wgrad_halo_bf16(h, &nsplit, (hipStream_t)s);
     if (hr == LTU_OK) {
@@ -563,7 +564,7 @@ extern "C" int ltu_conv3d_wgrad(const void* grad, const void* x0, const void* x1
 // For a dim of stride 2 the input positions split into parity classes:  even i receives only from
 // tap 1 (at o = i/2), odd i from tap 0 (o = (i+1)/2) and tap 2 (o = (i-1)/2).
 extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, void* dx1, int B, int Hl, int Wl, int Dl,
-                                int C0, int C1, int Co, int sh, int sw, int sd, float* ws, int dtype, ltu_stream_t s) {
+                                int C0, int C1, int Co, int sh, int sw, int sd, float* ws, long long ws_floats, int dtype, ltu_stream_t s) {
   if ((sh != 1 && sh != 2) || (sw != 1 && sw != 2) || (sd != 1 && sd != 2)) return LTU_E_ARG;
   if (Co % 4 != 0) return LTU_E_SHAPE;
   if (dtype == LTU_BF16 && sh == 1 && sw == 1 && sd == 1 && use_halo()) {
@@ -574,7 +575,7 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
     a.C = Co; a.c0 = Co; a.lda0 = Co; a.lda1 = Co;
     a.N = C0 + C1; a.n0 = C0; a.ldo0 = C0; a.ldo1 = C1 > 0 ? C1 : C0;
     a.flip = 1;
-    a.part = ws;
+    a.part = ws; a.part_floats = ws_floats;
     const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
     if (hr != 1) return hr;
   }
@@ -681,7 +682,7 @@ extern "C" int ltu_conv3d_dgrad(const void* grad, const void* wd, void* dx0, voi
 // 1380).  Forward: output columns [0,N0) -> y0 [.., N0], the rest -> y1 [.., N1]; wf [N0+N1][27][C], bias [N0+N1].
 // Data gradient: the virtual concat of g0 [.., N0] and g1 [.., N1] against wd [C][27][N0+N1] -> dx [.., C] (no add pass).
 extern "C" int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* bias, void* y0, void* y1, int B, int H, int W,
-                                   int D, int C, int N0, int N1, float* ws, int dtype, ltu_stream_t s) {
+                                   int D, int C, int N0, int N1, float* ws, long long ws_floats, int dtype, ltu_stream_t s) {
   if (N0 % 4 || N1 % 4 || N0 <= 0 || N1 <= 0) return LTU_E_SHAPE;
   IGemmArgs g;
   int Ho, Wo, Do;
@@ -698,7 +699,7 @@ extern "C" int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* b
       a.B = B; a.H = H; a.W = W; a.D = D;
       a.C = C; a.c0 = C; a.lda0 = C; a.lda1 = C;
       a.N = N0 + N1; a.n0 = N0; a.ldo0 = N0; a.ldo1 = N1;
-      a.part = ws;
+      a.part = ws; a.part_floats = ws_floats;
       const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
       if (hr != 1) return hr;
     }
@@ -709,7 +710,7 @@ extern "C" int ltu_conv3d_pair_fwd(const void* x, const void* wf, const float* b
 }
 
 extern "C" int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void* wd, void* dx, int B, int H, int W, int D, int C,
-                                     int N0, int N1, float* ws, int dtype, ltu_stream_t s) {
+                                     int N0, int N1, float* ws, long long ws_floats, int dtype, ltu_stream_t s) {
   if (N0 % 4 || N1 % 4 || N0 <= 0 || N1 <= 0) return LTU_E_SHAPE;
   if (dtype == LTU_BF16 && use_halo()) {
     HaloArgs a;
@@ -719,7 +720,7 @@ extern "C" int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void*
     a.C = N0 + N1; a.c0 = N0; a.lda0 = N0; a.lda1 = N1;
     a.N = C; a.n0 = C; a.ldo0 = C; a.ldo1 = C;
     a.flip = 1;
-    a.part = ws;
+    a.part = ws; a.part_floats = ws_floats;
     const int hr = launch_conv_halo_bf16(a, (hipStream_t)s);
     if (hr != 1) return hr;
   }
@@ -752,7 +753,7 @@ extern "C" int ltu_conv3d_pair_dgrad(const void* g0, const void* g1, const void*
 // rows [0, co_a) land in dwa [co_a][ci][27], rows [N0, N0 + co_b) in dwb.  Other dtypes / shapes: two ordinary calls.
 extern "C" int ltu_conv3d_pair_wgrad(const void* g0, const void* g1, const void* x, float* dwa, float* dba, float* dwb,
                                      float* dbb, int B, int H, int W, int D, int C, int N0, int N1, int co_a, int co_b, int ci,
-                                     float* ws, int dtype, ltu_stream_t s) {
+                                     float* ws, long long ws_floats, int dtype, ltu_stream_t s) {
   if (dtype == LTU_BF16 && ws != nullptr && use_halo()) {
     WGradArgs wa;
     memset(&wa, 0, sizeof(wa));
@@ -762,13 +763,13 @@ extern "C" int ltu_conv3d_pair_wgrad(const void* g0, const void* g1, const void*
     wa.g.a0 = x; wa.g.a1 = x;
     wa.dw = dwa; wa.db = dba; wa.t_co = co_a; wa.t_ci = ci;
     wa.dw2 = dwb; wa.db2 = dbb; wa.n0_2 = N0; wa.t_co2 = co_b;
-    wa.part = ws; wa.nseg_w = 1;
+    wa.part = ws; wa.part_floats = ws_floats; wa.nseg_w = 1;
     WHaloArgs h;
     memset(&h, 0, sizeof(h));
     h.x0 = x; h.x1 = x; h.grad = g0; h.grad1 = g1; h.gn0 = N0; h.ldg1 = N1;
     h.B = B; h.H = H; h.W = W; h.D = D;
     h.C = C; h.c0 = C; h.lda0 = C; h.lda1 = C;
-    h.N = N0 + N1; h.ldg = N0; h.part = ws;
+    h.N = N0 + N1; h.ldg = N0; h.part = ws; h.part_floats = ws_floats;
     int nsplit = 0;
     const int hr = launch_conv_wgrad_halo_bf16(h, &nsplit, (hipStream_t)s);
     if (hr == LTU_OK) {
@@ -778,9 +779,9 @@ extern "C" int ltu_conv3d_pair_wgrad(const void* g0, const void* g1, const void*
     }
     if (hr != 1) return hr;
   }
-  int rc = ltu_conv3d_wgrad(g0, x, nullptr, dwa, dba, B, H, W, D, C, 0, N0, 1, 1, 1, 0, co_a, ci, ws, dtype, s);
+  int rc = ltu_conv3d_wgrad(g0, x, nullptr, dwa, dba, B, H, W, D, C, 0, N0, 1, 1, 1, 0, co_a, ci, ws, ws_floats, dtype, s);
   if (rc) return rc;
-  return ltu_conv3d_wgrad(g1, x, nullptr, dwb, dbb, B, H, W, D, C, 0, N1, 1, 1, 1, 0, co_b, ci, ws, dtype, s);
+  return ltu_conv3d_wgrad(g1, x, nullptr, dwb, dbb, B, H, W, D, C, 0, N1, 1, 1, 1, 0, co_b, ci, ws, ws_floats, dtype, s);
 }
 
 // fp32 launchers for the other translation units (upconv.hip)

@@ -451,6 +451,7 @@ int launch_nt_bf16(const IGemmArgs& g_in, hipStream_t st) {
     const bool ok = g.out_identity && !g.accum && g.N % 4 == 0 && g.n0 % 4 == 0 && !ltu_knob("LTU_NO_NT_SPLIT", 0);
     const int ks = ok ? nt_split(g.M, g.N, g.K, &kps) : 1;
     if (ks > 1) {
+      if ((long long)ks * g.M * g.N > g.part_floats) return LTU_E_ARG;         // the workspace is shorter than this split needs
       g.ksplit = ks; g.kt_per_split = kps;
       dim3 grid(cdiv(g.M, 64), cdiv(g.N, 128), ks);
       hipLaunchKernelGGL((igemm_nt_bf16_kernel<2, 2, 1, 2, 64, 2>), grid, dim3(256), 0, st, g);
@@ -762,6 +763,7 @@ int launch_tn_bf16(WGradArgs& wa, hipStream_t st) {
   const TnGeom t = tn_geometry(g.M, g.N, g.K, 32);
   wa.rows_per_split = t.rows;
   if (wa.part != nullptr) {
+    if (t.ws_floats > wa.part_floats) return LTU_E_ARG;
     wa.npad = t.nn * t.bn;
     wa.kpad = t.nk * t.bk;
     wa.bpart = wa.part + (long long)t.nsplit * wa.npad * wa.kpad;

@@ -34,6 +34,7 @@ struct IGemmArgs {
   // split over K for small grids with long K loops (bf16 NT kernel): workgroup z handles K tiles [z*kt_per_split, ...) and
   // stores its fp32 tile to part[z][M][N]; igemm_fold_kernel adds the splits and the bias.  part == nullptr: no split.
   float* part;
+  long long part_floats;   // capacity of `part` (floats): a geometry that needs more is refused (LTU_E_ARG), never written past
   int ksplit, kt_per_split;
   // fused GELU + dropout epilogue of the weight-stationary projection kernel (transformer FFN: trans_block.py:208): the
   // pre-activation goes to o0 as usual and h = dropout(gelu(bf16(u))) to gelu_out [M][N]; nullptr: plain projection
@@ -70,6 +71,7 @@ struct WGradArgs {
   // two-stage mode (part != null): every split stores its fp32 tile to part[split][npad][kpad] (+ bias partials to
   // bpart[split][npad]) with plain stores; wgrad_reduce_kernel sums the splits into the gradient.  No atomics.
   float* part;
+  long long part_floats;   // capacity of `part` (floats)
   float* bpart;
   int npad, kpad;
   // second PyTorch-layout conv gradient (conv pairs): rows [n0_2, n0_2 + t_co2) of the tile go to dw2 [t_co2][t_ci][27] / db2
@@ -128,6 +130,7 @@ struct HaloArgs {
   // workgroup z accumulates chunks [z*cps, (z+1)*cps) and stores its fp32 tile to part[z][voxel][N]; conv_halo_fold_kernel
   // adds the splits and the bias.  part == nullptr: one workgroup per tile walks all chunks.
   float* part;
+  long long part_floats;   // capacity of `part` (floats)
   int ksplit, cps;
   int no_xcd_order;     // 1: bricks dealt to the workgroups of the persistent kernels strided by the grid (LTU_HALO_NO_XCD: the old order)
 };
@@ -150,6 +153,7 @@ struct WHaloArgs {
   int CC;               // channel chunk per workgroup: 16 or 32
   int bricks, bricks_per_split;
   float* part;          // [nsplit][npad][kpad]
+  long long part_floats;   // capacity of `part` (floats)
   float* bpart;         // [nsplit][npad]
   int npad, kpad;
 };
@@ -163,8 +167,8 @@ long long tn_ring_ws_floats(long long M, int N, int K);
 int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out = nullptr);   // LTU_OK / hipError, or 1 = shape not handled
 int launch_nt_ring_bf16(const IGemmArgs& g, hipStream_t st);
 // several dense weight gradients in one launch + one fold launch; 0 floats / 1 = group not handled
-long long tn_ring_group_ws_floats(const ltu_wgrad_job* jobs, int njobs);
-int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled (also: gelu_out set and no ring)
+long long tn_ring_group_ws_floats(const ltu_wgrad_job* jobs, int njobs, int blocks);
+int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, int blocks, float* ws, long long ws_floats, hipStream_t st);      // LTU_OK / hipError, or 1 = shape not handled (also: gelu_out set and no ring)
 
 // class convolutions on an LDS halo brick (conv_halo.hip): fine voxel o = m q + p gets sum_e [cls_e == class(p)] x[q + d_e] . W_e^T
 struct ClsEntry {
@@ -207,8 +211,10 @@ struct UpWgradArgs {
   int B, H, W, D, Ci, Co;
   int bricks, bricks_per_split;
   float* part;          // [nsplit][Co][27 Ci]
+  long long part_floats;   // capacity of `part` (floats)
   float* bpart;         // [nsplit][Co]
   int kpad;
+  int blocks;           // workgroup budget of the launch (<= 0: LTU_UPW_BLOCKS / 256)
 };
-long long upconv_wgrad_class_ws_floats(int Ci, int Co);
+long long upconv_wgrad_class_ws_floats(int Ci, int Co, int blocks);
 int launch_upconv_wgrad_class_bf16(UpWgradArgs a, int* nsplit_out, hipStream_t st);   // LTU_OK / hipError, or 1 = not handled

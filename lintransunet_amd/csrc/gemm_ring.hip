@@ -9,6 +9,7 @@
 // LDS-DMA writes lane-linear (wave base + 16 B x lane), so bank spreading is done on the SOURCE address: a 16-byte chunk c
 // of row r is fetched by the lane whose linear slot is c ^ f(r), and the fragment reads apply the same involution.
 #include "gemm_desc.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short rs16x4;
@@ -528,6 +529,7 @@ int launch_tn_ring_bf16(WGradArgs& wa, hipStream_t st, int* nsplit_out) {
   if (!tn_ring_shape_ok(g.M, g.N, g.K) || g.lda0 % 8 || wa.ldg % 8) return 1;
   if (((uintptr_t)g.a0 | (uintptr_t)wa.grad) & 15) return 1;
   const RingGeom t = tn_ring_geometry(g.M, g.N, g.K);
+  if (t.ws_floats > wa.part_floats) return LTU_E_ARG;
   wa.rows_per_split = t.rows;
   wa.npad = g.N; wa.kpad = g.K;
   wa.bpart = wa.part + (long long)t.nsplit * wa.npad * wa.kpad;
@@ -627,10 +629,10 @@ __global__ void __launch_bounds__(256) wgroup_fold_kernel(const WFoldArgs fa) {
   }
 }
 
-static void wgroup_geometry(const ltu_wgrad_job* jobs, int njobs, WGroupArgs& ga, long long* part_off, long long* ws_floats) {
+static void wgroup_geometry(const ltu_wgrad_job* jobs, int njobs, int blocks, WGroupArgs& ga, long long* part_off, long long* ws_floats) {
   int tiles = 0;
   for (int i = 0; i < njobs; ++i) tiles += (jobs[i].N / 128) * (jobs[i].K / 128);
-  const int budget = ltu_knob_pos("LTU_WGROUP_BLOCKS", 256);
+  const int budget = blocks > 0 ? blocks : ltu_knob_pos("LTU_WGROUP_BLOCKS", 256);
   long long off = 0, Mmax = 0;
   for (int i = 0; i < njobs; ++i) Mmax = jobs[i].M > Mmax ? jobs[i].M : Mmax;
   // one split count for the whole group (the jobs of a transformer layer have the same M): ~budget workgroups, splits of >= 128 rows
@@ -672,21 +674,35 @@ static bool wgroup_ok(const ltu_wgrad_job* jobs, int njobs) {
   }
   return true;
 }
-long long tn_ring_group_ws_floats(const ltu_wgrad_job* jobs, int njobs) {
+static bool wfat_enabled();
+long long wgrad_fat_group_ws_floats(const ltu_wgrad_job* jobs, int njobs, int blocks);
+int launch_wgrad_fat_group_bf16(const ltu_wgrad_job* jobs, int njobs, int blocks, float* ws, long long ws_floats, hipStream_t st);
+// blocks: the workgroup budget of the launch (<= 0: LTU_WGROUP_BLOCKS / 256).  The size query and the launch take the SAME argument,
+// and the launch is told the capacity of `ws`: a geometry that needs more returns LTU_E_ARG instead of writing past the end.
+long long tn_ring_group_ws_floats(const ltu_wgrad_job* jobs, int njobs, int blocks) {
+  if (wfat_enabled()) {
+    const long long n = wgrad_fat_group_ws_floats(jobs, njobs, blocks);
+    if (n > 0) return n;
+  }
   if (!wgroup_ok(jobs, njobs)) return 0;
   WGroupArgs ga;
   long long n = 0, off[LTU_WGRAD_GROUP_MAX];
-  wgroup_geometry(jobs, njobs, ga, off, &n);
+  wgroup_geometry(jobs, njobs, blocks, ga, off, &n);
   return n;
 }
 // launches the grouped kernel and its fold; returns 1 when the group is not handled
-int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, hipStream_t st) {
+int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, int blocks, float* ws, long long ws_floats, hipStream_t st) {
+  if (wfat_enabled()) {
+    const int rc = launch_wgrad_fat_group_bf16(jobs, njobs, blocks, ws, ws_floats, st);
+    if (rc != 1) return rc;
+  }
   if (!wgroup_ok(jobs, njobs) || ws == nullptr) return 1;
   WGroupArgs ga;
   memset(&ga, 0, sizeof(ga));
   long long n = 0, off[LTU_WGRAD_GROUP_MAX];
-  wgroup_geometry(jobs, njobs, ga, off, &n);
-  int blocks = 0, fblocks = 0;
+  wgroup_geometry(jobs, njobs, blocks, ga, off, &n);
+  if (n > ws_floats) return LTU_E_ARG;
+  int nblocks = 0, fblocks = 0;
   WFoldArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.njobs = njobs;
@@ -710,8 +726,438 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, float* ws, h
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_ring_bf16_kernel<TN_RING>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               smem_bytes);
   }
-  blocks = ga.nsplit >= 8 ? ((ga.nsplit + 7) / 8) * ga.tiles * 8 : ga.nsplit * ga.tiles;
-  hipLaunchKernelGGL((wgrad_group_ring_bf16_kernel<TN_RING>), dim3(blocks), dim3(256), smem_bytes, st, ga);
+  nblocks = ga.nsplit >= 8 ? ((ga.nsplit + 7) / 8) * ga.tiles * 8 : ga.nsplit * ga.tiles;
+  hipLaunchKernelGGL((wgrad_group_ring_bf16_kernel<TN_RING>), dim3(nblocks), dim3(256), smem_bytes, st, ga);
   if (!ga.direct) hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fa);
+  return ltu_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ grouped weight gradients, round 5
+// "Fat tiles": ONE workgroup owns all column tiles of a job's row split that its accumulators can hold, so an operand row is read
+// once - e.g. the 384-column q|k|v gradient of a d = 128 layer is three accumulator sets over ONE pass of X (the 128 x 128 tiles of
+// the kernel above read X three times and, at half the machine's width beside the main chain, those re-reads did reach HBM: 1.48x
+// the algorithmic bytes in profiles/r04_pmc_step.json).  Tile types (TN x TK outputs, <= 49 152 fp32 accumulators = 192
+// registers per lane at one wave per SIMD): 384 x 128, 256 x 128, 128 x 256, 128 x 128; a job is cut into the type that reads the fewest
+// bytes per row.  At d = 128 every projection of a layer is exactly one tile per row split (q|k|v 384 x 128, out 128 x 128, linear1
+// 256 x 128, linear2 128 x 256): operands are read exactly once.  Each job gets its own split count, proportional to the bytes
+// one of its tiles streams per row, so the workgroups of a launch finish together.
+// The ring is sized by BYTES IN FLIGHT, not by rows: these kernels run one workgroup per CU on half of the CUs (beside the main
+// chain), so what a CU keeps in flight x the CUs sets the rate (Little's law at 2-3 us of loaded HBM latency): units of 16 rows
+// (8-16 KB) in a ring of 144 KB, all but two units in flight (the kernel above: 80 KB).
+// LDS image of a unit: column blocks [TNB of G | TKB of X] of [ROWS][128] bf16 each, chunk c of row r at slot c ^ ((r & 3) << 2) as
+// above (conflict-free transposing reads).  4 waves as 2 (n) x 2 (k).
+struct WFatJob {
+  const uint16_t* grad;
+  const uint16_t* x;
+  float* part;          // [nsplit][N][K] followed by the bias partials [nsplit][N] (unused when direct)
+  float* out[3];        // the gradient blocks (direct mode)
+  float* outb[3];
+  long long M;
+  int ldg, lda, N, K, nper, rows, wg_begin;
+  short type, nt, kt, nsplit, direct, pad;
+};
+struct WFatArgs {
+  WFatJob j[LTU_WGRAD_GROUP_MAX];
+  int njobs;
+};
+static_assert(sizeof(WFatArgs) <= 4096, "kernel arguments");
+#ifndef WFAT_RING_KB
+#ifdef WFAT_TYPE0
+#define WFAT_RING_KB 144
+#else
+#define WFAT_RING_KB 96
+#endif
+#endif
+#define WFAT_RING_BYTES (WFAT_RING_KB * 1024)
+#define WFAT_R(unit_kb) (WFAT_RING_KB / (unit_kb))
+
+struct WFatView {     // one job as scalars (built field by field from the kernel arguments: no struct copy in private memory)
+  const uint16_t* grad;
+  const uint16_t* x;
+  float* part;
+  float* out0; float* out1; float* out2;
+  float* outb0; float* outb1; float* outb2;
+  int ldg, lda, N, K, nper, nsplit, direct;
+};
+// retire all but the youngest N LDS-DMA of this wave AND every LDS read it has issued, then meet the other waves
+template <int N>
+__device__ __forceinline__ void ring_sync_all() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// column sums of a bf16 pair, accumulated in fp32: c += lo + hi (v_dot2c_f32_bf16 against (1, 1); the builtin does not select in
+// hipcc 7.2).  Not volatile: the scheduler places it in the shadow of the MFMAs.
+__device__ __forceinline__ void bf16_pair_sum(float& c, uint32_t w) {
+  const uint32_t ones = 0x3f803f80u;
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(c) : "v"(w), "v"(ones));
+}
+
+// Units of 16 rows (one MFMA k-step).  The loop is software-pipelined by hand: while the MFMAs of unit `it` run on fragments that
+// are already in registers, the fragments of unit it + 1 are read from LDS into a second register set and the LDS-DMA of unit
+// it + R - 1 is issued piece by piece BETWEEN the MFMAs (ablation of the first version, profiles/r05_wgroup_ablation.txt: LDS-DMA
+// alone 53 us, fragment reads + MFMAs alone 55 us, together 79 us - one wave per SIMD issues in order, so whatever is not placed
+// in the shadow of an MFMA is serial time).
+template <int TNB, int TKB, int R, int DBG = 0>
+__device__ __forceinline__ void wgrad_fat_tile(const WFatView jb, long long m_begin, long long m_end, int n0, int k0, int split,
+                                               bool do_bias, uint16_t* smem) {
+  constexpr int NB = TNB + TKB;
+  constexpr int UNIT = 16 * NB * 128;                         // elements
+  constexpr int DPW = NB;                                     // LDS-DMA pieces per wave and unit (one per column block)
+  constexpr int NI = 2 * TNB, NJ = 2 * TKB;                   // 32-column groups per wave
+  constexpr int NMF = NI * NJ;
+  static_assert(R * UNIT * 2 <= WFAT_RING_BYTES, "ring");
+  static_assert(DPW * (R - 3) <= 63 && R >= 4, "vmcnt");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int niter = m_end > m_begin ? (int)((m_end - m_begin) >> 4) : 0;
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[TNB];
+#pragma unroll
+  for (int q = 0; q < TNB; ++q) bsum[q] = 0.f;
+
+  // LDS-DMA sources: wave w fills rows 4w .. 4w + 3 of every column block
+  const int prow = 4 * wave + (lane >> 4);
+  const int lchunk = (lane & 15) ^ ((lane >> 4) << 2);
+  const uint16_t* gsrc = jb.grad + (m_begin + prow) * jb.ldg + n0 + lchunk * 8;
+  const uint16_t* xsrc = jb.x + (m_begin + prow) * jb.lda + k0 + lchunk * 8;
+  const long long gstep = 16LL * jb.ldg, xstep = 16LL * jb.lda;
+  auto piece = [&](int slot, int b) {                         // column block b of the unit that goes to ring slot `slot`
+    if (DBG & 2) return;
+    uint16_t* base = smem + slot * UNIT + wave * 512 + b * 2048;
+    if (b < TNB) glds16(gsrc + b * 128, base); else glds16(xsrc + (b - TNB) * 128, base);
+  };
+  auto advance = [&]() { gsrc += gstep; xsrc += xstep; };
+
+  // transposing-read geometry (as in wgrad_ring_tile): this lane addresses row trow (and trow + 4) of the 16-row slab, 4 columns
+  // at tcol of a 32-column group; group g of a block sits at chunk slots ((g ^ tq) * 4 ..) of the row
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tcol = 16 * (gq & 1) + 4 * tp;
+  const int trow = 8 * (gq >> 1) + tq;
+  int aoff[NI], boff[NJ];            // element offsets of this lane's fragments inside a unit
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int gg = wm * NI + i;
+    aoff[i] = (gg >> 2) * 2048 + trow * 128 + (((((gg & 3) * 4 + (tcol >> 3)) ^ (tq << 2)) << 3) + (tcol & 7));
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int gg = wn * NJ + j;
+    boff[j] = (TNB + (gg >> 2)) * 2048 + trow * 128 + (((((gg & 3) * 4 + (tcol >> 3)) ^ (tq << 2)) << 3) + (tcol & 7));
+  }
+  auto frags = [&](bf16x8 (&a)[NI], bf16x8 (&b)[NJ], int slot) {
+    if (DBG & 1) return;
+    const uint16_t* U = smem + slot * UNIT;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      union { struct { rs16x4 l, h; } s; bf16x8 v; } u;
+      u.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_rs16x4*)(U + aoff[i]));
+      u.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_rs16x4*)(U + aoff[i] + 4 * 128));
+      a[i] = u.v;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      union { struct { rs16x4 l, h; } s; bf16x8 v; } u;
+      u.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_rs16x4*)(U + boff[j]));
+      u.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_rs16x4*)(U + boff[j] + 4 * 128));
+      b[j] = u.v;
+    }
+  };
+  // the NMF MFMAs of a unit with the DPW pieces of a later unit issued between them (ISSUE: compile time, two code versions)
+  auto mfmas = [&](const bf16x8 (&a)[NI], const bf16x8 (&b)[NJ], auto issue_tag, int slot) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;
+    if (DBG & 1) {
+      if (ISSUE) {
+#pragma unroll
+        for (int p = 0; p < DPW; ++p) piece(slot, p);
+      }
+      return;
+    }
+    constexpr int PER = NMF / DPW;                            // MFMAs per piece
+    // bias gradient = column sums of G: the A fragment holds 8 rows of column n = lane & 31.  The two waves that share the A
+    // fragments (wn = 0, 1) each sum every second one (selected dword by dword: a select between two 16-byte vectors compiles to an
+    // indexed load from private memory); the sums of fragment pair q sit in the q-th group of MFMAs
+    auto bias = [&](int q) {
+      union { bf16x8 v; uint32_t w[4]; } u0, u1;
+      u0.v = a[2 * q]; u1.v = a[2 * q + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bf16_pair_sum(bsum[q], wn ? u1.w[e] : u0.w[e]);
+    };
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) {
+      const int i = m / NJ, j = m % NJ;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (m % PER == PER - 1) {
+        if (m / PER < TNB) bias(m / PER);
+        if (ISSUE) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(slot, m / PER);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    static_assert(TNB <= DPW, "one bias group per piece");
+  };
+
+  bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
+  for (int u = 0; u < R - 1 && u < niter; ++u) {
+#pragma unroll
+    for (int p = 0; p < DPW; ++p) piece(u, p);
+    advance();
+  }
+  // steady state: iterations it < n_steady issue the LDS-DMA of unit it + R - 1 (into the slot of unit it - 1); two per trip so
+  // that the two fragment register sets are compile-time names; no test inside
+  const int n_steady = niter - (R - 1);
+  int it = 0, slot_c = 0;                                    // ring slot of unit `it`
+  auto nxt = [&](int sl) { return sl + 1 == R ? 0 : sl + 1; };
+  auto prv = [&](int sl) { return sl == 0 ? R - 1 : sl - 1; };
+  if (n_steady >= 2) {
+    ring_sync_all<DPW * (R - 2)>();                           // unit 0 has landed
+    frags(a0, b0, 0);
+    for (; it + 1 < n_steady; it += 2) {
+      // unit it + 1 has landed (this wave's pieces: vmcnt; the other waves': the barrier) and every wave holds the fragments of
+      // unit `it` in registers (lgkmcnt(0) before the barrier): the slots of all units <= it may be overwritten
+      ring_sync_all<DPW * (R - 3)>();
+      frags(a1, b1, nxt(slot_c));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a0, b0, std::true_type{}, prv(slot_c));
+      advance();
+      slot_c = nxt(slot_c);
+      ring_sync_all<DPW * (R - 3)>();
+      frags(a0, b0, nxt(slot_c));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a1, b1, std::true_type{}, prv(slot_c));
+      advance();
+      slot_c = nxt(slot_c);
+    }
+  }
+  // tail (at most R iterations): everything that is in flight is waited for, fragments are read where they are used
+  for (; it < niter; ++it) {
+    ring_sync_all<0>();
+    frags(a0, b0, slot_c);
+    if (it + R - 1 < niter) {
+#pragma unroll
+      for (int p = 0; p < DPW; ++p) piece(prv(slot_c), p);
+      advance();
+    }
+    mfmas(a0, b0, std::false_type{}, 0);
+    slot_c = nxt(slot_c);
+  }
+
+  const int li = lane & 31, lh = lane >> 5;
+  if (do_bias) {
+#pragma unroll
+    for (int q = 0; q < TNB; ++q) {
+      const float t = xhalf_combine<LtuAdd>(bsum[q]);
+      const int n = n0 + (wm * NI + 2 * q + wn) * 32 + li;
+      if (lh == 0) {
+        if (jb.direct) {
+          const int seg = n / jb.nper;
+          float* ob = seg == 0 ? jb.outb0 : (seg == 1 ? jb.outb1 : jb.outb2);
+          if (ob != nullptr) ob[n - seg * jb.nper] += t;
+        } else {
+          jb.part[(long long)jb.nsplit * jb.N * jb.K + (long long)split * jb.N + n] = t;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int nb = n0 + (wm * NI + i) * 32;                   // first of this group's 32 rows of cat(dW): inside one gradient block
+    float* rowbase;
+    if (jb.direct) {
+      const int seg = nb / jb.nper;
+      rowbase = (seg == 0 ? jb.out0 : (seg == 1 ? jb.out1 : jb.out2)) + (long long)(nb - seg * jb.nper) * jb.K;
+    } else {
+      rowbase = jb.part + ((long long)split * jb.N + nb) * jb.K;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float* p = rowbase + k0 + (wn * NJ + j) * 32 + li + (long long)(4 * lh) * jb.K;
+      if (jb.direct) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = p[(long long)((r & 3) + 8 * (r >> 2)) * jb.K];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(long long)((r & 3) + 8 * (r >> 2)) * jb.K] = old[r] + acc[i][j][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(long long)((r & 3) + 8 * (r >> 2)) * jb.K] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+struct WFatType { int tnb, tkb; };
+static const WFatType WFAT_TYPES[4] = {{3, 1}, {2, 1}, {1, 2}, {1, 1}};
+
+#ifdef WFAT_TYPE0
+#define WFAT_WAVES 1
+#else
+#define WFAT_WAVES 2          // <= 256 registers: a second wave per SIMD (of another kernel) fits beside this one
+#endif
+template <int DBG>
+__global__ void __launch_bounds__(256, WFAT_WAVES) wgrad_fat_group_bf16_kernel(const WFatArgs fa) {
+  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
+  int ji = 0;
+  for (int t = 1; t < fa.njobs; ++t)
+    if ((int)blockIdx.x >= fa.j[t].wg_begin) ji = t;
+  const WFatJob& J = fa.j[ji];
+  const int local = (int)blockIdx.x - J.wg_begin;
+  const int nt = J.nt, kt = J.kt, nsplit = J.nsplit, rows = J.rows, type = J.type;
+  const long long M = J.M;
+  const int tiles = nt * kt;
+  // all tiles of one row split get workgroup ids that are equal modulo 8 (one XCD under round-robin placement: the tiles of a
+  // multi-tile job read the same rows); wg_begin is a multiple of 8.  Placement affects speed only.
+  int tile, split;
+  if (nsplit >= 8) {
+    const int s_lo = local & 7, q = local >> 3;
+    tile = q % tiles; split = (q / tiles) * 8 + s_lo;
+    if (split >= nsplit) return;
+  } else {
+    tile = local / nsplit; split = local - tile * nsplit;
+    if (tile >= tiles) return;
+  }
+  WFatView v;
+  v.grad = J.grad; v.x = J.x; v.part = J.part;
+  v.out0 = J.out[0]; v.out1 = J.out[1]; v.out2 = J.out[2];
+  v.outb0 = J.outb[0]; v.outb1 = J.outb[1]; v.outb2 = J.outb[2];
+  v.ldg = J.ldg; v.lda = J.lda; v.N = J.N; v.K = J.K; v.nper = J.nper; v.nsplit = nsplit; v.direct = J.direct;
+  const int nb = tile / kt, kb = tile - nb * kt;
+  const long long m_begin = (long long)split * rows;
+  long long m_end = m_begin + rows;
+  if (m_end > M) m_end = M;
+  switch (type) {
+#ifdef WFAT_TYPE0
+    case 0: wgrad_fat_tile<3, 1, WFAT_R(16), DBG>(v, m_begin, m_end, nb * 384, kb * 128, split, kb == 0, smem); break;
+#endif
+    case 1: wgrad_fat_tile<2, 1, WFAT_R(12), DBG>(v, m_begin, m_end, nb * 256, kb * 128, split, kb == 0, smem); break;
+    case 2: wgrad_fat_tile<1, 2, WFAT_R(12), DBG>(v, m_begin, m_end, nb * 128, kb * 256, split, kb == 0, smem); break;
+    default: wgrad_fat_tile<1, 1, WFAT_R(8), DBG>(v, m_begin, m_end, nb * 128, kb * 128, split, kb == 0, smem); break;
+  }
+}
+
+static int wfat_pick(int N, int K) {
+  int best = -1;
+  long long bc = 0;
+#ifdef WFAT_TYPE0
+  const int t0 = 0;
+#else
+  const int t0 = 1;           // without the 384 x 128 tile (192 accumulator registers: one wave per SIMD and nothing else on the CU)
+#endif
+  for (int t = t0; t < 4; ++t) {
+    const int TN = 128 * WFAT_TYPES[t].tnb, TK = 128 * WFAT_TYPES[t].tkb;
+    if (N % TN || K % TK) continue;
+    const long long c = (long long)(N / TN) * (K / TK) * (TN + TK);          // bf16 elements read per row
+    if (best < 0 || c < bc) { best = t; bc = c; }
+  }
+  return best;
+}
+// the launch geometry: a function of the jobs' shapes and the workgroup budget ONLY (the size query and the launch are handed the
+// same `blocks`, so they cannot disagree; the launch checks the capacity it is given all the same)
+static bool wfat_geometry(const ltu_wgrad_job* jobs, int njobs, int blocks, WFatArgs& fa, long long* part_off, long long* ws_floats,
+                          int* grid) {
+  if (njobs < 1 || njobs > LTU_WGRAD_GROUP_MAX || !ring_enabled() || ltu_knob("LTU_NO_WGROUP", 0)) return false;
+  const int budget = blocks > 0 ? blocks : ltu_knob_pos("LTU_WGROUP_BLOCKS", 256);
+  double total = 0.0;
+  for (int i = 0; i < njobs; ++i) {
+    const ltu_wgrad_job& j = jobs[i];
+    if (!tn_ring_shape_ok(j.M, j.N, j.K) || j.lda % 8 || j.ldg % 8 || j.nw < 1 || j.nw > 3 || j.N % j.nw || (j.N / j.nw) % 32) return false;
+    if (((uintptr_t)j.a | (uintptr_t)j.grad) & 15) return false;
+    const int t = wfat_pick(j.N, j.K);
+    if (t < 0) return false;
+    WFatJob& f = fa.j[i];
+    f.type = (short)t;
+    f.nt = (short)(j.N / (128 * WFAT_TYPES[t].tnb));
+    f.kt = (short)(j.K / (128 * WFAT_TYPES[t].tkb));
+    total += (double)f.nt * f.kt * (WFAT_TYPES[t].tnb + WFAT_TYPES[t].tkb) * (double)j.M;
+  }
+  const double target = total / budget;                       // (128-column block x row) units one workgroup should stream
+  const bool no_direct = ltu_knob("LTU_WGROUP_NO_DIRECT", 0) != 0;
+  long long off = 0;
+  int wg = 0;
+  fa.njobs = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const ltu_wgrad_job& j = jobs[i];
+    WFatJob& f = fa.j[i];
+    const double w = (double)(WFAT_TYPES[f.type].tnb + WFAT_TYPES[f.type].tkb) * (double)j.M;
+    long long ns = (long long)(w / target + 0.5);
+    const long long maxs = j.M / 128;                         // splits of >= 128 rows
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    long long rows = ((j.M + ns - 1) / ns + 31) / 32 * 32;
+    ns = (j.M + rows - 1) / rows;
+    if (ns > 32767) return false;
+    f.M = j.M; f.N = j.N; f.K = j.K; f.ldg = j.ldg; f.lda = j.lda; f.nper = j.N / j.nw;
+    f.rows = (int)rows; f.nsplit = (short)ns;
+    f.direct = (short)(ns == 1 && !no_direct);
+    f.pad = 0;
+    f.wg_begin = wg;
+    const int tiles = f.nt * f.kt;
+    const int n_wg = ns >= 8 ? (int)((ns + 7) / 8) * 8 * tiles : (int)ns * tiles;
+    wg += (n_wg + 7) / 8 * 8;
+    part_off[i] = off;
+    if (!f.direct) off += ns * (long long)j.N * ((long long)j.K + 1);
+  }
+  *ws_floats = off > 0 ? off : 4;                             // a non-zero size keeps "0 = not handled" of the C-ABI
+  *grid = wg;
+  return true;
+}
+static bool wfat_enabled() { return ltu_knob("LTU_WGROUP_FAT", 0) != 0; }
+long long wgrad_fat_group_ws_floats(const ltu_wgrad_job* jobs, int njobs, int blocks) {
+  WFatArgs fa;
+  long long n = 0, off[LTU_WGRAD_GROUP_MAX];
+  int grid = 0;
+  return wfat_geometry(jobs, njobs, blocks, fa, off, &n, &grid) ? n : 0;
+}
+// LTU_OK / hipError, 1 = group not handled, LTU_E_ARG = the workspace is smaller than this geometry needs
+int launch_wgrad_fat_group_bf16(const ltu_wgrad_job* jobs, int njobs, int blocks, float* ws, long long ws_floats, hipStream_t st) {
+  WFatArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  long long n = 0, off[LTU_WGRAD_GROUP_MAX];
+  int grid = 0;
+  if (ws == nullptr || !wfat_geometry(jobs, njobs, blocks, fa, off, &n, &grid)) return 1;
+  if (n > ws_floats) return LTU_E_ARG;
+  WFoldArgs fo;
+  memset(&fo, 0, sizeof(fo));
+  int fblocks = 0, nf = 0;
+  for (int i = 0; i < njobs; ++i) {
+    WFatJob& j = fa.j[i];
+    j.grad = reinterpret_cast<const uint16_t*>(jobs[i].grad);
+    j.x = reinterpret_cast<const uint16_t*>(jobs[i].a);
+    j.part = ws + off[i];
+    for (int s = 0; s < 3; ++s) { j.out[s] = s < jobs[i].nw ? jobs[i].dw[s] : nullptr; j.outb[s] = s < jobs[i].nw ? jobs[i].db[s] : nullptr; }
+    if (j.direct) continue;
+    WFoldJob& f = fo.j[nf++];
+    f.part = j.part; f.nsplit = j.nsplit; f.N = j.N; f.K = j.K; f.nseg = jobs[i].nw;
+    for (int s = 0; s < 3; ++s) { f.out[s] = j.out[s]; f.outb[s] = j.outb[s]; }
+    f.blk_begin = fblocks;
+    f.wblocks = (int)(((long long)j.N * j.K / 4 + 63) / 64);
+    fblocks += f.wblocks + (j.N + 63) / 64;
+  }
+  fo.njobs = nf;
+  static LtuDevOnce attr_once;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
+#ifdef LTU_EXPERIMENTS
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
+#endif
+  }
+#ifdef LTU_EXPERIMENTS
+  const int dbg = ltu_knob("LTU_WFAT_DBG", 0);     // ablation: 1 = no fragment reads / MFMAs, 2 = no LDS-DMA (results invalid)
+  if (dbg == 1) hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<1>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
+  else if (dbg == 2) hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<2>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
+  else if (dbg == 3) hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<3>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
+  else
+#endif
+  hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<0>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
+  if (nf > 0) hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fo);
   return ltu_check_launch();
 }

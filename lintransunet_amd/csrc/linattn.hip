@@ -1045,18 +1045,25 @@ extern "C" int ltu_linattn_splits(int B, int N) {
   } while (0)
 
 extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws,
-                               int B, int N, int d, int dtype, ltu_stream_t s);
+                               long long ws_floats, int B, int N, int d, int dtype, ltu_stream_t s);
+// floats of part_ws that ltu_linattn_fwd / _ctx / _bwd need for this shape (the same split count the launches pick)
+extern "C" long long ltu_linattn_ws_floats(int B, int N, int d) {
+  int tps;
+  const long long ns = pick_splits(B, N, d, &tps), H = d / 32;
+  return (long long)B * (ns + (ns + KVC_GROUP - 1) / KVC_GROUP + 2) * H * PART_STRIDE;
+}
 // phase A alone (online softmax over the tokens + context, merged): for callers that run phase B themselves
 // (ltu_layer_tail_fwd with its qkv argument: the chain kernel applies the context to its own row block)
-extern "C" int ltu_linattn_ctx(const void* qkv, float* ctx, float* colstats, float* part_ws, int B, int N, int d, int dtype,
-                               ltu_stream_t s) {
-  return ltu_linattn_fwd(qkv, nullptr, ctx, colstats, nullptr, part_ws, B, N, d, dtype, s);
+extern "C" int ltu_linattn_ctx(const void* qkv, float* ctx, float* colstats, float* part_ws, long long ws_floats, int B, int N, int d,
+                               int dtype, ltu_stream_t s) {
+  return ltu_linattn_fwd(qkv, nullptr, ctx, colstats, nullptr, part_ws, ws_floats, B, N, d, dtype, s);
 }
 extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* colstats, float* qstat, float* part_ws,
-                               int B, int N, int d, int dtype, ltu_stream_t s) {
+                               long long ws_floats, int B, int N, int d, int dtype, ltu_stream_t s) {
   const int H = d / 32;
   int tps;
   const int nsplit = pick_splits(B, N, d, &tps);
+  if ((long long)B * (nsplit + (nsplit + KVC_GROUP - 1) / KVC_GROUP + 2) * H * PART_STRIDE > ws_floats) return LTU_E_ARG;
   hipStream_t st = (hipStream_t)s;
   const int tokb = pick_tokb(B, N, d);
   LTU_DISPATCH_T(dtype, {
@@ -1096,11 +1103,12 @@ extern "C" int ltu_linattn_fwd(const void* qkv, void* out, float* ctx, float* co
 }
 
 extern "C" int ltu_linattn_bwd(const void* qkv, const void* dout, const float* ctx, const float* colstats,
-                               const float* qstat, void* dqkv, float* dctx, float* tvec, float* part_ws, int B, int N,
-                               int d, int dtype, ltu_stream_t s) {
+                               const float* qstat, void* dqkv, float* dctx, float* tvec, float* part_ws, long long ws_floats, int B,
+                               int N, int d, int dtype, ltu_stream_t s) {
   const int H = d / 32;
   int tps;
   const int nsplit = pick_splits(B, N, d, &tps);
+  if ((long long)B * nsplit * H * 1024 > ws_floats) return LTU_E_ARG;
   hipStream_t st = (hipStream_t)s;
   const size_t lds_b = (size_t)(32 * (3 * d + 4) + 32 * (d + 4) + H * 96) * sizeof(float);
   const int tokb = pick_tokb(B, N, d);

@@ -304,11 +304,13 @@ static long long loss_rows(int B, long long S) {
 }
 extern "C" long long ltu_loss_ws_floats(int B, long long S, int C) { return (1 + cdiv(S, loss_rows(B, S))) * (long long)B * C * 4; }
 
-extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, float* values, float* coef, int B, long long S, int C,
+extern "C" int ltu_loss_fwd(const float* p, const uint8_t* label, float* sums, long long sums_floats, float* values, float* coef, int B, long long S,
+                            int C,
                             float w_ce, float w_bal, const float* w_dice, const float* scale_dev, ltu_stream_t s) {
   if (C < 1 || C > LOSS_MAXC || B * C * 4 > 256) return LTU_E_SHAPE;
   const long long rows = loss_rows(B, S);
   const int nblk = (int)cdiv(S, rows);
+  if ((1 + (long long)nblk) * B * C * 4 > sums_floats) return LTU_E_ARG;          // the scratch is shorter than this geometry needs
   LossCfg cfg;
   cfg.w_ce = w_ce; cfg.w_bal = w_bal;
   for (int c = 0; c < LOSS_MAXC; ++c) cfg.w_dice[c] = (c < C && w_dice) ? w_dice[c] : 0.f;

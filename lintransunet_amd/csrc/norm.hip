@@ -956,8 +956,10 @@ static void launch_in_apply(const void* x, float* sums, const void* res, void* y
                      S, C, act, slope, p, seed, step, ws, nchunks);
 }
 
-extern "C" int ltu_instnorm_stats(const void* x, float* sums, float* ws, int B, long long S, int C, int dtype, ltu_stream_t s) {
+extern "C" int ltu_instnorm_stats(const void* x, float* sums, float* ws, long long ws_floats, int B, long long S, int C, int dtype,
+                                  ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  if (ws != nullptr && ws_floats < LTU_NORM_WS_FLOATS) return LTU_E_ARG;
   {
     int nit = 0;
     const int nthr = in_small_plan(dtype, S, C, &nit);
@@ -1004,9 +1006,10 @@ extern "C" int ltu_instnorm_apply(const void* x, const float* sums, const void* 
 
 // statistics + apply in one call: sums [B][C][3] (zero on entry) receives the statistics for the backward pass.  When the shape
 // qualifies the statistics kernel's partials are folded by the apply kernel itself (no fold launch in between).
-extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const void* res, void* y, int B, long long S, int C, int act,
-                                float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, long long ws_floats, const void* res, void* y, int B, long long S, int C,
+                                int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  if (ws != nullptr && ws_floats < LTU_NORM_WS_FLOATS) return LTU_E_ARG;
   {
     int nit = 0;
     const int nthr = in_small_plan(dtype, S, C, &nit);
@@ -1024,7 +1027,7 @@ extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const voi
   const int vw = in_vw(dtype, C);
   int nchunks = 0, rows = 0;
   if (!in_fold_plan(S, B, C, vw, ws, &nchunks, &rows)) {
-    const int rc = ltu_instnorm_stats(x, sums, ws, B, S, C, dtype, s);
+    const int rc = ltu_instnorm_stats(x, sums, ws, ws_floats, B, S, C, dtype, s);
     return rc != LTU_OK ? rc : ltu_instnorm_apply(x, sums, res, y, B, S, C, act, slope, p, seed, step, dtype, s);
   }
 #ifdef LTU_EXPERIMENTS
@@ -1039,10 +1042,11 @@ extern "C" int ltu_instnorm_fwd(const void* x, float* sums, float* ws, const voi
 }
 
 extern "C" int ltu_instnorm_bwd(const void* dy, const void* dy2, const void* dy3, const void* x, const float* sums, float* bsums,
-                                float* ws, void* dx, int B,
+                                float* ws, long long ws_floats, void* dx, int B,
                                 long long S, int C, int act, float slope, float p, uint64_t seed, const uint64_t* step, int dtype,
                                 ltu_stream_t s) {
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return LTU_E_SHAPE;
+  if (ws != nullptr && ws_floats < LTU_NORM_WS_FLOATS) return LTU_E_ARG;
   {
     int nit = 0;
     const int nthr = in_small_plan(dtype, S, C, &nit);
@@ -1125,8 +1129,8 @@ extern "C" int ltu_layernorm_fwd(const void* x, void* r, const float* gamma, con
 }
 
 extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z, const float* stat, const float* gamma, void* dz, void* dr,
-                                 float* dgamma, float* dbeta, float* ws, ltu_reduce_job* defer, long long M, int d, float p,
-                                 uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+                                 float* dgamma, float* dbeta, float* ws, long long ws_floats, ltu_reduce_job* defer, long long M, int d,
+                                 float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
   if (defer != nullptr) defer->part = nullptr;
   LTU_DISPATCH_T(dtype, {
     LN_DISPATCH_GV(d, {
@@ -1136,7 +1140,7 @@ extern "C" int ltu_layernorm_bwd(const void* dy, const void* dy2, const void* z,
       rows = (rows + nrg - 1) / nrg * nrg;
       const size_t lds = (size_t)nrg * d * 2 * sizeof(float);
       const int nblk = cdiv(M, rows);
-      if ((long long)nblk * d * 2 > LTU_NORM_WS_FLOATS) ws = nullptr;
+      if (ws != nullptr && (long long)nblk * d * 2 > ws_floats) return LTU_E_ARG;     // [nblk][2 d] partial rows
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, G, V>), dim3(nblk), dim3(256), lds, (hipStream_t)s, (const T*)dy, (const T*)dy2,
                          (const T*)z, stat, gamma, (T*)dz, (T*)dr, dgamma, dbeta, ws, M, (int)rows, p, seed, step);
       if (ws != nullptr && defer != nullptr) {

@@ -666,8 +666,9 @@ extern "C" int ltu_gate_fwd(const void* u1, const void* u2, const float* sums1, 
 
 extern "C" int ltu_gate_bwd(const void* dout, const void* u1, const void* u2, const float* sums1, const float* sums2,
                             const float* psi_w, const void* skip, const float* a_in, void* dskip, float* ds_ws, float* dpsi_w,
-                            float* dpsi_b, float* bs1, float* bs2, float* ws, void* du1, void* du2, int B, long long S, int C,
-                            int dtype, ltu_stream_t s) {
+                            float* dpsi_b, float* bs1, float* bs2, float* ws, long long ws_floats, void* du1, void* du2, int B, long long S,
+                            int C, int dtype, ltu_stream_t s) {
+  if (ws != nullptr && ws_floats < ltu_norm_ws_floats()) return LTU_E_ARG;
   // ws: ltu_norm_ws_floats() floats of workspace for the two-stage reduction, or NULL (atomics)
   LTU_DISPATCH_T(dtype, {
     GATE_DISPATCH_G(C, {
@@ -1036,8 +1037,10 @@ extern "C" int ltu_dwconv_fwd(const void* x, const float* w, const float* bias, 
   return ltu_check_launch();
 }
 extern "C" int ltu_dwconv_bwd(const void* dy, const void* dy2, const void* x, const float* w, void* dx, float* dwt, float* db, float* ws,
-                              int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype, ltu_stream_t s) {
+                              long long ws_floats, int B, int H, int W, int D, int C, float p, uint64_t seed, const uint64_t* step, int dtype,
+                              ltu_stream_t s) {
   if (C % 4 || (dtype == LTU_BF16 && C % 8)) return LTU_E_SHAPE;
+  if (ws != nullptr && dwt != nullptr && ws_floats < ltu_dwconv_bwd_ws_floats(B, H, W, D, C, dtype)) return LTU_E_ARG;
   LTU_DISPATCH_T(dtype, {
     // either half may be left out (dx NULL: weight / bias gradient only; dwt NULL: data gradient only): the weight gradient is off
     // the data-gradient chain and the caller may issue it later, on another stream

@@ -786,9 +786,10 @@ extern "C" long long ltu_trilinear_adjoint_ws_elems(int B, int H, int W, int D, 
   return (sd == 2 ? 2 * t2 + t2 : t2) + (long long)(H + W + D + 1) * 64 + (long long)((H + 1) / 2 + (W + 1) / 2 + (D + 1) / 2 + 2) * 64;
 }
 
-extern "C" int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, int B, int H, int W, int D, int C, int sd,
-                                     int dtype, ltu_stream_t s) {
+extern "C" int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, void* ws, long long ws_elems, int B, int H, int W, int D, int C,
+                                     int sd, int dtype, ltu_stream_t s) {
   if (C % 4 || (dtype == LTU_BF16 && C % 8) || (sd != 1 && sd != 2) || ws == nullptr) return LTU_E_SHAPE;
+  if (ws_elems < ltu_trilinear_adjoint_ws_elems(B, H, W, D, C, sd)) return LTU_E_ARG;
   const int Ho = 2 * H, Wo = 2 * W, Do = sd * D;
   if ((long long)B * Ho * Wo * D >= (1LL << 31)) return LTU_E_SHAPE;
   hipStream_t st = (hipStream_t)s;

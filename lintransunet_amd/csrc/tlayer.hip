@@ -692,12 +692,13 @@ extern "C" long long ltu_layer_tail_blocks(long long M) { return (M + TL_ROWS - 
 extern "C" int ltu_layer_tail_bwd(const void* dy, const void* dy2, const void* z2, const void* z1, const void* u, const float* stat2,
                                   const float* stat1, const float* g2, const float* g1, const void* w2t, const void* w1t,
                                   const void* wot, void* dr2, void* du, void* dr1, void* dz1, void* da, float* lnws2, float* lnws1,
-                                  long long M, int d, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step,
+                                  long long lnws_floats, long long M, int d, float p, uint64_t seed1, uint64_t seedg, uint64_t seed2, const uint64_t* step,
                                   int u_mode, int dtype, ltu_stream_t s) {
   if (dtype != LTU_BF16) return LTU_E_DTYPE;
   if (d != 128 && d != 256) return LTU_E_SHAPE;
   if (u_mode != 0 && u_mode != 1) return LTU_E_ARG;
   if (M <= 0) return LTU_OK;
+  if (lnws_floats < ltu_layer_tail_blocks(M) * 2 * d) return LTU_E_ARG;       // capacity of EACH of lnws2 / lnws1
   TailBwdArgs ta;
   ta.u_mode = u_mode;
   ta.dy = (const uint16_t*)dy; ta.dy2 = (const uint16_t*)dy2; ta.z2 = (const uint16_t*)z2; ta.z1 = (const uint16_t*)z1;

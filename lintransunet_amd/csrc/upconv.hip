@@ -78,7 +78,7 @@ extern "C" int ltu_upconv_fwd(const void* x, const void* wsub_f, const float* bi
 
 // dx[v] = sum over (class, slot) of g[2v + (p - 2 off)] . Weff[class][slot]^T      (wsub_d [Ci][64][Co])
 extern "C" int ltu_upconv_dgrad(const void* grad, const void* wsub_d, void* dx, int B, int H, int W, int D, int Ci, int Co,
-                                float* ws, int dtype, ltu_stream_t s) {
+                                float* ws, long long ws_floats, int dtype, ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
   if (dtype == LTU_BF16 && !ltu_knob("LTU_NO_UPDGRAD_RING", 0)) {      // class-planar halo kernel (updgrad_ring.hip)
     const int hr = launch_updgrad_ring_bf16(grad, wsub_d, dx, B, H, W, D, Ci, Co, (hipStream_t)s);
@@ -105,7 +105,7 @@ extern "C" int ltu_upconv_dgrad(const void* grad, const void* wsub_d, void* dx, 
   g.w[0] = wsub_d;
   g.out_identity = 1;
   g.n0 = Ci; g.o0 = dx; g.o1 = dx; g.ldo0 = Ci; g.ldo1 = Ci;
-  g.part = dtype == LTU_BF16 ? ws : nullptr;     // small grids split the 64*Co-long K loop (ltu_igemm_ws_floats(B*H*W*D, Ci, 64*Co))
+  g.part = dtype == LTU_BF16 ? ws : nullptr; g.part_floats = ws_floats;     // small grids split the 64*Co-long K loop (ltu_igemm_ws_floats(B*H*W*D, Ci, 64*Co))
   return run_nt(g, dtype, (hipStream_t)s);
 }
 
@@ -133,13 +133,14 @@ __global__ void upconv_fold_kernel(const float* __restrict__ dweff, float* __res
 
 // dweff [8][Co][8][Ci] must be zero-filled by the caller; dw_torch [co_real][ci_real][27] and db are accumulated (+=)
 extern "C" int ltu_upconv_wgrad(const void* grad, const void* x, float* dweff, float* db, float* dw_torch, int co_real,
-                                int ci_real, float* ws, int B, int H, int W, int D, int Ci, int Co, int dtype, ltu_stream_t s) {
+                                int ci_real, float* ws, long long ws_floats, int blocks, int B, int H, int W, int D, int Ci, int Co, int dtype,
+                                ltu_stream_t s) {
   if (Ci % 4 || Co % 4) return LTU_E_SHAPE;
   if (dtype == LTU_BF16 && ws != nullptr && !ltu_knob("LTU_NO_CLASS_HALO", 0)) {
     // all classes and taps from LDS halo bricks, folded in registers; the reduce kernel writes the PyTorch layout
     UpWgradArgs u;
     memset(&u, 0, sizeof(u));
-    u.x = x; u.grad = grad; u.B = B; u.H = H; u.W = W; u.D = D; u.Ci = Ci; u.Co = Co; u.part = ws;
+    u.x = x; u.grad = grad; u.B = B; u.H = H; u.W = W; u.D = D; u.Ci = Ci; u.Co = Co; u.part = ws; u.part_floats = ws_floats; u.blocks = blocks;
     int nsplit = 0;
     const int hr = launch_upconv_wgrad_class_bf16(u, &nsplit, (hipStream_t)s);
     if (hr == LTU_OK) {
@@ -149,7 +150,7 @@ extern "C" int ltu_upconv_wgrad(const void* grad, const void* x, float* dweff, f
       g.N = Co; g.C = Ci; g.c0 = Ci; g.K = 27 * Ci; g.wrow = 27 * Ci; g.ntaps = 27;
       for (int t = 0; t < 27; ++t) g.tap[t] = Tap{0, 0, 0, (int8_t)t};
       wa.dw = dw_torch; wa.db = db; wa.t_co = co_real; wa.t_ci = ci_real; wa.nseg_w = 1;
-      wa.part = ws; wa.npad = Co; wa.kpad = 27 * Ci;
+      wa.part = ws; wa.part_floats = ws_floats; wa.npad = Co; wa.kpad = 27 * Ci;
       wa.bpart = ws + (long long)nsplit * Co * wa.kpad;
       return launch_wgrad_reduce(wa, nsplit, (hipStream_t)s);
     }
@@ -182,20 +183,20 @@ extern "C" int ltu_upconv_wgrad(const void* grad, const void* x, float* dweff, f
     wa.db = db;
     wa.nseg_w = 1;
     int rc;
-    if (dtype == LTU_BF16) { wa.part = ws; rc = launch_tn_bf16(wa, (hipStream_t)s); }
+    if (dtype == LTU_BF16) { wa.part = ws; wa.part_floats = ws_floats; rc = launch_tn_bf16(wa, (hipStream_t)s); }
     else if (dtype == LTU_F32) rc = launch_tn_f32(wa, (hipStream_t)s);
     else return LTU_E_DTYPE;
     if (rc) return rc;
   }
   const long long n = (long long)co_real * ci_real * 27;
-  long long blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(upconv_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, dweff, dw_torch, co_real, ci_real, Co, Ci);
+  long long fblocks = (n + 255) / 256;
+  if (fblocks > 4096) fblocks = 4096;
+  hipLaunchKernelGGL(upconv_fold_kernel, dim3((unsigned)fblocks), dim3(256), 0, (hipStream_t)s, dweff, dw_torch, co_real, ci_real, Co, Ci);
   return ltu_check_launch();
 }
 
 // workspace (floats) ltu_upconv_wgrad needs for M coarse voxels
-extern "C" long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci) {
-  const long long a = ltu_wgrad_ws_floats(M, Co, 8 * Ci), b = upconv_wgrad_class_ws_floats(Ci, Co);
+extern "C" long long ltu_upconv_wgrad_ws_floats(long long M, int Co, int Ci, int blocks) {
+  const long long a = ltu_wgrad_ws_floats(M, Co, 8 * Ci), b = upconv_wgrad_class_ws_floats(Ci, Co, blocks);
   return a > b ? a : b;
 }

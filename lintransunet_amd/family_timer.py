@@ -30,7 +30,7 @@ NO_LAUNCH = ('ltu_roi_plan_size', 'ltu_config_set', 'ltu_version', 'ltu_comm_')
 # host pointers passed as integers: (argument index of the array, index of its length, element type) - copied when recorded
 HOST_ARRAYS = {'ltu_linear_wgrad_group': (0, 1, _lib.WgradJob), 'ltu_reduce_batch': (0, 1, _lib.ReduceJob)}
 # host OUTPUT structs (a deferred-fold descriptor the call fills): replaced by a scratch struct at replay
-HOST_OUT = {'ltu_linear_wgrad': 11, 'ltu_layernorm_bwd': 10}
+HOST_OUT = {'ltu_linear_wgrad': 12, 'ltu_layernorm_bwd': 11}
 
 # SURVEY 8d, forward, per 128^3 patch: (GB, GFLOP); 96^3 in brackets there.  `transformer` = Linear + LayerNorm + linear-attention
 # core + 1x1x1 convs (the chain kernels fuse them); `conv3` = 3x3x3 convs + the nearest upsampling fused into the un-embedding.

@@ -49,6 +49,11 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _n(t):
+    """capacity (elements) of a workspace tensor handed to the C-ABI beside its pointer; 0 for None"""
+    return 0 if t is None else t.numel()
+
+
 def _chk(t, name='tensor'):
     if not t.is_cuda:
         raise _lib.LtuError(f'{name} must live on the GPU: the HIP path has no CPU fallback')
@@ -182,26 +187,33 @@ class Context:
         if not jobs:
             return
         self.wg_group, self.wg_bytes, self.wg_layers = [], 0, 0
-        self.wq_push(lambda keep: self._wgrad_group_launch(jobs, keep), [t for j in jobs for t in j[:2]])
+        self.wq_push(lambda keep: self._wgrad_group_launch(jobs, keep), [t for j in jobs for t in j[:2]], 'group')
 
-    @staticmethod
-    def _wgrad_group_launch(jobs, keep):
+    def side_width(self):
+        """workgroup budget of the weight-gradient kernels that take one (ltu_linear_wgrad_group, ltu_upconv_wgrad): the width the
+        owner of the weight-gradient queue asked for while a queue is installed (train.GraphedStep: half the machine, its side
+        stream runs beside the main chain), 0 = the library's stand-alone default otherwise.  An ARGUMENT of the size query and of
+        the launch - not a process-wide knob that the two could read at different values (round 4's workspace overrun)."""
+        return 0 if self.wq is None else int(self.wq.get('width', 0))
+
+    def _wgrad_group_launch(self, jobs, keep):
         arr = (_lib.WgradJob * len(jobs))()
         for r, (g, x, dws, dbs, M, N, K) in zip(arr, jobs):
             r.grad, r.a, r.ldg, r.lda, r.nw, r.M, r.N, r.K = g.data_ptr(), x.data_ptr(), N, K, len(dws), M, N, K
             for i, (dw, db) in enumerate(zip(dws, dbs)):
                 r.dw[i], r.db[i] = dw.data_ptr(), db.data_ptr()
         lib = _lib.load()
-        n = lib.ltu_linear_wgrad_group_ws_floats(ctypes.addressof(arr), len(jobs))
+        blocks = self.side_width()
+        n = lib.ltu_linear_wgrad_group_ws_floats(ctypes.addressof(arr), len(jobs), blocks)
         if n > 0:
             ws = torch.empty(n, device=jobs[0][0].device, dtype=torch.float32)
             keep.append(ws)
-            _lib.call('ltu_linear_wgrad_group', ctypes.addressof(arr), len(jobs), _p(ws), BF16, _s())
+            _lib.call('ltu_linear_wgrad_group', ctypes.addressof(arr), len(jobs), blocks, _p(ws), n, BF16, _s())
             return
         for g, x, dws, dbs, M, N, K in jobs:            # shapes the grouped kernel does not take: one call each
             wsb = _wgrad_ws(M, N, K, x)
             keep.append(wsb)
-            _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(dws), M, N, K, _p(wsb), 0,
+            _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(dws), M, N, K, _p(wsb), _n(wsb), 0,
                       _dt(x), _s())
 
     def _fold_flush(self):
@@ -213,7 +225,7 @@ class Context:
         def launch(keep, jobs=jobs):
             arr = (_lib.ReduceJob * len(jobs))(*[j for j, _ in jobs])
             _lib.call('ltu_reduce_batch', ctypes.addressof(arr), len(jobs), _s())
-        self.wq_push(launch, [ws for _, ws in jobs])
+        self.wq_push(launch, [ws for _, ws in jobs], 'fold')
 
     def flush_deferred(self):
         """fold every pending partial-sum workspace into its gradient and launch every weight gradient still held back
@@ -230,12 +242,12 @@ class Context:
     # no graph contains a fork: a fork inside a replayed graph costs more than it gains on ROCm 7).
     # Operands and workspaces of a batch stay alive until `wq_join` (the main stream has waited for the side stream): nothing
     # the main chain allocates meanwhile can land on memory a batch still reads.
-    def wq_install(self, side_stream, on_flush=None, on_join=None):
+    def wq_install(self, side_stream, on_flush=None, on_join=None, width=0):
         """side_stream None uninstalls.  on_flush(run): called instead of issuing a batch on the side stream (run() issues it on the
         current stream - the caller brackets it with its own capture); on_join(): called instead of making the current stream wait
-        for the side stream (`side_join`)"""
+        for the side stream (`side_join`); width: workgroup budget of the queued kernels that take one (`side_width`)"""
         self.wq = None if side_stream is None else {'side': side_stream, 'jobs': [], 'keep': [], 'on_flush': on_flush, 'on_join': on_join,
-                                                    'running': False, 'batches': 0, 'side_pending': False, 'after': []}
+                                                    'running': False, 'batches': 0, 'side_pending': False, 'after': [], 'width': int(width)}
 
     # -- forward-side work on the same side stream: what the first kernels of the step do not need yet (the weight operands of
     # everything behind the encoder, the label pyramid) runs beside the encoder; `side_join` is placed in front of its first consumer
@@ -263,9 +275,17 @@ class Context:
         else:
             torch.cuda.current_stream().wait_stream(q['side'])
 
-    def wq_push(self, fn, tensors=()):
-        """fn(keep): launches weight-gradient kernels on the current stream, appending the workspaces it allocates to `keep`"""
+    def wq_push(self, fn, tensors=(), fam=''):
+        """fn(keep): launches weight-gradient kernels on the current stream, appending the workspaces it allocates to `keep`;
+        fam: which family of weight gradients this is (WQ_INLINE lists families that are launched in line instead)"""
         q = self.wq
+        if q is not None and not q['running'] and fam in WQ_INLINE:       # experiment: this family in line, at its stand-alone width
+            w, q['width'] = q['width'], 0
+            try:
+                fn(q['keep'])
+            finally:
+                q['width'] = w
+            return
         if q is None or q['running']:
             fn(q['keep'] if q is not None else [])
             return
@@ -431,6 +451,7 @@ GROUP_WGRAD = True       # per-layer grouped projection weight gradients (ltu_li
 import os as _os
 WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '400'))     # operand bytes of the layers' weight-gradient groups launched together
 WQ_MAX_JOBS = int(_os.environ.get('LTU_WQ_JOBS', '1000000'))      # weight-gradient queue: a batch goes out when this many launches are queued
+WQ_INLINE = frozenset(f for f in _os.environ.get('LTU_WQ_INLINE', '').split(',') if f)      # families of weight gradients kept off the queue
 WQ_SIDE_FWD = _os.environ.get('LTU_WQ_FWD', '1') == '1'      # forward-side work (weight operands behind the encoder, label pyramid) on the side stream
 WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
 WQ_SCHEDULE = _os.environ.get('LTU_WQ_SCHEDULE', 'end')     # weight-gradient queue: a batch where backward ENTERS ('start') / leaves ('end') a transformer
@@ -586,7 +607,7 @@ class _Conv3d(torch.autograd.Function):
         y = torch.empty((B, Ho, Wo, Do, cop), device=dev, dtype=x0.dtype)
         ws = _conv_ws(B, Ho, Wo, Do, CiP, cop, x0)
         _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias_p), _p(y), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd,
-                  int(ups), _p(ws), _dt(x0), _s())
+                  int(ups), _p(ws), _n(ws), _dt(x0), _s())
         ctx.save_for_backward(x0, x1)
         ctx.params = (weight, bias)
         ctx.cfg = (stride, ups, cop, C0, C1, prep)
@@ -617,7 +638,7 @@ class _Conv3d(torch.autograd.Function):
             d0 = torch.empty((B, Hl, Wl, Dl, C0), device=dev, dtype=x0.dtype)
             d1 = torch.empty((B, Hl, Wl, Dl, C1), device=dev, dtype=x0.dtype) if C1 else None
             ws = _conv_ws(B, Hl, Wl, Dl, cop, CiP, x0) if (sh, sw, sd) == (1, 1, 1) else None
-            _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(d0), _p(d1), B, Hl, Wl, Dl, C0, C1, cop, sh, sw, sd, _p(ws), dt, _s())
+            _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(d0), _p(d1), B, Hl, Wl, Dl, C0, C1, cop, sh, sw, sd, _p(ws), _n(ws), dt, _s())
             if ups:
                 dx0 = torch.empty_like(x0)
                 _lib.call('ltu_sumpool2', _p(d0), _p(dx0), B, Hi, Wi, Di, C0, dt, _s())
@@ -631,9 +652,9 @@ class _Conv3d(torch.autograd.Function):
             ws = _wgrad_ws(g.numel() // cop, cop, 27 * CiP, x0)
             keep.append(ws)
             _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, Hi, Wi, Di, C0, C1, cop, sh, sw, sd, int(ups),
-                      Co, Ci, _p(ws), dt, _s())
+                      Co, Ci, _p(ws), _n(ws), dt, _s())
         if fw and fb:
-            lc.wq_push(launch, (g, x0, x1))          # fused gradient buffers: nothing reads them before the end of the step
+            lc.wq_push(launch, (g, x0, x1), 'conv')          # fused gradient buffers: nothing reads them before the end of the step
         else:
             launch([])
         return dx0, dx1, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None, None, None, None
@@ -695,7 +716,7 @@ class _Conv3dPair(torch.autograd.Function):
         y0 = torch.empty((B, H, W, D, n0), device=x.device, dtype=x.dtype)
         y1 = torch.empty((B, H, W, D, n1), device=x.device, dtype=x.dtype)
         ws = _conv_ws(B, H, W, D, C, n0 + n1, x)
-        _lib.call('ltu_conv3d_pair_fwd', _p(x), _p(prep.wf), _p(prep.bias), _p(y0), _p(y1), B, H, W, D, C, n0, n1, _p(ws), _dt(x), _s())
+        _lib.call('ltu_conv3d_pair_fwd', _p(x), _p(prep.wf), _p(prep.bias), _p(y0), _p(y1), B, H, W, D, C, n0, n1, _p(ws), _n(ws), _dt(x), _s())
         ctx.save_for_backward(x)
         ctx.params = (wa, ba, wb, bb)
         ctx.prep = prep
@@ -716,7 +737,7 @@ class _Conv3dPair(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws = _conv_ws(B, H, W, D, n0 + n1, C, x)
-            _lib.call('ltu_conv3d_pair_dgrad', _p(g0), _p(g1), _p(prep.wd), _p(dx), B, H, W, D, C, n0, n1, _p(ws), dt, _s())
+            _lib.call('ltu_conv3d_pair_dgrad', _p(g0), _p(g1), _p(prep.wd), _p(dx), B, H, W, D, C, n0, n1, _p(ws), _n(ws), dt, _s())
         dwa, fwa = _grad_buf(wa)
         dba, fba = _grad_buf(ba)
         dwb, fwb = _grad_buf(wb)
@@ -725,9 +746,9 @@ class _Conv3dPair(torch.autograd.Function):
             ws = _wgrad_ws(g0.numel() // n0, n0 + n1, 27 * C, x)
             keep.append(ws)
             _lib.call('ltu_conv3d_pair_wgrad', _p(g0), _p(g1), _p(x), _p(dwa), _p(dba), _p(dwb), _p(dbb), B, H, W, D, C, n0, n1,
-                      wa.shape[0], wb.shape[0], wa.shape[1], _p(ws), dt, _s())
+                      wa.shape[0], wb.shape[0], wa.shape[1], _p(ws), _n(ws), dt, _s())
         if fwa and fba and fwb and fbb:
-            lc.wq_push(launch, (g0, g1, x))
+            lc.wq_push(launch, (g0, g1, x), 'pair')
         else:
             launch([])
         outs = [_grad_done(wa, dwa, fwa), _grad_done(ba, dba, fba), _grad_done(wb, dwb, fwb), _grad_done(bb, dbb, fbb)]
@@ -796,19 +817,20 @@ class _UpConv3d(torch.autograd.Function):
             dx = torch.empty_like(x)
             nws = _lib.load().ltu_igemm_ws_floats(B * H * W * D, Ci, 64 * Co) if x.dtype == torch.bfloat16 else 0
             wsd = torch.empty(nws, device=x.device, dtype=torch.float32) if nws > 0 else None
-            _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, _p(wsd), dt, _s())
+            _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, _p(wsd), _n(wsd), dt, _s())
         dw, fw = _grad_buf(weight)
         db, fb = _grad_buf(bias)
         dweff = lc.scratch_zeros((8, Co, 8, Ci), x.device)
 
         def launch(keep):
-            ws = None
+            ws, blocks = None, lc.side_width()
             if x.dtype == torch.bfloat16:
-                ws = torch.empty(_lib.load().ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci), device=x.device, dtype=torch.float32)
+                ws = torch.empty(_lib.load().ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci, blocks), device=x.device, dtype=torch.float32)
                 keep.append(ws)
-            _lib.call('ltu_upconv_wgrad', _p(g), _p(x), _p(dweff), _p(db), _p(dw), Co, Ci, _p(ws), B, H, W, D, Ci, Co, dt, _s())
+            _lib.call('ltu_upconv_wgrad', _p(g), _p(x), _p(dweff), _p(db), _p(dw), Co, Ci, _p(ws), _n(ws), blocks, B, H, W, D, Ci, Co, dt,
+                      _s())
         if fw and fb:
-            lc.wq_push(launch, (g, x))
+            lc.wq_push(launch, (g, x, dweff), 'upconv')      # dweff: read and written by the queued kernels (kept alive until the join)
         else:
             launch([])
         return dx, _grad_done(weight, dw, fw), _grad_done(bias, db, fb), None
@@ -874,8 +896,8 @@ class _Linear(torch.autograd.Function):
                 wsb = _wgrad_ws(M, N, K, x)
                 keep.append(wsb)
                 _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
-                          M, N, K, _p(wsb), 0, dt, _s())
-            lc.wq_push(launch, (g, x))
+                          M, N, K, _p(wsb), _n(wsb), 0, dt, _s())
+            lc.wq_push(launch, (g, x), 'lin')
             dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
             dbs = [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
             return (dx, None, *dws, *dbs)
@@ -884,7 +906,7 @@ class _Linear(torch.autograd.Function):
         # L2 / MALL (measured: a batched fold of 8 cold workspaces costs twice the 8 separate hot ones).
         job = _defer_job() if (DEFER_WGRAD and wsb is not None and all(f for _, f in gw) and all(f for _, f in gb)) else None
         _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([t for t, _ in gw]), _ptr_array([t for t, _ in gb]), nw,
-                  M, N, K, _p(wsb), ctypes.addressof(job) if job is not None else 0, dt, _s())
+                  M, N, K, _p(wsb), _n(wsb), ctypes.addressof(job) if job is not None else 0, dt, _s())
         if job is not None:
             lc.defer_push(job, wsb)
         dws = [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)]
@@ -940,12 +962,12 @@ class _LinearGelu(torch.autograd.Function):
         def launch(keep):
             wsb = _wgrad_ws(M, N, K, x)
             keep.append(wsb)
-            _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), 0, dt, _s())
+            _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(wsb), _n(wsb), 0, dt, _s())
         grp = ctx.prep.group if ctx.prep is not None else None
         if grp is not None and GROUP_WGRAD and x.dtype == torch.bfloat16 and fw and fb:
             lc.wgrad_group_push(g, x, [dw], [db], M, N, K, grp == 'flush')
         elif fw and fb:
-            lc.wq_push(launch, (g, x))
+            lc.wq_push(launch, (g, x), 'lin')
         else:
             launch([])
         return dx, None, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None
@@ -980,7 +1002,7 @@ class _InstNormAct(torch.autograd.Function):
         sums = lc.scratch_zeros((B, C, 3), x.device)
         dt = _dt(x)
         y = torch.empty_like(x)
-        _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(lc.norm_ws(x.device)), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed,
+        _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(lc.norm_ws(x.device)), _n(lc.norm_ws(x.device)), _p(res), _p(y), B, S, C, act, LRELU_SLOPE, float(p), seed,
                   lc.step_ptr(), dt, _s())
         ctx.save_for_backward(x, sums)
         ctx.cfg = (act, p, seed, res is not None, res_dup is not None)
@@ -996,7 +1018,7 @@ class _InstNormAct(torch.autograd.Function):
         S = x.numel() // (B * C)
         bsums = lc.scratch_zeros((B, C, 2), x.device)
         dx = torch.empty_like(x)
-        _lib.call('ltu_instnorm_bwd', _p(g), _p(g2), _p(g3), _p(x), _p(sums), _p(bsums), _p(lc.norm_ws(x.device)), _p(dx), B, S, C, act,
+        _lib.call('ltu_instnorm_bwd', _p(g), _p(g2), _p(g3), _p(x), _p(sums), _p(bsums), _p(lc.norm_ws(x.device)), _n(lc.norm_ws(x.device)), _p(dx), B, S, C, act,
                   LRELU_SLOPE, float(p), seed, lc.step_ptr(), _dt(x), _s())
         # the residual passes the output gradient through.  With two output ports and a duplicate residual port the two gradient
         # tensors travel on separately (the producer of the residual sums them on load); otherwise they have to be added here.
@@ -1058,7 +1080,7 @@ class _ResLayerNorm(torch.autograd.Function):
             job = _defer_job()
             ws = torch.empty(2048 * 2 * d, device=g.device, dtype=torch.float32)       # private: it outlives this call
         _lib.call('ltu_layernorm_bwd', _p(g), _p(g2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dgamma), _p(dbeta),
-                  _p(ws), ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, lc.step_ptr(), _dt(z), _s())
+                  _p(ws), _n(ws), ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, lc.step_ptr(), _dt(z), _s())
         if job is not None:
             lc.defer_push(job, ws)
         return dz, dr, _grad_done(gamma, dgamma, fg), _grad_done(beta, dbeta, fb), None, None, None, None
@@ -1113,8 +1135,9 @@ def _wgrad_now_or_group(lc, g, x, ws, bs, M, N, K):
     if GROUP_WGRAD and all(f for _, f in gw) and all(f for _, f in gb):
         lc.wgrad_group_push(g, x, dws, dbs, M, N, K, False)
     else:
+        wsb = _wgrad_ws(M, N, K, x)
         _lib.call('ltu_linear_wgrad', _p(g), N, _p(x), K, _ptr_array(dws), _ptr_array(dbs), len(ws), M, N, K,
-                  _p(_wgrad_ws(M, N, K, x)), 0, _dt(x), _s())
+                  _p(wsb), _n(wsb), 0, _dt(x), _s())
     return [_grad_done(w, t, f) for w, (t, f) in zip(ws, gw)], [_grad_done(b, t, f) for b, (t, f) in zip(bs, gb)]
 
 
@@ -1147,8 +1170,8 @@ class _LayerTail(torch.autograd.Function):
             cx = torch.empty((B * H, 32, 32), device=dev, dtype=torch.float32)
             colstats = torch.empty((B * H, 64), device=dev, dtype=torch.float32)
             qstat = torch.empty((M, H, 2), device=dev, dtype=torch.float32)
-            ws = torch.empty(B * (nsplit + nsplit // 16 + 2) * H * 1088, device=dev, dtype=torch.float32)
-            _lib.call('ltu_linattn_ctx', _p(qkv), _p(cx), _p(colstats), _p(ws), B, N, d, _dt(qkv), _s())
+            ws = torch.empty(_lib.load().ltu_linattn_ws_floats(B, N, d), device=dev, dtype=torch.float32)
+            _lib.call('ltu_linattn_ctx', _p(qkv), _p(cx), _p(colstats), _p(ws), _n(ws), B, N, d, _dt(qkv), _s())
             a = torch.empty((M, d), device=dev, dtype=dt)
         z1, t1, z2, y = (torch.empty((M, d), device=dev, dtype=dt) for _ in range(4))
         u, h = (torch.empty((M, 2 * d), device=dev, dtype=dt) for _ in range(2))
@@ -1196,8 +1219,9 @@ class _LayerTail(torch.autograd.Function):
                 if GROUP_WGRAD and all(f for _, f in gw) and all(f for _, f in gb):
                     lc.wgrad_group_push(gq, y, dws, dbs, M, 3 * d, d, True)
                 else:
+                    wsq = _wgrad_ws(M, 3 * d, d, y)
                     _lib.call('ltu_linear_wgrad', _p(gq), 3 * d, _p(y), d, _ptr_array(dws), _ptr_array(dbs), 3, M, 3 * d, d,
-                              _p(_wgrad_ws(M, 3 * d, d, y)), 0, dt, _s())
+                              _p(wsq), _n(wsq), 0, dt, _s())
                 nxt_grads = tuple(_grad_done(w, t, f) for w, (t, f) in zip(nws, gw)) + \
                     tuple(_grad_done(b, t, f) for b, (t, f) in zip(nbs, gb)) + (None,)
         if g is None:
@@ -1215,7 +1239,7 @@ class _LayerTail(torch.autograd.Function):
             if fg and fb:
                 job = _defer_job()
                 ws = torch.empty(2048 * 2 * d, device=dev, dtype=torch.float32)
-            _lib.call('ltu_layernorm_bwd', _p(gy), _p(gy2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(ws),
+            _lib.call('ltu_layernorm_bwd', _p(gy), _p(gy2), _p(z), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(ws), _n(ws),
                       ctypes.addressof(job) if job is not None else 0, M, d, float(p), seed, lc.step_ptr(), dt, _s())
             if job is not None:
                 lc.defer_push(job, ws)
@@ -1234,7 +1258,7 @@ class _LayerTail(torch.autograd.Function):
             nblk = _lib.load().ltu_layer_tail_blocks(M)
             lnws = torch.empty((2, nblk, 2 * d), device=dev, dtype=torch.float32)
             _lib.call('ltu_layer_tail_bwd', _p(g), _p(g2), _p(z2), _p(z1), _p(u), _p(stat2), _p(stat1), _p(gm2), _p(gm1), _p(p2.fragT),
-                      _p(p1.fragT), _p(po.fragT), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), M, d, float(p),
+                      _p(p1.fragT), _p(po.fragT), _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), _n(lnws[0]), M, d, float(p),
                       seeds[0], seeds[1], seeds[2], lc.step_ptr(), 1, dt, _s())
             outs = []
             for k, (gamma, beta) in enumerate(((gm2, be2), (gm1, be1))):
@@ -1276,8 +1300,8 @@ class _LayerTail(torch.autograd.Function):
         nsplit = _lib.load().ltu_linattn_splits(B, N)
         dqkv = torch.empty_like(qkv)
         dctx = torch.empty_like(cx)
-        ws = torch.empty(B * nsplit * H * 1088, device=da.device, dtype=torch.float32)
-        _lib.call('ltu_linattn_bwd', _p(qkv), _p(da), _p(cx), _p(colstats), _p(qstat), _p(dqkv), _p(dctx), 0, _p(ws), B, N, d,
+        ws = torch.empty(_lib.load().ltu_linattn_ws_floats(B, N, d), device=da.device, dtype=torch.float32)
+        _lib.call('ltu_linattn_bwd', _p(qkv), _p(da), _p(cx), _p(colstats), _p(qstat), _p(dqkv), _p(dctx), 0, _p(ws), _n(ws), B, N, d,
                   _dt(qkv), _s())
         return dqkv
 
@@ -1309,8 +1333,8 @@ class _LinAttn(torch.autograd.Function):
         cx = torch.empty((B * H, 32, 32), device=dev, dtype=torch.float32)
         colstats = torch.empty((B * H, 64), device=dev, dtype=torch.float32)
         qstat = torch.empty((B * N, H, 2), device=dev, dtype=torch.float32)
-        ws = torch.empty(B * (nsplit + nsplit // 16 + 2) * H * 1088, device=dev, dtype=torch.float32)
-        _lib.call('ltu_linattn_fwd', _p(qkv), _p(out), _p(cx), _p(colstats), _p(qstat), _p(ws), B, N, d, _dt(qkv), _s())
+        ws = torch.empty(_lib.load().ltu_linattn_ws_floats(B, N, d), device=dev, dtype=torch.float32)
+        _lib.call('ltu_linattn_fwd', _p(qkv), _p(out), _p(cx), _p(colstats), _p(qstat), _p(ws), _n(ws), B, N, d, _dt(qkv), _s())
         ctx.save_for_backward(qkv, cx, colstats, qstat)
         ctx.cfg = (B, N, d, nsplit)
         return out
@@ -1326,8 +1350,8 @@ class _LinAttn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dctx = torch.empty_like(cx)
         tvec = torch.empty((B * H, 32), device=dev, dtype=torch.float32)
-        ws = torch.empty(B * nsplit * H * 1088, device=dev, dtype=torch.float32)
-        _lib.call('ltu_linattn_bwd', _p(qkv), _p(g), _p(cx), _p(colstats), _p(qstat), _p(dqkv), _p(dctx), _p(tvec), _p(ws),
+        ws = torch.empty(_lib.load().ltu_linattn_ws_floats(B, N, d), device=dev, dtype=torch.float32)
+        _lib.call('ltu_linattn_bwd', _p(qkv), _p(g), _p(cx), _p(colstats), _p(qstat), _p(dqkv), _p(dctx), _p(tvec), _p(ws), _n(ws),
                   B, N, d, _dt(qkv), _s())
         return dqkv, None, None, None
 
@@ -1363,16 +1387,16 @@ class _PosConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, fw = _grad_buf(w)
         db, fb = _grad_buf(b)
-        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), 0, 0, 0, B, H, W, D, C, float(p), seed,
+        _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), _p(dx), 0, 0, 0, 0, B, H, W, D, C, float(p), seed,
                   lc.step_ptr(), _dt(x), _s())
 
         def launch(keep):                    # the weight / bias gradient: off the data-gradient chain
             ws = torch.empty(_lib.load().ltu_dwconv_bwd_ws_floats(B, H, W, D, C, _dt(x)), device=x.device, dtype=torch.float32)
             keep.append(ws)
-            _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), 0, _p(dw), _p(db), _p(ws), B, H, W, D, C, float(p), seed,
+            _lib.call('ltu_dwconv_bwd', _p(g), _p(g2), _p(x), _p(w), 0, _p(dw), _p(db), _p(ws), _n(ws), B, H, W, D, C, float(p), seed,
                       lc.step_ptr(), _dt(x), _s())
         if fw and fb:
-            lc.wq_push(launch, (g, g2, x))
+            lc.wq_push(launch, (g, g2, x), 'dw')
         else:
             launch([])
         return dx, _grad_done(w, dw, fw), _grad_done(b, db, fb), None, None, None
@@ -1406,7 +1430,7 @@ class _Trilinear(torch.autograd.Function):
         dx = torch.empty((B, H, W, D, C), device=g.device, dtype=g.dtype)
         if SEPARABLE_TRILINEAR_ADJOINT and (C % 8 == 0 or g.dtype == torch.float32):
             ws = torch.empty(_lib.load().ltu_trilinear_adjoint_ws_elems(B, H, W, D, C, sd), device=g.device, dtype=g.dtype)
-            _lib.call('ltu_trilinear_adjoint', _p(g), _p(g2), _p(dx), _p(ws), B, H, W, D, C, sd, _dt(g), _s())
+            _lib.call('ltu_trilinear_adjoint', _p(g), _p(g2), _p(dx), _p(ws), _n(ws), B, H, W, D, C, sd, _dt(g), _s())
         else:
             _lib.call('ltu_trilinear_up', _p(g), _p(g2), _p(dx), 1, B, H, W, D, C, sd, _dt(g), _s())
         return dx, None, None
@@ -1535,8 +1559,8 @@ class _Gate(torch.autograd.Function):
         _lib.call('ltu_linear_fwd', _p(up), Cg, _ptr_array([wgo]), 1, _ptr_array([bg]), _p(u2), C, M, C, Cg, 0, dt, _s())
         s1 = lc.scratch_zeros((B, C, 3), dev)
         s2 = lc.scratch_zeros((B, C, 3), dev)
-        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), _p(lc.norm_ws(dev)), B, S, C, dt, _s())
-        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), _p(lc.norm_ws(dev)), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(u1), _p(s1), _p(lc.norm_ws(dev)), _n(lc.norm_ws(dev)), B, S, C, dt, _s())
+        _lib.call('ltu_instnorm_stats', _p(u2), _p(s2), _p(lc.norm_ws(dev)), _n(lc.norm_ws(dev)), B, S, C, dt, _s())
         a = torch.empty(M, device=dev, dtype=torch.float32)
         out = torch.empty_like(skip)
         _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, dt, _s())
@@ -1566,7 +1590,7 @@ class _Gate(torch.autograd.Function):
         du1 = torch.empty_like(u1)
         du2 = torch.empty_like(u2)
         _lib.call('ltu_gate_bwd', _p(g), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
-                  _p(dpb), _p(bs1), _p(bs2), _p(lc.norm_ws(dev)), _p(du1), _p(du2), B, S, C, dt, _s())
+                  _p(dpb), _p(bs1), _p(bs2), _p(lc.norm_ws(dev)), _n(lc.norm_ws(dev)), _p(du1), _p(du2), B, S, C, dt, _s())
         # through the two 1x1x1 convs
         wxt = px.wt if px is not None else _w_transposed([wx], C, C, skip.dtype)
         wgt = pg.wt if pg is not None else _w_transposed([wg], C, Cg, skip.dtype)
@@ -1581,10 +1605,10 @@ class _Gate(torch.autograd.Function):
         def launch(keep):
             w1, w2 = _wgrad_ws(M, C, C, skip), _wgrad_ws(M, C, Cg, skip)
             keep.extend((w1, w2))
-            _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _ptr_array([dwx]), _ptr_array([dbx]), 1, M, C, C, _p(w1), 0, dt, _s())
-            _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _ptr_array([dwg]), _ptr_array([dbg]), 1, M, C, Cg, _p(w2), 0, dt, _s())
+            _lib.call('ltu_linear_wgrad', _p(du1), C, _p(skip), C, _ptr_array([dwx]), _ptr_array([dbx]), 1, M, C, C, _p(w1), _n(w1), 0, dt, _s())
+            _lib.call('ltu_linear_wgrad', _p(du2), C, _p(up), Cg, _ptr_array([dwg]), _ptr_array([dbg]), 1, M, C, Cg, _p(w2), _n(w2), 0, dt, _s())
         if f1 and f2 and f3 and f4:
-            lc.wq_push(launch, (du1, du2, skip, up))
+            lc.wq_push(launch, (du1, du2, skip, up), 'gate')
         else:
             launch([])
         return (dskip, dup, _grad_done(wx, dwx, f1), _grad_done(bx, dbx, f2), _grad_done(wg, dwg, f3), _grad_done(bg, dbg, f4),
@@ -1612,7 +1636,7 @@ class _LevelLoss(torch.autograd.Function):
         values = buf[:8]                 # the report (non-differentiable); buf[8] repeats the total as the differentiable output, so
         coef = torch.empty((B, C, 3), device=dev, dtype=torch.float32)          # no copy kernel is needed to separate the two
         wd = (ctypes.c_float * 5)(*[float(w_dice[c]) if c < len(w_dice) else 0.0 for c in range(5)])
-        _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _p(scale_dev), _s())
+        _lib.call('ltu_loss_fwd', _p(p), _p(label), _p(sums), _n(sums), _p(values), _p(coef), B, S, C, float(w_ce), float(w_bal), wd, _p(scale_dev), _s())
         ctx.save_for_backward(p, label, coef)
         ctx.mark_non_differentiable(values)
         ctx.set_materialize_grads(False)         # no zero-filled gradient tensor for the report output

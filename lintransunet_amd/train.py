@@ -347,7 +347,8 @@ class GraphedStep:
 
     def _body(self, zero, reduce, on_flush=None, on_join=None):
         self.counter.add_(1)
-        self.ctx.wq_install(self.wq_stream, on_flush, on_join)       # weight gradients in batches on a side stream / as graphs of their own
+        # weight gradients in batches on a side stream / as graphs of their own, at SIDE_BLOCKS workgroups per launch
+        self.ctx.wq_install(self.wq_stream, on_flush, on_join, width=self.SIDE_BLOCKS)
         try:
             if zero:
                 # nothing accumulates into the gradient buffers before backward: the fills run on the side stream, beside the
@@ -367,30 +368,12 @@ class GraphedStep:
     # Width of the weight-gradient kernels while they run on the side stream: half the machine.  At their stand-alone width (256
     # workgroups) they crowd the main chain's kernels out of the CUs (every main-chain kernel of backward ran 1.3-2x longer beside
     # them); at 128 the side stream is still far from being the critical path (64: it becomes it, 14.7 ms).  tools/sweep_side_grids.sh:
-    # 13.58 -> 13.29 ms.  The knobs are process-wide, so they are set around the capture only (a captured graph keeps its grids).
-    SIDE_WIDTH = {'LTU_WGROUP_BLOCKS': 128, 'LTU_UPW_BLOCKS': 128}
-
-    def capture_knobs(self):
-        """context manager: the process-wide launch-geometry knobs this step was captured under.  Anything that re-issues the step's
-        recorded C-ABI calls (family_timer: their workspaces were sized under these knobs) has to run inside it."""
-        import contextlib
-        from . import _lib
-
-        @contextlib.contextmanager
-        def cm():
-            narrow = [k for k in self.SIDE_WIDTH if self.wq_stream is not None and k not in os.environ]
-            for k in narrow:
-                _lib.config_set(k, self.SIDE_WIDTH[k])
-            try:
-                yield
-            finally:
-                for k in narrow:
-                    _lib.config_set(k, None)
-        return cm()
+    # 13.58 -> 13.29 ms.  The width is an ARGUMENT of the launches that take one (ops.Context.side_width -> ltu_linear_wgrad_group /
+    # ltu_upconv_wgrad: size query and launch get the same value), not a process-wide knob flipped around the capture (round 4).
+    SIDE_BLOCKS = int(os.environ.get('LTU_SIDE_BLOCKS', '128'))
 
     def _capture(self, key):
-        with self.capture_knobs():
-            self._capture_inner(key)
+        self._capture_inner(key)
 
     def _capture_inner(self, key):
         zero, reduce = key

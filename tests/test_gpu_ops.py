@@ -384,9 +384,9 @@ def test_instnorm_fwd_one_call(ops, instnorm_variant, dtype, B, S, C):
     st = torch.cuda.current_stream().cuda_stream
     s1, s2 = torch.zeros(B, C, 3, device=DEV), torch.zeros(B, C, 3, device=DEV)
     y1, y2 = torch.empty_like(x), torch.empty_like(x)
-    _lib.call('ltu_instnorm_stats', x.data_ptr(), s1.data_ptr(), ws.data_ptr(), B, S, C, dt, st)
+    _lib.call('ltu_instnorm_stats', x.data_ptr(), s1.data_ptr(), ws.data_ptr(), ws.numel(), B, S, C, dt, st)
     _lib.call('ltu_instnorm_apply', x.data_ptr(), s1.data_ptr(), res.data_ptr(), y1.data_ptr(), B, S, C, 1, 0.01, 0.0, 0, 0, dt, st)
-    _lib.call('ltu_instnorm_fwd', x.data_ptr(), s2.data_ptr(), ws.data_ptr(), res.data_ptr(), y2.data_ptr(), B, S, C, 1, 0.01, 0.0, 0, 0, dt, st)
+    _lib.call('ltu_instnorm_fwd', x.data_ptr(), s2.data_ptr(), ws.data_ptr(), ws.numel(), res.data_ptr(), y2.data_ptr(), B, S, C, 1, 0.01, 0.0, 0, 0, dt, st)
     assert torch.equal(s1[..., 0], s2[..., 0])
     assert rel_err(s2, s1) < 1e-5
     xr = x.float().requires_grad_(True)
@@ -396,7 +396,7 @@ def test_instnorm_fwd_one_call(ops, instnorm_variant, dtype, B, S, C):
     go = torch.randn(B, S, C, generator=g).to(DEV).to(dtype)
     yr.backward(go.float())
     bs, dx = torch.zeros(B, C, 2, device=DEV), torch.empty_like(x)
-    _lib.call('ltu_instnorm_bwd', go.data_ptr(), 0, 0, x.data_ptr(), s2.data_ptr(), bs.data_ptr(), ws.data_ptr(), dx.data_ptr(), B, S, C, 1,
+    _lib.call('ltu_instnorm_bwd', go.data_ptr(), 0, 0, x.data_ptr(), s2.data_ptr(), bs.data_ptr(), ws.data_ptr(), ws.numel(), dx.data_ptr(), B, S, C, 1,
               0.01, 0.0, 0, 0, dt, st)
     assert rel_err(dx.float(), xr.grad) < (2e-4 if dtype == torch.float32 else 8e-3)
     xh = (x.float() - x.float().mean(1, keepdim=True)) * torch.rsqrt(x.float().var(1, unbiased=False, keepdim=True) + 1e-5)
@@ -424,14 +424,14 @@ def test_instnorm_small_against_streaming(ops, dtype, B, S, C):
     def run():
         s0, s1 = torch.zeros(B, C, 3, device=DEV), torch.zeros(B, C, 3, device=DEV)
         y = torch.empty_like(x)
-        _lib.call('ltu_instnorm_stats', x.data_ptr(), s0.data_ptr(), ws.data_ptr(), B, S, C, dt, st)
-        _lib.call('ltu_instnorm_fwd', x.data_ptr(), s1.data_ptr(), ws.data_ptr(), res.data_ptr(), y.data_ptr(), B, S, C, 1, 0.01, 0.3, 4242,
+        _lib.call('ltu_instnorm_stats', x.data_ptr(), s0.data_ptr(), ws.data_ptr(), ws.numel(), B, S, C, dt, st)
+        _lib.call('ltu_instnorm_fwd', x.data_ptr(), s1.data_ptr(), ws.data_ptr(), ws.numel(), res.data_ptr(), y.data_ptr(), B, S, C, 1, 0.01, 0.3, 4242,
                   step.data_ptr(), dt, st)
         bs, dx = torch.zeros(B, C, 2, device=DEV), torch.empty_like(x)
         _lib.call('ltu_instnorm_bwd', gos[0].data_ptr(), gos[1].data_ptr(), gos[2].data_ptr(), x.data_ptr(), s1.data_ptr(), bs.data_ptr(),
-                  ws.data_ptr(), dx.data_ptr(), B, S, C, 1, 0.01, 0.3, 4242, step.data_ptr(), dt, st)
+                  ws.data_ptr(), ws.numel(), dx.data_ptr(), B, S, C, 1, 0.01, 0.3, 4242, step.data_ptr(), dt, st)
         bs1, dx1 = torch.zeros(B, C, 2, device=DEV), torch.empty_like(x)
-        _lib.call('ltu_instnorm_bwd', gos[0].data_ptr(), 0, 0, x.data_ptr(), s1.data_ptr(), bs1.data_ptr(), ws.data_ptr(), dx1.data_ptr(),
+        _lib.call('ltu_instnorm_bwd', gos[0].data_ptr(), 0, 0, x.data_ptr(), s1.data_ptr(), bs1.data_ptr(), ws.data_ptr(), ws.numel(), dx1.data_ptr(),
                   B, S, C, 0, 0.0, 0.0, 0, 0, dt, st)
         torch.cuda.synchronize()
         return s0, s1, y.float(), bs, dx.float(), bs1, dx1.float()
@@ -580,14 +580,19 @@ def test_dropout_group_pattern_histogram(ops, p):
         assert abs(counts[k].item() - want) < 4 * (want * (1 - want) / groups) ** 0.5 + 3e-4, (k, counts[k].item(), want)
 
 
-@pytest.mark.parametrize('M,d', [(4320, 256), (2048, 128), (21504, 256), (1024, 256)])
-def test_linear_wgrad_group(ops, M, d):
+@pytest.mark.parametrize('M,d,width', [(4320, 256, 0), (2048, 128, 0), (21504, 256, 0), (1024, 256, 0), (114816, 128, 0), (114816, 128, 128),
+                                       (21504, 256, 128), (8640, 256, 128), (1056, 128, 7), (2080, 256, 1000)])
+def test_linear_wgrad_group(ops, M, d, width):
     """the four projection weight gradients of a transformer layer (qkv with 3 blocks, out, ffn1, ffn2) as ONE grouped launch +
-    ONE fold against torch fp32 (G^T X and column sums of G on the bf16-rounded operands), accumulated onto existing values"""
+    ONE fold against torch fp32 (G^T X and column sums of G on the bf16-rounded operands), accumulated onto existing values; at the
+    library's stand-alone width (0) and at the workgroup budget train.GraphedStep hands the side-stream launches (128), plus
+    ragged row counts with odd budgets (row splits of unequal length, more / fewer workgroups than tiles)"""
     g = G(31)
     bf = lambda t: t.bfloat16()
     shapes = [(3 * d, d, 3), (d, d, 1), (2 * d, d, 1), (d, 2 * d, 1)]          # (N, K, nw)
     lc = ops.Context()
+    if width:
+        lc.wq_install(torch.cuda.current_stream(), width=width)              # a queue on the current stream: in line, at that width
     want, bufs = [], []
     for N, K, nw in shapes:
         gr, x = bf(torch.randn(M, N, generator=g) * 0.1).to(DEV), bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -599,10 +604,118 @@ def test_linear_wgrad_group(ops, M, d):
         bufs.append((dws, dbs))
     assert len(lc.wg_group) == 4
     lc.flush_deferred()
+    lc.wq_join()
     assert not lc.wg_group
     for (dw_ref, db_ref), (dws, dbs) in zip(want, bufs):
         dw, db = torch.cat(dws, 0), torch.cat(dbs, 0)
         assert rel_err(dw, dw_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
+
+
+def test_wgrad_group_short_workspace_is_refused(ops):
+    """SURVEY 8(b) error contract for workspaces (round 4's GPU fault: a launch whose geometry needed more than the workspace it had
+    been sized for wrote past its end): the launch is told the capacity and returns LTU_E_ARG (-4) WITHOUT launching when its
+    geometry - here: a larger workgroup budget than the size query was asked for - needs more; a sufficient workspace runs"""
+    import ctypes
+    from lintransunet_amd import _lib
+    M, d = 8192, 128
+    g = G(5)
+    gr = (torch.randn(M, 3 * d, generator=g) * 0.1).bfloat16().to(DEV)
+    x = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    dws = [torch.zeros(d, d, device=DEV) for _ in range(3)]
+    dbs = [torch.zeros(d, device=DEV) for _ in range(3)]
+    arr = (_lib.WgradJob * 1)()
+    r = arr[0]
+    r.grad, r.a, r.ldg, r.lda, r.nw, r.M, r.N, r.K = gr.data_ptr(), x.data_ptr(), 3 * d, d, 3, M, 3 * d, d
+    for i in range(3):
+        r.dw[i], r.db[i] = dws[i].data_ptr(), dbs[i].data_ptr()
+    lib = _lib.load()
+    n8, n32 = (lib.ltu_linear_wgrad_group_ws_floats(ctypes.addressof(arr), 1, b) for b in (8, 32))
+    assert 0 < n8 < n32
+    guard = 1 << 16
+    ws = torch.zeros(n32 + guard, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    rc = lib.ltu_linear_wgrad_group(ctypes.addressof(arr), 1, 32, ws.data_ptr(), n8, 1, s)       # sized at 8, launched at 32
+    torch.cuda.synchronize()
+    assert rc == -4
+    assert not ws.any() and not any(t.any() for t in dws)                                        # nothing was launched
+    with pytest.raises(_lib.LtuError, match='LTU_E_ARG'):
+        _lib.call('ltu_linear_wgrad_group', ctypes.addressof(arr), 1, 32, ws.data_ptr(), n8, 1, s)
+    assert lib.ltu_linear_wgrad_group(ctypes.addressof(arr), 1, 32, ws.data_ptr(), n32, 1, s) == 0
+    torch.cuda.synchronize()
+    assert not ws[n32:].any()                                                                    # ... and stayed inside its size
+    assert rel_err(torch.cat(dws, 0), gr.float().t() @ x.float()) < 2e-5
+
+
+def test_short_workspaces_are_refused(ops):
+    """the same contract on the other workspace-taking entry points, one per kind of geometry: a capacity below what the launch is
+    about to use yields LTU_E_ARG (-4) and nothing is launched (the outputs keep their fill value)"""
+    from lintransunet_amd import _lib
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    g = G(6)
+    bf = lambda *sh: (torch.randn(*sh, generator=g) * 0.1).bfloat16().to(DEV)
+    # (1) dense weight gradient: row splits through the workspace
+    M, N, K = 4096, 128, 128
+    gr, x = bf(M, N), bf(M, K)
+    dw, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    need = lib.ltu_wgrad_ws_floats(M, N, K)
+    ws = torch.zeros(need, device=DEV)
+    import ctypes
+    arr1 = (ctypes.c_void_p * 3)(dw.data_ptr(), 0, 0)
+    arr2 = (ctypes.c_void_p * 3)(db.data_ptr(), 0, 0)
+    assert lib.ltu_linear_wgrad(gr.data_ptr(), N, x.data_ptr(), K, arr1, arr2, 1, M, N, K, ws.data_ptr(), 1024, 0, 1, s) == -4
+    torch.cuda.synchronize()
+    assert not dw.any() and not ws.any()
+    assert lib.ltu_linear_wgrad(gr.data_ptr(), N, x.data_ptr(), K, arr1, arr2, 1, M, N, K, ws.data_ptr(), need, 0, 1, s) == 0
+    torch.cuda.synchronize()
+    assert rel_err(dw, gr.float().t() @ x.float()) < 2e-5
+    # (2) sub-pixel un-embedding weight gradient: sized at a budget of 64 workgroups, launched at 256
+    B, H, W, D, Ci, Co = 1, 8, 8, 8, 64, 32
+    xg, gg = bf(B, H, W, D, Ci), bf(B, 2 * H, 2 * W, 2 * D, Co)
+    n64, n256 = (lib.ltu_upconv_wgrad_ws_floats(B * H * W * D, Co, Ci, b) for b in (2, 256))
+    assert 0 < n64 < n256
+    dweff = torch.zeros(8, Co, 8, Ci, device=DEV)
+    dwt, dbt = torch.zeros(Co, Ci, 27, device=DEV), torch.zeros(Co, device=DEV)
+    ws = torch.zeros(n256, device=DEV)
+    args = lambda cap, blocks: (gg.data_ptr(), xg.data_ptr(), dweff.data_ptr(), dbt.data_ptr(), dwt.data_ptr(), Co, Ci, ws.data_ptr(), cap, blocks,
+                                B, H, W, D, Ci, Co, 1, s)
+    assert lib.ltu_upconv_wgrad(*args(n64, 256)) == -4
+    torch.cuda.synchronize()
+    assert not dwt.any() and not ws.any()
+    assert lib.ltu_upconv_wgrad(*args(n256, 256)) == 0 and lib.ltu_upconv_wgrad(*args(n64, 2)) == 0
+    torch.cuda.synchronize()
+    assert dwt.any()
+    # (3) linear attention: split partials
+    Bq, Nq, d = 2, 4096, 128
+    qkv = bf(Bq * Nq, 3 * d)
+    Hh = d // 32
+    cx, cs = torch.zeros(Bq * Hh, 32, 32, device=DEV), torch.zeros(Bq * Hh, 64, device=DEV)
+    need = lib.ltu_linattn_ws_floats(Bq, Nq, d)
+    ws = torch.zeros(need, device=DEV)
+    assert lib.ltu_linattn_ctx(qkv.data_ptr(), cx.data_ptr(), cs.data_ptr(), ws.data_ptr(), need // 4, Bq, Nq, d, 1, s) == -4
+    torch.cuda.synchronize()
+    assert not cx.any() and not ws.any()
+    assert lib.ltu_linattn_ctx(qkv.data_ptr(), cx.data_ptr(), cs.data_ptr(), ws.data_ptr(), need, Bq, Nq, d, 1, s) == 0
+    # (4) the fixed-size scratch of the two-stage norm reductions, the trilinear adjoint's intermediate, the loss partials
+    xs = bf(2, 4096, 16)
+    sums = torch.zeros(2, 16, 3, device=DEV)
+    nws = torch.zeros(lib.ltu_norm_ws_floats(), device=DEV)
+    assert lib.ltu_instnorm_stats(xs.data_ptr(), sums.data_ptr(), nws.data_ptr(), 16, 2, 4096, 16, 1, s) == -4
+    assert lib.ltu_instnorm_stats(xs.data_ptr(), sums.data_ptr(), nws.data_ptr(), nws.numel(), 2, 4096, 16, 1, s) == 0
+    gy = bf(1, 8, 8, 16, 16)
+    dxo = torch.zeros(1, 4, 4, 8, 16, device=DEV, dtype=torch.bfloat16)
+    ne = lib.ltu_trilinear_adjoint_ws_elems(1, 4, 4, 8, 16, 2)
+    tws = torch.zeros(ne, device=DEV, dtype=torch.bfloat16)
+    assert lib.ltu_trilinear_adjoint(gy.data_ptr(), 0, dxo.data_ptr(), tws.data_ptr(), ne - 1, 1, 4, 4, 8, 16, 2, 1, s) == -4
+    assert lib.ltu_trilinear_adjoint(gy.data_ptr(), 0, dxo.data_ptr(), tws.data_ptr(), ne, 1, 4, 4, 8, 16, 2, 1, s) == 0
+    pr = torch.rand(1, 4096, 2, device=DEV)
+    lab = torch.zeros(1, 4096, dtype=torch.uint8, device=DEV)
+    nl = lib.ltu_loss_ws_floats(1, 4096, 2)
+    lsum, vals, coef = torch.zeros(nl, device=DEV), torch.zeros(9, device=DEV), torch.zeros(1, 2, 3, device=DEV)
+    wd = (ctypes.c_float * 5)(1, 1, 0, 0, 0)
+    assert lib.ltu_loss_fwd(pr.data_ptr(), lab.data_ptr(), lsum.data_ptr(), nl - 1, vals.data_ptr(), coef.data_ptr(), 1, 4096, 2, 1.0, 0.0, wd, 0, s) == -4
+    assert lib.ltu_loss_fwd(pr.data_ptr(), lab.data_ptr(), lsum.data_ptr(), nl, vals.data_ptr(), coef.data_ptr(), 1, 4096, 2, 1.0, 0.0, wd, 0, s) == 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('M,d,layers', [(2048, 256, 8), (1024, 256, 8), (2048, 128, 8), (4320, 256, 2), (2048, 256, 3)])

@@ -33,9 +33,30 @@ def test_cabi_exports_every_declared_symbol():
         quoted = set(int(m) for m in re.findall(r'(\d+) (?:`extern "C"` )?(?:entry points|functions)', text))
         assert quoted == {len(declared)}, (doc, quoted, len(declared))
     # argument counts of the binding table match the C prototypes
-    for name, args in re.findall(r'^(?:int|long long)\s+(ltu_\w+)\s*\(([^;]*)\);', header, flags=re.M | re.S):
+    protos = re.findall(r'^(?:int|long long)\s+(ltu_\w+)\s*\(([^;]*)\);', header, flags=re.M | re.S)
+    for name, args in protos:
         n = 0 if args.strip() == 'void' else len(args.split(','))
         assert n == len(_lib.SIGNATURES[name]), name
+    # the workspace contract (SURVEY 8b error behaviour; round 4's GPU fault was a launch writing past a workspace sized under
+    # another geometry): every caller-owned workspace / scratch pointer is followed by its capacity, as a `long long` argument
+    cap_after = {'ws': ('ws_floats', 'ws_elems'), 'part_ws': ('ws_floats',), 'lnws1': ('lnws_floats',)}
+    with_ws = 0
+    for name, args in protos:
+        params = [re.sub(r'/\*.*?\*/', '', a, flags=re.S).strip() for a in args.split(',')]
+        names = [p.split()[-1].lstrip('*') if p else '' for p in params]
+        for i, n in enumerate(names):
+            if n in cap_after:
+                with_ws += 1
+                assert i + 1 < len(names) and names[i + 1] in cap_after[n] and params[i + 1].startswith('long long'), (name, n)
+                assert _lib.SIGNATURES[name][i + 1] is _lib.L, name
+        if name == 'ltu_loss_fwd':
+            assert names[names.index('sums') + 1] == 'sums_floats'
+    assert with_ws == 21, with_ws
+    # the two launches whose width the caller chooses take it in the size query AND in the launch
+    for q, l in (('ltu_linear_wgrad_group_ws_floats', 'ltu_linear_wgrad_group'), ('ltu_upconv_wgrad_ws_floats', 'ltu_upconv_wgrad')):
+        for fn in (q, l):
+            args = dict(protos)[fn]
+            assert re.search(r'\bint blocks\b', args), fn
 
 
 @pytest.mark.parametrize('dim_output', [2, 3])

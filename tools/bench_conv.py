@@ -21,9 +21,9 @@ def run(B, H, W, D, C0, C1, Co):
     nf, nd = _lib.load().ltu_conv3d_ws_floats(B, H, W, D, C, Co), _lib.load().ltu_conv3d_ws_floats(B, H, W, D, Co, C)
     WSF = torch.empty(nf, device='cuda') if nf and not nosplit else None
     WSD = torch.empty(nd, device='cuda') if nd and not nosplit else None
-    f = lambda: _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias), _p(y), B, H, W, D, C0, C1, Co, 1, 1, 1, 0, _p(WSF), 1, _s())
-    dg = lambda: _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(dx0), _p(dx1), B, H, W, D, C0, C1, Co, 1, 1, 1, _p(WSD), 1, _s())
-    wg = lambda: _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, H, W, D, C0, C1, Co, 1, 1, 1, 0, Co, C, _p(ws), 1, _s())
+    f = lambda: _lib.call('ltu_conv3d_fwd', _p(x0), _p(x1), _p(wf), _p(bias), _p(y), B, H, W, D, C0, C1, Co, 1, 1, 1, 0, _p(WSF), nf if WSF is not None else 0, 1, _s())
+    dg = lambda: _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(dx0), _p(dx1), B, H, W, D, C0, C1, Co, 1, 1, 1, _p(WSD), nd if WSD is not None else 0, 1, _s())
+    wg = lambda: _lib.call('ltu_conv3d_wgrad', _p(g), _p(x0), _p(x1), _p(dw), _p(db), B, H, W, D, C0, C1, Co, 1, 1, 1, 0, Co, C, _p(ws), ws.numel(), 1, _s())
     tf, td, tw = timed(f), timed(dg), timed(wg)
     vox = B * H * W * D
     mb_f = vox * (C + Co) * 2 / 1e6

@@ -12,7 +12,7 @@ def run(B, H, W, D, C, p=float(os.environ.get("DW_P", "0.3"))):
     w = torch.randn(C, 27, device='cuda'); b = torch.randn(C, device='cuda')
     dw = torch.zeros(C, 27, device='cuda'); db = torch.zeros(C, device='cuda')
     f = lambda: _lib.call('ltu_dwconv_fwd', _p(x), _p(w), _p(b), _p(y), B, H, W, D, C, p, 1, 0, 1, _s())
-    bw = lambda: _lib.call('ltu_dwconv_bwd', _p(g), 0, _p(x), _p(w), _p(y), _p(dw), _p(db), 0, B, H, W, D, C, p, 1, 0, 1, _s())
+    bw = lambda: _lib.call('ltu_dwconv_bwd', _p(g), 0, _p(x), _p(w), _p(y), _p(dw), _p(db), 0, 0, B, H, W, D, C, p, 1, 0, 1, _s())
     tf, tb = timed(f), timed(bw)
     mb = x.numel() * 2 / 1e6
     print(f'B={B} {H}x{W}x{D} C={C} ({mb:.1f} MB): fwd {tf:.1f} us  bwd(data+weight) {tb:.1f} us', flush=True)

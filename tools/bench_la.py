@@ -19,7 +19,7 @@ def run(B, N, d):
     cx = torch.empty(B * H, 32, 32, device='cuda')
     cs = torch.empty(B * H, 64, device='cuda')
     qstat = torch.empty(B * N, H, 2, device='cuda')
-    ws = torch.empty(B * (nsplit + nsplit // 16 + 2) * H * 1088, device='cuda')
+    ws = torch.empty(_lib.load().ltu_linattn_ws_floats(B, N, d), device='cuda')
     dqkv = torch.empty_like(qkvs[0])
     dctx = torch.empty_like(cx)
     tvec = torch.empty(B * H, 32, device='cuda')
@@ -27,11 +27,11 @@ def run(B, N, d):
 
     def fwd():
         i = cnt[0] % nb; cnt[0] += 1
-        _lib.call('ltu_linattn_fwd', _p(qkvs[i]), _p(out), _p(cx), _p(cs), _p(qstat), _p(ws), B, N, d, 1, _s())
+        _lib.call('ltu_linattn_fwd', _p(qkvs[i]), _p(out), _p(cx), _p(cs), _p(qstat), _p(ws), ws.numel(), B, N, d, 1, _s())
 
     def bwd():
         i = cnt[0] % nb; cnt[0] += 1
-        _lib.call('ltu_linattn_bwd', _p(qkvs[i]), _p(gos[i]), _p(cx), _p(cs), _p(qstat), _p(dqkv), _p(dctx), _p(tvec), _p(ws), B, N, d, 1, _s())
+        _lib.call('ltu_linattn_bwd', _p(qkvs[i]), _p(gos[i]), _p(cx), _p(cs), _p(qstat), _p(dqkv), _p(dctx), _p(tvec), _p(ws), ws.numel(), B, N, d, 1, _s())
     tf = timed(fwd)
     tb = timed(bwd)
     fb, bb = 4 * B * N * d * 2, 8 * B * N * d * 2

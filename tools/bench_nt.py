@@ -42,7 +42,7 @@ def run(M, K, N):
     ws = torch.empty(nws, device='cuda')
     def wg():
         i = cnt[0] % nb; cnt[0] += 1
-        _lib.call('ltu_linear_wgrad', _p(ys[i]), N, _p(xs[i]), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(ws), 0, 1, _s())
+        _lib.call('ltu_linear_wgrad', _p(ys[i]), N, _p(xs[i]), K, _ptr_array([dw]), _ptr_array([db]), 1, M, N, K, _p(ws), ws.numel(), 0, 1, _s())
     tw = timed(wg)
     print(f'M={M:7d} K={K:4d} N={N:4d}: fwd {t:7.1f} us  {byts / t / 1e6:5.2f} TB/s {2 * M * K * N / t / 1e6:6.0f} TF | '
           f'wgrad(+reduce) {tw:7.1f} us {byts / tw / 1e6:5.2f} TB/s', flush=True)

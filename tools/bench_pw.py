@@ -18,7 +18,7 @@ def ln(M, d):
     dg, db = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
     stat = torch.empty(M, 2, device='cuda')
     f = lambda: _lib.call('ltu_layernorm_fwd', _p(x), _p(r), _p(gamma), _p(beta), _p(y), _p(stat), M, d, 1e-5, 0.3, 1, 0, 1, _s())
-    b = lambda: _lib.call('ltu_layernorm_bwd', _p(g), 0, _p(r), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(WS), 0, M, d, 0.3, 1, 0, 1, _s())
+    b = lambda: _lib.call('ltu_layernorm_bwd', _p(g), 0, _p(r), _p(stat), _p(gamma), _p(dz), _p(dr), _p(dg), _p(db), _p(WS), (WS.numel() if WS is not None else 0), 0, M, d, 0.3, 1, 0, 1, _s())
     tf, tb = timed(f), timed(b)
     mb = M * d * 2 / 1e6
     print(f'LN   M={M:7d} d={d:4d}: fwd {tf:6.1f} us ({4 * mb / tf:.1f} TB/s)  bwd {tb:6.1f} us ({4 * mb / tb:.1f} TB/s)', flush=True)
@@ -34,10 +34,10 @@ def gelu(n):
 def inorm(B, S, C):
     x, y, dy, dx = bf(B, S, C), bf(B, S, C), bf(B, S, C), bf(B, S, C)
     sums = torch.zeros(B, C, 3, device='cuda'); bs = torch.zeros(B, C, 2, device='cuda')
-    st = lambda: _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(WS), B, S, C, 1, _s())
+    st = lambda: _lib.call('ltu_instnorm_stats', _p(x), _p(sums), _p(WS), (WS.numel() if WS is not None else 0), B, S, C, 1, _s())
     ap = lambda: _lib.call('ltu_instnorm_apply', _p(x), _p(sums), 0, _p(y), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
-    bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), 0, 0, _p(x), _p(sums), _p(bs), _p(WS), _p(dx), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
-    fw = lambda: _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(WS), 0, _p(y), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
+    bw = lambda: _lib.call('ltu_instnorm_bwd', _p(dy), 0, 0, _p(x), _p(sums), _p(bs), _p(WS), (WS.numel() if WS is not None else 0), _p(dx), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
+    fw = lambda: _lib.call('ltu_instnorm_fwd', _p(x), _p(sums), _p(WS), (WS.numel() if WS is not None else 0), 0, _p(y), B, S, C, 1, 0.01, PDROP, 1, 0, 1, _s())
     t1, t2, t3, t4 = timed(st), timed(ap), timed(bw), timed(fw)
     mb = B * S * C * 2 / 1e6
     print(f'IN   B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): stats {t1:6.1f} us ({mb / t1:.1f} TB/s)  apply {t2:6.1f} us ({2 * mb / t2:.1f} TB/s)  '
@@ -54,7 +54,7 @@ def gate(B, S, C):
     b1, b2 = torch.zeros(B, C, 2, device='cuda'), torch.zeros(B, C, 2, device='cuda')
     f = lambda: _lib.call('ltu_gate_fwd', _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(pb), _p(skip), _p(a), _p(out), B, S, C, 1, _s())
     bw = lambda: _lib.call('ltu_gate_bwd', _p(dout), _p(u1), _p(u2), _p(s1), _p(s2), _p(pw), _p(skip), _p(a), _p(dskip), _p(ds), _p(dpw),
-                           _p(dpb), _p(b1), _p(b2), _p(WS), _p(du1), _p(du2), B, S, C, 1, _s())
+                           _p(dpb), _p(b1), _p(b2), _p(WS), (WS.numel() if WS is not None else 0), _p(du1), _p(du2), B, S, C, 1, _s())
     tf, tb = timed(f), timed(bw)
     mb = B * S * C * 2 / 1e6
     print(f'gate B={B} S={S:8d} C={C:4d} ({mb:.0f} MB): fwd {tf:6.1f} us ({4 * mb / tf:.1f} TB/s)  bwd {tb:6.1f} us ({9 * mb / tb:.1f} TB/s)', flush=True)

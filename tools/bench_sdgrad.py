@@ -15,7 +15,7 @@ def run(B, Hl, Wl, Dl, Ci, Co, sd):
     _lib.call('ltu_pack_conv_weight', _p(w), 0, _p(wd), Co, Ci, Co, Ci, 1, _s())
     dx = torch.empty(B, Hl, Wl, Dl, Ci, device='cuda', dtype=torch.bfloat16)
     def f():
-        _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(dx), 0, B, Hl, Wl, Dl, Ci, 0, Co, 2, 2, sd, 0, 1, _s())
+        _lib.call('ltu_conv3d_dgrad', _p(g), _p(wd), _p(dx), 0, B, Hl, Wl, Dl, Ci, 0, Co, 2, 2, sd, 0, 0, 1, _s())
     t = timed(f)
     fl = 2.0 * B * Ho * Wo * Do * 27 * Ci * Co
     print(f'dgrad B={B} fine {Hl}x{Wl}x{Dl} Ci={Ci} <- Co={Co} stride (2,2,{sd}): {t:7.1f} us ({fl / t / 1e6:.0f} TF)', flush=True)

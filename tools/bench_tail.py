@@ -54,17 +54,17 @@ def run(M, d):
     nblk = _lib.load().ltu_layer_tail_blocks(M)
     lnws = torch.empty(2, nblk, 2 * d, device='cuda')
     dg, db = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
-    ws = torch.empty(2048 * 2 * d, device='cuda')
+    ws = torch.empty(_lib.load().ltu_norm_ws_floats(), device='cuda')
     btail = lambda: _lib.call('ltu_layer_tail_bwd', _p(gy), 0, _p(z2), _p(z1), _p(u), _p(s2), _p(s1), _p(g), _p(g), _p(f2t), _p(f1t), _p(fot),
-                              _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), M, d, P, 11, 12, 13, 0, 1, 1, _s())
+                              _p(dr2), _p(du), _p(dr1), _p(dz1), _p(da), _p(lnws[0]), _p(lnws[1]), lnws[0].numel(), M, d, P, 11, 12, 13, 0, 1, 1, _s())
     wot, w1t, w2t = wo.t().contiguous().bfloat16(), w1.t().contiguous().bfloat16(), w2.t().contiguous().bfloat16()
 
     def bsteps():
-        _lib.call('ltu_layernorm_bwd', _p(gy), 0, _p(z2), _p(s2), _p(g), _p(dz2), _p(dr2), _p(dg), _p(db), _p(ws), 0, M, d, 0.3, 13, 0, 1, _s())
+        _lib.call('ltu_layernorm_bwd', _p(gy), 0, _p(z2), _p(s2), _p(g), _p(dz2), _p(dr2), _p(dg), _p(db), _p(ws), ws.numel(), 0, M, d, 0.3, 13, 0, 1, _s())
         _lib.call('ltu_linear_fwd', _p(dr2), d, pa([w2t]), 1, pa([None]), _p(dh), 2 * d, M, 2 * d, d, 0, 1, _s())
         _lib.call('ltu_gelu_dropout_bwd', _p(dh), _p(u), _p(du), M * 2 * d, 0.3, 12, 0, 1, _s())
         _lib.call('ltu_linear_fwd', _p(du), 2 * d, pa([w1t]), 1, pa([None]), _p(dt1), d, M, d, 2 * d, 0, 1, _s())
-        _lib.call('ltu_layernorm_bwd', _p(dt1), _p(dz2), _p(z1), _p(s1), _p(g), _p(dz1), _p(dr1), _p(dg), _p(db), _p(ws), 0, M, d, 0.3, 11, 0, 1, _s())
+        _lib.call('ltu_layernorm_bwd', _p(dt1), _p(dz2), _p(z1), _p(s1), _p(g), _p(dz1), _p(dr1), _p(dg), _p(db), _p(ws), ws.numel(), 0, M, d, 0.3, 11, 0, 1, _s())
         _lib.call('ltu_linear_fwd', _p(dr1), d, pa([wot]), 1, pa([None]), _p(da), d, M, d, d, 0, 1, _s())
     bt, bs = timed(btail), timed(bsteps)
     print(f'M={M:7d} d={d}: forward chain {tt:7.1f} us vs five launches {ts:7.1f} us;  backward chain {bt:7.1f} us vs six launches {bs:7.1f} us', flush=True)

@@ -13,7 +13,7 @@ for B, H, W, D, Ci, Co in [(2, 39, 23, 64, 128, 32), (2, 24, 14, 32, 256, 64), (
     dx = torch.empty(B, H, W, D, Ci, device='cuda', dtype=torch.bfloat16)
     nws = _lib.load().ltu_igemm_ws_floats(B * H * W * D, Ci, 64 * Co)
     ws = torch.empty(max(nws, 1), device='cuda')
-    f = lambda: _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, _p(ws) if nws else 0, 1, _s())
+    f = lambda: _lib.call('ltu_upconv_dgrad', _p(g), _p(prep.wd), _p(dx), B, H, W, D, Ci, Co, _p(ws) if nws else 0, nws, 1, _s())
     t = timed(f)
     fl = 2.0 * B * H * W * D * 64 * Ci * Co
     print(f'upconv dgrad B={B} {H}x{W}x{D} Ci={Ci} Co={Co}: {t:7.1f} us ({fl / t / 1e6:.0f} TF)', flush=True)

@@ -29,5 +29,8 @@ def run(M, d, layers=1):
     print(f'M={M:7d} d={d} layers={layers}: {t:6.1f} us ({gf * 1e3 / t:.0f} TFLOP/s)', flush=True)
 
 
-for M, d, layers in [(114816, 128, 1), (21504, 256, 1), (8640, 256, 1), (8640, 256, 2), (8640, 256, 4), (1024, 256, 1), (1024, 256, 8)]:
-    run(M, d, layers)
+CASES = [(114816, 128, 1), (21504, 256, 1), (8640, 256, 1), (8640, 256, 2), (8640, 256, 4), (1024, 256, 1), (1024, 256, 8)]
+sel = os.environ.get('WG_CASES')
+for i, (M, d, layers) in enumerate(CASES):
+    if sel is None or str(i) in sel.split(','):
+        run(M, d, layers)
