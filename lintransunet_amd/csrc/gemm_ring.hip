@@ -732,7 +732,17 @@ int launch_tn_ring_group_bf16(const ltu_wgrad_job* jobs, int njobs, int blocks, 
   return ltu_check_launch();
 }
 
+#ifdef LTU_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------ grouped weight gradients, round 5
+// EXPERIMENTS BUILD ONLY (make EXPERIMENTS=1, knob LTU_WGROUP_FAT=1): built for the round-4 verdict (one workgroup owns all column tiles
+// of a job's row split), meets its micro-benchmark targets (d = 128 level at 128 workgroups: 97-101 us against 106 us, 3.6 TB/s of
+// operands read once) and LOSES in the step: 12.73-12.80 ms against 12.42-12.50 ms with the kernel above, at every side width and ring
+// size tried, also as the 256-register variant below (2 waves per SIMD possible, 96 KB ring).  rocprofv3 of the step: the kernel
+// itself is 0.24 ms shorter per step, the main-chain kernels that run beside it lose 0.4 ms (halo / class convs, InstanceNorm
+// backward, attention partials: +20-40 % each).  Not register or LDS occupancy (the polite variant loses the same) and not bytes in
+// flight (64 / 96 / 144 KB rings alike): what differs is that the pipelined kernel keeps the matrix pipe and the LDS-DMA path busy
+// where the kernel above idles in exposed latencies - beside a latency-bound main chain a denser side kernel is a worse neighbour
+// (profiles/r05_wgroup.txt).
 // "Fat tiles": ONE workgroup owns all column tiles of a job's row split that its accumulators can hold, so an operand row is read
 // once - e.g. the 384-column q|k|v gradient of a d = 128 layer is three accumulator sets over ONE pass of X (the 128 x 128 tiles of
 // the kernel above read X three times and, at half the machine's width beside the main chain, those re-reads did reach HBM: 1.48x
@@ -1144,20 +1154,20 @@ int launch_wgrad_fat_group_bf16(const ltu_wgrad_job* jobs, int njobs, int blocks
   static LtuDevOnce attr_once;
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
-#ifdef LTU_EXPERIMENTS
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fat_group_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, WFAT_RING_BYTES);
-#endif
   }
-#ifdef LTU_EXPERIMENTS
   const int dbg = ltu_knob("LTU_WFAT_DBG", 0);     // ablation: 1 = no fragment reads / MFMAs, 2 = no LDS-DMA (results invalid)
   if (dbg == 1) hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<1>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
   else if (dbg == 2) hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<2>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
   else if (dbg == 3) hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<3>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
-  else
-#endif
-  hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<0>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
+  else hipLaunchKernelGGL(wgrad_fat_group_bf16_kernel<0>, dim3(grid), dim3(256), WFAT_RING_BYTES, st, fa);
   if (nf > 0) hipLaunchKernelGGL(wgroup_fold_kernel, dim3(fblocks), dim3(256), 0, st, fo);
   return ltu_check_launch();
 }
+#else
+static bool wfat_enabled() { return false; }
+long long wgrad_fat_group_ws_floats(const ltu_wgrad_job*, int, int) { return 0; }
+int launch_wgrad_fat_group_bf16(const ltu_wgrad_job*, int, int, float*, long long, hipStream_t) { return 1; }
+#endif

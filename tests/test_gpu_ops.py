@@ -580,9 +580,10 @@ def test_dropout_group_pattern_histogram(ops, p):
         assert abs(counts[k].item() - want) < 4 * (want * (1 - want) / groups) ** 0.5 + 3e-4, (k, counts[k].item(), want)
 
 
+@pytest.mark.parametrize('fat', [0, 1])
 @pytest.mark.parametrize('M,d,width', [(4320, 256, 0), (2048, 128, 0), (21504, 256, 0), (1024, 256, 0), (114816, 128, 0), (114816, 128, 128),
                                        (21504, 256, 128), (8640, 256, 128), (1056, 128, 7), (2080, 256, 1000)])
-def test_linear_wgrad_group(ops, M, d, width):
+def test_linear_wgrad_group(ops, M, d, width, fat):
     """the four projection weight gradients of a transformer layer (qkv with 3 blocks, out, ffn1, ffn2) as ONE grouped launch +
     ONE fold against torch fp32 (G^T X and column sums of G on the bf16-rounded operands), accumulated onto existing values; at the
     library's stand-alone width (0) and at the workgroup budget train.GraphedStep hands the side-stream launches (128), plus
@@ -593,6 +594,11 @@ def test_linear_wgrad_group(ops, M, d, width):
     lc = ops.Context()
     if width:
         lc.wq_install(torch.cuda.current_stream(), width=width)              # a queue on the current stream: in line, at that width
+    if fat:
+        from lintransunet_amd import _lib
+        if not _lib.experiments():
+            pytest.skip('the fat-tile grouped kernel is compiled into an experiments build only (make EXPERIMENTS=1)')
+        _lib.call('ltu_config_set', b'LTU_WGROUP_FAT', 1, 0)
     want, bufs = [], []
     for N, K, nw in shapes:
         gr, x = bf(torch.randn(M, N, generator=g) * 0.1).to(DEV), bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -603,8 +609,12 @@ def test_linear_wgrad_group(ops, M, d, width):
         want.append((dw + 0.5, gr.float().sum(0) - 0.25))
         bufs.append((dws, dbs))
     assert len(lc.wg_group) == 4
-    lc.flush_deferred()
-    lc.wq_join()
+    try:
+        lc.flush_deferred()
+        lc.wq_join()
+    finally:
+        if fat:
+            _lib.call('ltu_config_set', b'LTU_WGROUP_FAT', 0, 1)
     assert not lc.wg_group
     for (dw_ref, db_ref), (dws, dbs) in zip(want, bufs):
         dw, db = torch.cat(dws, 0), torch.cat(dbs, 0)
