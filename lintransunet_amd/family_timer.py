@@ -53,6 +53,32 @@ def family_of(name):
     return 'other'
 
 
+# kernel name (as rocprofv3 prints it) -> family, for the IN-STEP times of the committed kernel statistics (profiles/rNN_bench_kernel_stats.csv):
+# what each family's kernels take inside the replayed step, beside the other stream's kernels
+KERNEL_FAMILY = [
+    (r'tail_fwd|tail_bwd|linear_ring|wgrad_group_ring|wgrad_fat_group|wgroup_fold|wgrad_ring_bf16|linattn|layernorm|gelu_drop|reduce_batch|'
+     r'gate_|pw_small', 'transformer'),
+    (r'conv3_|conv_class|conv_halo_fold|igemm_|wgrad_tn|wgrad_reduce|upconv|updgrad|sdgrad|sumpool', 'conv3'),
+    (r'instnorm|reduce_parts', 'instnorm'),
+    (r'plan_gather|plan_scatter|roi_|trilinear|tri_', 'resample'),
+    (r'dwconv', 'dwconv'),
+]
+
+
+def in_step_ms(csv_path, steps=8):
+    """{family: ms per step} summed from a kernel-statistics file written by tools/profile_bench.sh (exact per step: the last `steps`
+    complete replays); kernel durations there include what the concurrency of the two streams costs them"""
+    import csv
+    import re
+    out = {}
+    with open(csv_path) as f:
+        for r in csv.DictReader(f):
+            name = re.sub(r'\(.*', '', r['Name'])
+            fam = next((fm for pat, fm in KERNEL_FAMILY if re.search(pat, name)), 'other')
+            out[fam] = out.get(fam, 0.0) + int(r['TotalDurationNs']) / steps / 1e6
+    return out
+
+
 class FamilyTimer:
     def __init__(self):
         self.calls = []          # (name, args list, kept-alive objects)
@@ -125,13 +151,36 @@ class FamilyTimer:
             del g
         return out
 
-    def table(self, measured, size, batch, hbm_peak_gbs=8000.0, mfma_peak_tflops=2500.0):
-        """the `roofline.families` list of bench.py: per family time, algorithmic work of SURVEY 8d (fwd + bwd = 3 x forward, x batch),
-        bound, achieved rate and fraction of the peak"""
+    def group_wgrad(self, reps=5):
+        """the largest single kernel of the step, the grouped projection weight gradient (csrc/gemm_ring.hip), alone: (ms per step of its
+        recorded launches incl. their folds - at the width the step launches them with -, launches, algorithmic operand bytes =
+        sum over jobs of (M K + M N) 2 B)"""
+        calls = [(n, a) for n, a, _ in self.calls if n == 'ltu_linear_wgrad_group']
+        if not calls:
+            return None
+        byts = 0
+        for _, a in calls:
+            jobs = ctypes.cast(int(a[0]), ctypes.POINTER(_lib.WgradJob))
+            for i in range(int(a[1])):
+                byts += 2 * jobs[i].M * (jobs[i].N + jobs[i].K)
+        saved, self.calls = self.calls, [(n, a, None) for n, a in calls]
+        try:
+            FAMILY_OF.insert(0, ('ltu_linear_wgrad_group', '_group'))
+            ms = self.measure(reps)['_group'][0]
+        finally:
+            FAMILY_OF.pop(0)
+            self.calls = saved
+        return ms, len(calls), byts
+
+    def table(self, measured, size, batch, hbm_peak_gbs=8000.0, mfma_peak_tflops=2500.0, in_step=None):
+        """the `roofline.families` list of bench.py: per family time (replayed ALONE at the capture's launch geometry, and - in_step, from
+        the committed kernel statistics of the same bench command - INSIDE the step), algorithmic work of SURVEY 8d (fwd + bwd = 3 x
+        forward, x batch), bound, achieved rate and fraction of the peak (of the alone time)"""
         work = {128: WORK_128, 96: WORK_96}.get(size)
         rows = []
         for fam, (ms, n) in sorted(measured.items(), key=lambda kv: -kv[1][0]):
-            row = {'family': fam, 'what': TITLES[fam], 'ms_per_step': ms, 'launches': n}
+            row = {'family': fam, 'what': TITLES[fam], 'ms_per_step': ms, 'ms_alone': ms,
+                   'ms_in_step': (in_step or {}).get(fam), 'launches': n}
             if work and fam in work:
                 gb, gf = (3 * batch * v for v in work[fam])
                 t_hbm, t_mfma = gb / hbm_peak_gbs * 1e3, gf / (mfma_peak_tflops * 1e3) * 1e3          # ms

@@ -331,7 +331,7 @@ class MaskTransUnet(nn.Module):
         lin = lay.self_attn.linears
         wl = self._store.lin
         if qkv is None:
-            if ops.WGRAD_FLUSH_PER_LAYER:
+            if ops.flush_per_layer(B * N):
                 t = ops.wgrad_flush_point(t)     # the qkv data gradient is the last backward op of a layer
             qkv = ops.linear(t, [lin[0].weight, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias],
                              prep=wl[(id(lay), 'qkv')])

@@ -384,7 +384,14 @@ def concurrent_stream(device, avoid, tries=8, cycles=1000000, priority=0):
             c = torch.cuda.Stream(device=device, priority=priority)
             cands.append(c)
             if all(min(pair_ms(a, c) for _ in range(2)) < 1.5 * base for a in avoid):
+                c.ltu_concurrent = True
                 return c
+    # no candidate ran beside every stream of `avoid` (a noisy probe on a shared GPU, or all hardware queues taken): the work on this
+    # stream will serialise behind one of them - said loudly, and recorded on the stream for the caller's report
+    import sys
+    print(f'[lintransunet_amd] concurrent_stream: none of {tries} candidate streams ran beside the {len(avoid)} stream(s) to avoid '
+          f'(a spin kernel pair took >= 1.5x one kernel): the side stream shares a hardware queue and will serialise', file=sys.stderr)
+    cands[0].ltu_concurrent = False
     return cands[0]
 
 
@@ -456,6 +463,13 @@ WQ_SIDE_FWD = _os.environ.get('LTU_WQ_FWD', '1') == '1'      # forward-side work
 WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
 WQ_SCHEDULE = _os.environ.get('LTU_WQ_SCHEDULE', 'end')     # weight-gradient queue: a batch where backward ENTERS ('start') / leaves ('end') a transformer
 WGRAD_FLUSH_PER_LAYER = _os.environ.get('LTU_WGRAD_FLUSH', '') == 'layer'      # experiment: one edge per layer instead of per transformer
+# tokens from which a transformer hands its weight gradients over LAYER BY LAYER (a batch behind every layer's backward instead of one
+# behind the whole transformer): 0 = never
+WGRAD_FLUSH_LAYER_TOKENS = int(_os.environ.get('LTU_WGRAD_FLUSH_TOKENS', '0'))
+
+
+def flush_per_layer(tokens):
+    return WGRAD_FLUSH_PER_LAYER or (WGRAD_FLUSH_LAYER_TOKENS > 0 and tokens >= WGRAD_FLUSH_LAYER_TOKENS)
 
 
 def _defer_job():

@@ -2,7 +2,7 @@
 # regenerates the files kept under profiles/ for the current round (run from the repo root on the GPU box; outputs land in
 # gpurun_out/ and are copied into profiles/ by hand afterwards):  bash tools/refresh_profiles.sh r02
 set -e
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$(pwd)
 python3 bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 bash tools/profile_bench.sh
@@ -35,8 +35,6 @@ cp gpurun_out/pmc_valu.txt gpurun_out/${R}_pmc_valu.txt
   echo; echo "== the same through the 64-tap gather implicit GEMM (LTU_NO_UPDGRAD_RING=1)"; LTU_NO_UPDGRAD_RING=1 python3 tools/bench_updgrad.py 2>/dev/null
   echo; echo "== bench_conv.py at the 32x32x128 level: generic convs in the ring style"; python3 tools/bench_conv.py 2 32 32 128 64 0 64  2 32 32 128 32 32 32  2 16 16 64 128 0 160 2>/dev/null
   echo; echo "== the same with the first-generation halo kernel (LTU_NO_CONV_RING=1)"; LTU_NO_CONV_RING=1 python3 tools/bench_conv.py 2 32 32 128 64 0 64  2 32 32 128 32 32 32  2 16 16 64 128 0 160 2>/dev/null
-  echo; echo "== bench_gate_proj.py (attention gates' 1x1x1 convs)"; python3 tools/bench_gate_proj.py 2>/dev/null
-  echo; echo "== the same through the implicit GEMM (LTU_NO_PW_SMALL=1)"; LTU_NO_PW_SMALL=1 python3 tools/bench_gate_proj.py 2>/dev/null
   echo; echo "== bench_dwconv.py (positional depthwise conv)"; python3 tools/bench_dwconv.py 2>/dev/null
   echo; echo "== bucket_timeline.py"; python3 tools/bucket_timeline.py 2>/dev/null
 } > gpurun_out/${R}_microbench.txt
