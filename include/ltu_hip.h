@@ -68,7 +68,7 @@ int ltu_selftest_group_reduce(const float* x, float* sum, float* mx, int n, int 
  * partials, agent-scope ticket, one acquire by the last arriver: the guide's hand-off recipe R1).  Both fold in the same fixed
  * order, so `out` [n] must be bit-identical.  part: nwg * n floats (pre-read by every workgroup: an L1-warm consumer), counter: one
  * zeroed word (left zero by the last arriver), sink: nwg floats (never written for finite data).  tests/test_gpu_ops.py runs 10^4
- * launches of it in one process; tools/bench_last_arriver.py times both forms. */
+ * launches of it in one process; profiles/r03_last_arriver.txt has the timings of both forms. */
 int ltu_selftest_last_arriver(const float* x, float* part, float* out, unsigned* counter, float* sink, int nwg, int n,
                               int rows_per_chunk, int skew, int mode, ltu_stream_t s);
 #endif

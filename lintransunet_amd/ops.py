@@ -289,7 +289,7 @@ class Context:
         if q is None or q['running']:
             fn(q['keep'] if q is not None else [])
             return
-        q['jobs'].append(fn)
+        q['jobs'].append((fam, fn))
         q['keep'].extend(t for t in tensors if t is not None)
         if len(q['jobs']) >= WQ_MAX_JOBS:
             self.flush_deferred()
@@ -301,11 +301,13 @@ class Context:
             return
         jobs, q['jobs'] = q['jobs'], []
         q['batches'] += 1
+        if WQ_ORDER:       # experiment: families in a fixed order inside a batch (stable; e.g. the narrow grouped kernels first)
+            jobs = sorted(jobs, key=lambda j: WQ_ORDER.index(j[0]) if j[0] in WQ_ORDER else len(WQ_ORDER))
 
         def run():
             q['running'] = True
             try:
-                for fn in jobs:
+                for _fam, fn in jobs:
                     fn(q['keep'])
                 # parameters whose gradients were reported while the queue held their kernels back (train.GradReducer._hook parks
                 # them here): NOW their gradients are enqueued - a bucket that this completes is reduced behind this batch
@@ -359,8 +361,8 @@ def use(ctx):
 def concurrent_stream(device, avoid, tries=8, cycles=1000000, priority=0):
     """A stream that REALLY runs beside every stream in `avoid`.  HIP maps its streams round-robin onto a few hardware queues
     (GPU_MAX_HW_QUEUES, 4 by default; 8 doubles the step time on this runtime) and two streams that share a queue serialise:
-    every fourth stream of torch's pool lands on the current stream's queue (tools/probe_streams.py: 1.99x for those, 1.0x for the
-    rest), which silently removed the whole benefit of the weight-gradient side stream whenever a communicator had taken a stream
+    every fourth stream of torch's pool lands on the current stream's queue (1.99x for those, 1.0x for the
+    rest: profiles/HISTORY.md finding 34), which silently removed the whole benefit of the weight-gradient side stream whenever a communicator had taken a stream
     before it.  So candidates are probed: a spin kernel on each stream of `avoid` and on the candidate must take 1x, not 2x.
     Synchronises the device; call outside captures."""
     import time
@@ -459,6 +461,7 @@ import os as _os
 WGRAD_DEFER_MB = float(_os.environ.get('LTU_WGRAD_DEFER_MB', '400'))     # operand bytes of the layers' weight-gradient groups launched together
 WQ_MAX_JOBS = int(_os.environ.get('LTU_WQ_JOBS', '1000000'))      # weight-gradient queue: a batch goes out when this many launches are queued
 WQ_INLINE = frozenset(f for f in _os.environ.get('LTU_WQ_INLINE', '').split(',') if f)      # families of weight gradients kept off the queue
+WQ_ORDER = [f for f in _os.environ.get('LTU_WQ_ORDER', '').split(',') if f]     # experiment: order of the families inside a batch
 WQ_SIDE_FWD = _os.environ.get('LTU_WQ_FWD', '1') == '1'      # forward-side work (weight operands behind the encoder, label pyramid) on the side stream
 WQ_FLUSH_IN_ENCODER = _os.environ.get('LTU_WQ_ENC', '1') == '1'      # ... and a batch per encoder block in the encoder's backward
 WQ_SCHEDULE = _os.environ.get('LTU_WQ_SCHEDULE', 'end')     # weight-gradient queue: a batch where backward ENTERS ('start') / leaves ('end') a transformer

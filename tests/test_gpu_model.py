@@ -145,7 +145,7 @@ def test_model_sampled_fp32(golden_dir, tag, cfgkw, size, batch, wseed):
 # a trained model and a held-out volume is tests/test_heldout.py).
 # The ROI boxes are step functions of the coarser mask (get_mask_boundary2 thresholds it at 0.5, Unet_3Dblock.py:738-739).  With
 # random weights the masks hover around 0.5, so a bf16-sized perturbation can move a box edge by one cell; every activation behind
-# that ROI bridge then differs by O(1) although each op is exact to bf16 (tools/diag_trace.py shows the op-by-op picture: 2e-2
+# that ROI bridge then differs by O(1) although each op is exact to bf16 (a per-op trace (round 2) shows the op-by-op picture: 2e-2
 # drift up to the first moved box, 3e-1 right after it).  The element-wise gate therefore applies when the boxes agree.
 BF16_DICE_TOL = 3e-4
 BF16_DICE_TOL_MOVED_BOX = 1e-3

@@ -1243,7 +1243,7 @@ def test_last_arriver_reduce(nwg, n, skew):
     workgroup - the guide's hand-off recipe R1) against the two-stage fold the step uses: uneven per-workgroup load, an L1-warm
     consumer (every workgroup pre-reads the previous launch's partial rows), 2-4 workgroups per CU, 10^4 launches in ONE process on
     alternating data, every output word compared bit for bit.  (VERDICT round 2, item 6.  The reducer is correct here; it is still
-    not used in the step because it does not pay: tools/bench_last_arriver.py, DESIGN.md section 5 finding 15.)"""
+    not used in the step because it does not pay: profiles/r03_last_arriver.txt, profiles/HISTORY.md finding 15.)"""
     from lintransunet_amd import _lib
     from lintransunet_amd.ops import _p, _s
     if not _lib.experiments():
