@@ -23,10 +23,10 @@ DEV = 'cuda'
 # gradients whose kernels are launched at another width on the side stream (other split counts = another fp32 summation order):
 # the projections of the transformer layers (grouped weight gradients) and the un-embedding conv; everything else must be BIT-equal
 WIDTH_DEPENDENT = ('.self_attn.linears.', '.linear1.', '.linear2.', '.up_embed.')
-TOL = 1e-5
+TOL = 3e-5          # weight gradients: fp32 sums of ~1e5 bf16 x bf16 products per element, another row-split count = another order; observed <= 1.6e-5
 # a bias gradient is one fp32 column sum over up to 115 000 token rows of bf16 values of both signs: two split counts (= summation
 # orders) agree on it to ~6e-8 * sqrt(rows) * (sum |g| / |sum g|), observed 1e-5 .. 1e-4; the weight gradients (fp32 MFMA sums per
-# split, then a fold) hold 1e-5
+# split, then a fold) stay below 2e-5
 TOL_BIAS = 2e-4
 # gradients that are analytically ZERO: the bias of the un-embedding conv feeds an InstanceNorm (Unet_3Dblock.py:426-427: a per-channel
 # shift is normalised away) and the bias of the k projection sits in front of the softmax over tokens (trans_block.py:59: a per-column
