@@ -338,3 +338,26 @@ def test_reducer_tail_bucket_plan():
     assert red.generation == gen + 1
     assert sorted(id(p) for b in red.buckets for p in b) == sorted(id(p) for p in net.parameters())
     assert red.buckets[0][0] is net[7].bias or red.buckets[0][0] is net[7].weight          # the last layer's gradients arrive first
+
+
+def test_bench_report_helpers_read_the_committed_profiles():
+    """bench.py's second roofline object and the in-step family times are computed from the committed kernel statistics / PMC passes
+    (profiles/rNN_*): the helpers parse the newest committed files and the numbers are consistent with each other"""
+    import glob
+    import importlib.util
+    from lintransunet_amd import family_timer
+    stats = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_kernel_stats.csv')))
+    pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_step.json')))
+    assert stats and pmcs
+    fam = family_timer.in_step_ms(stats[-1])
+    assert set(fam) >= {'transformer', 'conv3', 'instnorm', 'resample', 'dwconv', 'other'}
+    assert 12.0 < sum(fam.values()) < 25.0 and fam['transformer'] > fam['conv3'] > fam['instnorm'] > fam['dwconv']
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    byts = 4353687552                      # 24 M d bytes per layer over the 32 layers of the 128^3 x 2 step
+    lk = bench.largest_kernel((1.8, 14, byts), pmcs[-1], stats[-1])
+    assert lk['launches'] == 14 and abs(lk['achieved'] - byts / 1.8e-3 / 1e9) < 1e-6
+    assert 1.5 < lk['ms_in_step'] < 3.0 and 0.1 < lk['frac_in_step'] < lk['frac'] < 0.5
+    assert 1.0 <= lk['traffic'] / byts < 2.0          # PMC traffic of the kernel and its fold against the algorithmic operand bytes
+    assert bench.largest_kernel(None, pmcs[-1], stats[-1]) is None
