@@ -1013,6 +1013,10 @@ int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st) {
   if (!whalo_shape_ok(a.C, a.N) || a.c0 % 8 || a.lda0 % 8 || a.lda1 % 8 || a.ldg % 8) return 1;
   if (a.grad1 != nullptr && (a.gn0 % 8 || a.ldg1 % 8)) return 1;
   if (a.H < 2 || a.W < 2 || a.D < 4) return 1;
+  if (a.C % 32 == 0 && ltu_knob("LTU_WHALO_RING", 1)) {        // second generation (wgrad_halo_ring.hip)
+    const int rc = launch_conv_wgrad_halo_ring_bf16(a, nsplit_out, st);
+    if (rc != 1) return rc;
+  }
   a.CC = a.C % 32 == 0 ? 32 : 16;
   const long long bricks = (long long)a.B * ((a.H + 3) / 4) * ((a.W + 3) / 4) * ((a.D + 7) / 8);
   if (bricks >= (1LL << 31)) return 1;

@@ -159,6 +159,7 @@ struct WHaloArgs {
 };
 long long conv_wgrad_halo_ws_floats(int N, int K);
 int launch_conv_wgrad_halo_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st);   // LTU_OK / hipError, or 1 = not handled
+int launch_conv_wgrad_halo_ring_bf16(WHaloArgs a, int* nsplit_out, hipStream_t st);   // C % 32 == 0 (wgrad_halo_ring.hip): LTU_OK / hipError / LTU_E_ARG, or 1
 int launch_wgrad_reduce(const WGradArgs& wa, int nsplit, hipStream_t st);
 
 // LDS-DMA ring kernels for the dense projections (gemm_ring.hip)

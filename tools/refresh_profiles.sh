@@ -27,6 +27,7 @@ cp gpurun_out/pmc_valu.txt gpurun_out/${R}_pmc_valu.txt
   echo; echo "== bench_la.py (linear-attention core, forward | backward)"; python3 tools/bench_la.py 2>/dev/null
   echo; echo "== bench_pw.py (LayerNorm, GELU, InstanceNorm)"; python3 tools/bench_pw.py 2>/dev/null
   echo; echo "== bench_conv.py (3x3x3 convs, stride 1)"; python3 tools/bench_conv.py 2>/dev/null
+  echo; echo "== the same with the first-generation halo weight gradient (LTU_WHALO_RING=0)"; LTU_WHALO_RING=0 python3 tools/bench_conv.py 2>/dev/null
   echo; echo "== bench_class.py (sub-pixel un-embedding forward) at the three bridge shapes + one brick"; python3 tools/bench_class.py 2 39 23 64 128 32  2 24 14 32 256 64  2 15 9 32 256 128  2 8 8 8 256 256 2>/dev/null
   echo; echo "== the same with the first-generation class kernel (LTU_NO_UPRING=1)"; LTU_NO_UPRING=1 python3 tools/bench_class.py 2 39 23 64 128 32  2 24 14 32 256 64  2 15 9 32 256 128  2 8 8 8 256 256 2>/dev/null
   echo; echo "== bench_sdgrad.py (data gradient of the stride-2 convs)"; python3 tools/bench_sdgrad.py 2>/dev/null
