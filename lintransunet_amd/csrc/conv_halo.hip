@@ -723,6 +723,7 @@ static int halo_cc(int C, int c0) { return (C % 32 == 0 && c0 % 32 == 0) ? 32 : 
 long long conv_halo_ws_floats(int B, int H, int W, int D, int C, int N) {
   const long long bricks = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * ((D + 7) / 8);
   int cps = 0;
+  if (conv_ring_splits(B, H, W, D, C, N)) return 8LL * B * H * W * D * N;
   const int ks = halo_split(bricks, N, C, halo_cc(C, C), &cps);
   // c0 may lower CC to 16 (more chunks, never more than 8 splits): bound by 8
   return (ks > 1 || halo_split(bricks, N, C, 16, &cps) > 1) ? 8LL * B * H * W * D * N : 0;
@@ -767,7 +768,15 @@ int launch_conv_halo_bf16(HaloArgs a, hipStream_t st) {
     return ltu_check_launch();
   }
   if ((a.C >= 64 || a.N > 32) && !ltu_knob("LTU_NO_CONV_RING", 0)) {     // second generation for grids that fill the machine (conv_ring.hip)
+    a.ksplit = 1;
     const int hr = launch_conv_ring_bf16(a, st);
+    if (hr == LTU_OK && a.ksplit > 1) {      // small grid: the channel chunks were split over workgroups
+      const long long M = (long long)a.B * a.H * a.W * a.D;
+      long long blocks = (M * (a.N / 4) + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(conv_halo_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, M);
+      return ltu_check_launch();
+    }
     if (hr != 1) return hr;
   }
   int cps = 0;

@@ -43,7 +43,9 @@ __device__ __forceinline__ void cr_sfor(F&& f) {
 // weight tiles (73 % of the LDS-DMA traffic of the 4-wave kernel: every workgroup streams all of them) are fetched once per 512
 // instead of 256 voxels and the halo factor drops from 2.34 to 1.95; one workgroup of 100 KB per CU, two waves per SIMD as before.
 // The weight pieces of a stage (12) are issued by waves 0-3 only (3 each: a uniform count for the counted waits).
-template <int TN, bool FLIP, int HB, int NW>
+// SPLIT (small grids, the deep levels: a few dozen bricks, thousands of input channels x taps): workgroup z walks the channel chunks
+// [z cps, (z + 1) cps) only and stores its fp32 tile to part[z][voxel][N]; conv_halo_fold_kernel adds the splits and the bias.
+template <int TN, bool FLIP, int HB, int NW, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64, (HB == 1 && NW == 4) ? 2 : 1) conv3_ring_bf16_kernel(const HaloArgs a) {
   constexpr int BN = 32 * TN, WTAP = BN * 64, WSTAGE = 3 * WTAP, PW = 3 * BN / 64;      // bytes per tap tile / stage; weight pieces per (issuing) wave and stage
   constexpr int HROWS = (NW + 2) * 100, HPW = ((HROWS + 15) / 16 + NW - 1) / NW;        // halo rows; halo pieces per wave
@@ -61,7 +63,8 @@ __global__ void __launch_bounds__(NW * 64, (HB == 1 && NW == 4) ? 2 : 1) conv3_r
   const int b = bid / nbh;
   const int h0 = bh * NW, w0 = bw * 8, d0 = bd * 8;
   const int n_blk = blockIdx.y * BN;
-  const int nchunk = a.C / 32;
+  const int c_lo = SPLIT ? blockIdx.z * a.cps : 0;                       // first chunk of this workgroup; `chunk` below counts from it
+  const int nchunk = SPLIT ? min(a.C / 32 - c_lo, a.cps) : a.C / 32;
   const int total = nchunk * 9;
   const bool wissue = NW == 4 || wave < 4;   // this wave issues weight pieces
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
@@ -81,7 +84,7 @@ __global__ void __launch_bounds__(NW * 64, (HB == 1 && NW == 4) ? 2 : 1) conv3_r
     hslot[s] = ((lane & 3) ^ (hw & 3)) * 8;
   }
   auto issue_halo = [&](int chunk) {
-    const int c = chunk * 32;
+    const int c = (c_lo + chunk) * 32;
     const bool s1 = c >= a.c0;             // the chunk's concat source (c0 is a multiple of 32 or equals C)
     const char* base = s1 ? reinterpret_cast<const char*>(a.x1) + (c - a.c0) * 2 : reinterpret_cast<const char*>(a.x0) + c * 2;
     const int ld2 = (s1 ? a.lda1 : a.lda0) * 2;
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(NW * 64, (HB == 1 && NW == 4) ? 2 : 1) conv3_r
   }
   auto issue_w = [&](int g) {               // stage g = chunk * 9 + st: taps 3 st .. 3 st + 2
     const int chunk = g / 9, st = g - chunk * 9;
-    const uint16_t* wsrc = reinterpret_cast<const uint16_t*>(a.w) + st * 3 * a.C + chunk * 32;
+    const uint16_t* wsrc = reinterpret_cast<const uint16_t*>(a.w) + st * 3 * a.C + (c_lo + chunk) * 32;
     const uint32_t wb = lds0 + RING + (st % 3) * WSTAGE + (wave & 3) * PW * 1024;
     if (!wissue) return;
 #pragma unroll
@@ -206,6 +209,26 @@ __global__ void __launch_bounds__(NW * 64, (HB == 1 && NW == 4) ? 2 : 1) conv3_r
     });
   }
 
+  if constexpr (SPLIT) {
+    // fp32 tile of this channel range: lane (li, lh) owns voxel row wave * 64 + i * 32 + li and, per column tile, 4 x 4 columns
+    const long long M = (long long)a.B * a.H * a.W * a.D;
+    float* pz = a.part + (long long)blockIdx.z * M * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wave * 64 + i * 32 + li;
+      const int qh = h0 + (row >> 6), qw = w0 + ((row >> 3) & 7), qd = d0 + (row & 7);
+      if (qh >= a.H || qw >= a.W || qd >= a.D) continue;
+      float* pr = pz + ((((long long)b * a.H + qh) * a.W + qw) * a.D + qd) * a.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int n = n_blk + j * 32 + 8 * rr + 4 * lh;
+          if (n < a.N) *reinterpret_cast<float4*>(pr + n) = make_float4(acc[i][j][4 * rr], acc[i][j][4 * rr + 1], acc[i][j][4 * rr + 2], acc[i][j][4 * rr + 3]);
+        }
+    }
+    return;
+  }
   // ---- epilogue: [256 voxels][BN n] staged (rows of 2 BN bytes, 16-byte parts XOR-ed with the row), bias added; 16 bytes per lane ----
   constexpr int PARTS = BN / 8, RB = 2 * BN;
   float4 bv[TN][4];
@@ -246,8 +269,29 @@ __global__ void __launch_bounds__(NW * 64, (HB == 1 && NW == 4) ? 2 : 1) conv3_r
   }
 }
 
+// split geometry of the small grids (shared with the workspace query): number of channel ranges (1 = no split) and chunks per range
+static int conv_ring_split(long long bricks, int C, int N, int* cps) {
+  const int nchunk = C / 32;
+  const long long tiles = bricks * ((N + 63) / 64);
+  // up to 64 tiles (8x8x64 and deeper at B = 2): 256 -> 128 at 8x8x64 31.4 -> 24.7 us forward, 8x8x32 21.9 -> 20.1 / 25.1 -> 23.8 (data gradient),
+  // 4x4x16 15.5 -> 14.5.  With 128 tiles (16x16x64, 128 -> 64; the data gradient of 256 -> 128 at 8x8x64) two ranges of fp32 partial tiles
+  // cost more than the first generation's nine-tap stages save: 28.6 -> 31.1, 26.9 -> 29.7 - those stay there (profiles/r05_conv_ring_split.txt)
+  if (tiles > ltu_knob_pos("LTU_CONV_RING_SPLIT_TILES", 64) || ltu_knob("LTU_NO_CONV_RING_SPLIT", 0)) return 1;
+  int want = (int)((ltu_knob_pos("LTU_CONV_RING_SPLIT_SLOTS", 256) + tiles - 1) / tiles);
+  if (want > 8) want = 8;
+  if (want > nchunk) want = nchunk;
+  if (want < 2) return 1;
+  *cps = (nchunk + want - 1) / want;
+  return (nchunk + *cps - 1) / *cps;
+}
+bool conv_ring_splits(int B, int H, int W, int D, int C, int N) {
+  if (C % 32 || C > 512 || C < 64 || N % 8 || N <= 32 || H < 2 || W < 4 || D < 4 || ltu_knob("LTU_NO_CONV_RING", 0)) return false;
+  int cps = 0;
+  return conv_ring_split((long long)B * ((H + 3) / 4) * ((W + 7) / 8) * ((D + 7) / 8), C, N, &cps) > 1;
+}
+
 // LTU_OK after launching, or 1 when the shape is not handled here (the caller keeps the first-generation kernels)
-int launch_conv_ring_bf16(const HaloArgs& a, hipStream_t st) {
+int launch_conv_ring_bf16(HaloArgs& a, hipStream_t st) {
   if (a.C % 32 || a.C > 512 || a.N % 8 || a.n0 % 8 || a.lda0 % 8 || a.lda1 % 8 || a.ldo0 % 8 || a.ldo1 % 8) return 1;
   if (a.c0 % 32 != 0 && a.c0 != a.C) return 1;
   if (a.H < 2 || a.W < 4 || a.D < 4 || (long long)a.N * 27 * a.C >= (1LL << 31)) return 1;
@@ -262,7 +306,6 @@ int launch_conv_ring_bf16(const HaloArgs& a, hipStream_t st) {
   // 8x8x8 bricks (eight waves) where they still fill the machine and H does not waste half a brick
   const bool big = !wide && a.H % 8 == 0 && bricks8 * ((a.N + 63) / 64) >= ltu_knob_pos("LTU_CONV_RING_BIG_MIN", 256) && !ltu_knob("LTU_CONV_RING_NO_BIG", 0);
   const long long nwg = (big ? bricks8 : bricks) * ((a.N + bn - 1) / bn);
-  if (nwg < ltu_knob_pos("LTU_CONV_RING_MIN_WG", 200)) return 1;
   static LtuDevOnce attr_once;
   constexpr int smem2 = CR_HBUF + 3 * 3 * 64 * 64, smem4 = 2 * CR_HBUF + 3 * 3 * 128 * 64, smem8 = 64 * 1024 + 3 * 3 * 64 * 64;
   if (attr_once.first()) {
@@ -272,6 +315,24 @@ int launch_conv_ring_bf16(const HaloArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring_bf16_kernel<4, true, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring_bf16_kernel<2, false, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring_bf16_kernel<2, true, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
+  }
+  if (nwg < ltu_knob_pos("LTU_CONV_RING_MIN_WG", 200)) {
+    // small grid: 64-column tiles and the channel chunks split over up to 8 workgroups (two workgroups per CU: 512 slots)
+    int cps = 0;
+    const int ks = conv_ring_split(bricks, a.C, a.N, &cps);
+    if (a.part == nullptr || ks < 2) return 1;
+    a.cps = cps;
+    a.ksplit = ks;
+    if ((long long)a.ksplit * a.B * a.H * a.W * a.D * a.N > a.part_floats) { a.ksplit = 1; return LTU_E_ARG; }
+    static LtuDevOnce split_once;
+    if (split_once.first()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring_bf16_kernel<2, false, 1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring_bf16_kernel<2, true, 1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+    }
+    const dim3 sgrid((unsigned)bricks, (unsigned)((a.N + 63) / 64), (unsigned)a.ksplit);
+    if (a.flip) hipLaunchKernelGGL((conv3_ring_bf16_kernel<2, true, 1, 4, true>), sgrid, dim3(256), smem2, st, a);
+    else hipLaunchKernelGGL((conv3_ring_bf16_kernel<2, false, 1, 4, true>), sgrid, dim3(256), smem2, st, a);
+    return ltu_check_launch();           // the caller folds part[0 .. ksplit) (conv_halo_fold_kernel)
   }
   const dim3 grid((unsigned)(big ? bricks8 : bricks), (unsigned)((a.N + bn - 1) / bn));
   if (wide) {

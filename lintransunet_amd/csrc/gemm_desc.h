@@ -136,7 +136,8 @@ struct HaloArgs {
 };
 long long conv_halo_ws_floats(int B, int H, int W, int D, int C, int N);
 int launch_conv_halo_bf16(HaloArgs a, hipStream_t st);   // LTU_OK / hipError, or 1 = shape not handled (fall back)
-int launch_conv_ring_bf16(const HaloArgs& a, hipStream_t st);      // C >= 64 or N > 32, large grids (conv_ring.hip): LTU_OK / hipError, or 1
+bool conv_ring_splits(int B, int H, int W, int D, int C, int N);   // the ring kernel would split the channel chunks: `part` needed
+int launch_conv_ring_bf16(HaloArgs& a, hipStream_t st);            // C >= 64 or N > 32 (conv_ring.hip): LTU_OK / hipError, or 1; small grids: sets ksplit / cps (> 1: the caller folds `part`)
 int launch_conv_fc_ring_bf16(const HaloArgs& a, hipStream_t st);   // C = 32, N <= 32 (conv_fc_ring.hip): LTU_OK / hipError, or 1 = not handled
 int launch_conv_c16_ring_bf16(const HaloArgs& a, hipStream_t st);  // C = 16, N <= 32 (conv_c16_ring.hip): LTU_OK / hipError, or 1 = not handled
 

@@ -139,6 +139,7 @@ def test_linear_bf16(ops, M, K, N, nw):
     (1, 64, 96, 9, 16, 6, (2, 2, 1), 0, False, None),    # ... three chunks
     (2, 128, 128, 8, 8, 8, (2, 2, 2), 0, False, None),   # strided forward on a tiny grid with K = 3456: K-split implicit GEMM + fold
     (1, 256, 128, 4, 4, 8, (1, 1, 1), 0, False, None),   # stride-1 halo conv on one brick row: channel-split + fold
+    (1, 128, 96, 6, 9, 12, (1, 1, 1), 128, False, None), # conv_ring.hip with the chunks split over workgroups: 128 + 128 concat -> 96 (ragged tile, ragged bricks); data gradient 96 -> 128 + 128
     (1, 16, 16, 36, 38, 60, (1, 1, 1), 0, False, None),  # persistent few-channel kernels: 720 ragged bricks on 512 workgroups (the
     (1, 32, 32, 36, 38, 60, (1, 1, 1), 0, False, None),  # double-buffered brick loop runs more than once), 16 and 32 channels
     (1, 16, 16, 17, 30, 41, (1, 1, 1), 16, False, None), # conv_fc_ring.hip: 16 + 16 concat -> 16, bricks ragged in every axis
