@@ -1708,6 +1708,10 @@ int launch_upconv_wgrad_class_bf16(UpWgradArgs a, int* nsplit_out, hipStream_t s
   if ((long long)nsplit * a.Co * ((long long)a.kpad + 1) > a.part_floats) return LTU_E_ARG;
   a.bpart = a.part + (long long)nsplit * a.Co * a.kpad;
   *nsplit_out = nsplit;
+  if (ltu_knob("LTU_UPW_RING", 1)) {        // second generation (upconv_wgrad_ring.hip)
+    const int rc = launch_upconv_wgrad_ring_bf16(a, nchunk, ntile, nsplit, st);
+    if (rc != 1) return rc;
+  }
   hipLaunchKernelGGL(upconv_wgrad_class_bf16_kernel, dim3(nchunk, ntile, nsplit), dim3(256), 0, st, a);
   return ltu_check_launch();
 }

@@ -220,3 +220,4 @@ struct UpWgradArgs {
 };
 long long upconv_wgrad_class_ws_floats(int Ci, int Co, int blocks);
 int launch_upconv_wgrad_class_bf16(UpWgradArgs a, int* nsplit_out, hipStream_t st);   // LTU_OK / hipError, or 1 = not handled
+int launch_upconv_wgrad_ring_bf16(const UpWgradArgs& a, int nchunk, int ntile, int nsplit, hipStream_t st);   // same work, LDS-DMA ring (upconv_wgrad_ring.hip)

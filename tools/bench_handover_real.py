@@ -66,28 +66,36 @@ def graph_of(lst, stream):
 
 main, side = torch.cuda.current_stream(dev), g.wq_stream
 cap = torch.cuda.Stream()
-gm = graph_of(nxt, cap)
-subsets = {'nothing': [], 'whole batch': batch,
-           'level convs + pairs': [c for c in batch if c[0] in ('ltu_conv3d_wgrad', 'ltu_conv3d_pair_wgrad')],
-           'un-embedding': [c for c in batch if c[0] == 'ltu_upconv_wgrad'],
-           'grouped projections': [c for c in batch if c[0] == 'ltu_linear_wgrad_group'],
-           'folds / small': [c for c in batch if c[0] in ('ltu_reduce_batch', 'ltu_linear_wgrad', 'ltu_dwconv_bwd')]}
+gh, gm = graph_of(nxt[:1], cap), graph_of(nxt[1:], cap)          # the main piece: its first launch, the rest
+fam = {'convs': [c for c in batch if c[0] in ('ltu_conv3d_wgrad', 'ltu_conv3d_pair_wgrad')],
+       'unembed': [c for c in batch if c[0] == 'ltu_upconv_wgrad'],
+       'group': [c for c in batch if c[0] == 'ltu_linear_wgrad_group'],
+       'small': [c for c in batch if c[0] in ('ltu_reduce_batch', 'ltu_linear_wgrad', 'ltu_dwconv_bwd')]}
+subsets = {'nothing': [], 'whole batch': batch}
+for tag in ('convs', 'unembed', 'group', 'small', 'convs+unembed', 'unembed+convs', 'convs+group', 'group+convs', 'unembed+group',
+            'group+unembed+convs+small', 'unembed+group+small+convs'):
+    subsets[tag] = [c for f in tag.split('+') for c in fam[f]]
+sel = os.environ.get('HANDOVER_TAGS')
+print('GPU time on the main stream from the hand-over to the end of the main piece\'s FIRST launch | to its end; the side graph; us')
 for tag, sub in subsets.items():
+    if sel and tag not in sel.split(','):
+        continue
     gs = graph_of(sub, cap) if sub else None
-    tot, tside = 0.0, 0.0
+    th, tot, tside = 0.0, 0.0, 0.0
     for r in range(8):
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, eh, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        orig('ltu_cast_f32', batches[0][0].data_ptr(), batches[0][0].data_ptr(), 0, 0, main.cuda_stream) if False else None
+        e0.record(main)
         if gs is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 s0.record(side); gs.replay(); s1.record(side)
-        e0.record(main); gm.replay(); e1.record(main)
+        gh.replay(); eh.record(main); gm.replay(); e1.record(main)
         torch.cuda.synchronize()
         if r >= 2:
+            th += e0.elapsed_time(eh)
             tot += e0.elapsed_time(e1)
             tside += s0.elapsed_time(s1) if gs is not None else 0.0
-    print(f'  beside {tag:22s} ({len(sub):3d} calls): main piece {tot / 6 * 1e3:8.1f} us   side graph {tside / 6 * 1e3:8.1f} us', flush=True)
+    print(f'  beside {tag:28s} ({len(sub):3d} calls): first launch done {th / 6 * 1e3:8.1f}   main piece {tot / 6 * 1e3:8.1f}   side graph {tside / 6 * 1e3:8.1f}', flush=True)
 reducer.zero_grad()
