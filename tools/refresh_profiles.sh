@@ -36,6 +36,8 @@ cp gpurun_out/pmc_valu.txt gpurun_out/${R}_pmc_valu.txt
   echo; echo "== the same through the 64-tap gather implicit GEMM (LTU_NO_UPDGRAD_RING=1)"; LTU_NO_UPDGRAD_RING=1 python3 tools/bench_updgrad.py 2>/dev/null
   echo; echo "== bench_conv.py at the 32x32x128 level: generic convs in the ring style"; python3 tools/bench_conv.py 2 32 32 128 64 0 64  2 32 32 128 32 32 32  2 16 16 64 128 0 160 2>/dev/null
   echo; echo "== the same with the first-generation halo kernel (LTU_NO_CONV_RING=1)"; LTU_NO_CONV_RING=1 python3 tools/bench_conv.py 2 32 32 128 64 0 64  2 32 32 128 32 32 32  2 16 16 64 128 0 160 2>/dev/null
+  echo; echo "== bench_upwgrad.py (weight gradient of the un-embedding)"; python3 tools/bench_upwgrad.py 2>/dev/null
+  echo; echo "== the same with the first-generation kernel (LTU_UPW_RING=0)"; LTU_UPW_RING=0 python3 tools/bench_upwgrad.py 2>/dev/null
   echo; echo "== bench_dwconv.py (positional depthwise conv)"; python3 tools/bench_dwconv.py 2>/dev/null
   echo; echo "== bucket_timeline.py"; python3 tools/bucket_timeline.py 2>/dev/null
 } > gpurun_out/${R}_microbench.txt
