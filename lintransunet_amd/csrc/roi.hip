@@ -538,8 +538,7 @@ __device__ __forceinline__ void tri_adj1d_body(const T* ib, const T* ib2, T* ob,
 }
 struct TriEntry { int n; int o[8]; float w[8]; int pad[15]; };       // 128 bytes
 // entries [0, H) for the height axis, [H, H+W) width, [H+W, H+W+D) depth
-__global__ void tri_table_kernel(TriEntry* __restrict__ t, int H, int W, int D, int Ho, int Wo, int Do, TriScale sc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tri_table_entry(int i, TriEntry* __restrict__ t, int H, int W, int D, int Ho, int Wo, int Do, TriScale sc) {
   if (i >= H + W + D) return;
   int os[8];
   float ws[8];
@@ -580,9 +579,8 @@ __global__ void __launch_bounds__(256) tri_adj1d_kernel(const T* __restrict__ in
 // lists come from a table as well (TriPair: union rows, the weights of either output, zero where a row does not contribute).
 struct TriPair { int n; int o[8]; float w0[8]; float w1[8]; int pad[7]; };     // 128 bytes; n < 0: union longer than 8, rows done singly
 // entries [0, PH) for the height axis, [PH, PH + PW) width, then depth; P* = (L + 1) / 2
-__global__ void tri_pair_table_kernel(TriPair* __restrict__ t, int H, int W, int D, int Ho, int Wo, int Do, TriScale sc) {
+__device__ __forceinline__ void tri_pair_table_entry(int i, TriPair* __restrict__ t, int H, int W, int D, int Ho, int Wo, int Do, TriScale sc) {
   const int PH = (H + 1) / 2, PW = (W + 1) / 2, PD = (D + 1) / 2;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= PH + PW + PD) return;
   int L, Lo, pr;
   float scale, inv;
@@ -609,6 +607,13 @@ __global__ void tri_pair_table_kernel(TriPair* __restrict__ t, int H, int W, int
   e.n = over ? -1 : n;
   for (int q = 0; q < 7; ++q) e.pad[q] = 0;
   t[i] = e;
+}
+// both tables of a call in ONE launch (they used to be two 8-9 us one-workgroup kernels at the head of every adjoint, on the backward chain):
+// workgroups [0, nb1) fill the row table, the rest the pair table (pt == nullptr: none)
+__global__ void __launch_bounds__(128) tri_tables_kernel(TriEntry* __restrict__ t, TriPair* __restrict__ pt, int nb1, int H, int W, int D, int Ho,
+                                                         int Wo, int Do, TriScale sc) {
+  if ((int)blockIdx.x < nb1) tri_table_entry(blockIdx.x * 128 + threadIdx.x, t, H, W, D, Ho, Wo, Do, sc);
+  else tri_pair_table_entry(((int)blockIdx.x - nb1) * 128 + threadIdx.x, pt, H, W, D, Ho, Wo, Do, sc);
 }
 template <typename T, bool HAS2, int N>
 __device__ __forceinline__ void tri_adj1d_pair_body(const T* ib, const T* ib2, T* ob0, T* ob1, const int (&os)[8], const float (&w0)[8],
@@ -802,11 +807,10 @@ extern "C" int ltu_trilinear_adjoint(const void* dy, const void* dy2, void* dx, 
     T* t1 = t2 + t2n;                                            // [B][Ho][Wo][D][C] (sd == 2 only)
     T* tend = sd == 2 ? t1 + 2 * t2n : t1;
     TriEntry* table = reinterpret_cast<TriEntry*>((reinterpret_cast<uintptr_t>(tend) + 127) & ~(uintptr_t)127);
-    hipLaunchKernelGGL(tri_table_kernel, dim3((unsigned)((H + W + D + 127) / 128)), dim3(128), 0, st, table, H, W, D, Ho, Wo, Do, sc);
     TriPair* ptable = ltu_knob("LTU_TRI_NO_PAIR", 0) ? nullptr : reinterpret_cast<TriPair*>(table + (H + W + D + 1));
     const int PH = (H + 1) / 2, PW = (W + 1) / 2, PDn = (D + 1) / 2;
-    if (ptable != nullptr)
-      hipLaunchKernelGGL(tri_pair_table_kernel, dim3((unsigned)((PH + PW + PDn + 127) / 128)), dim3(128), 0, st, ptable, H, W, D, Ho, Wo, Do, sc);
+    const int nb1 = (H + W + D + 127) / 128, nb2 = ptable != nullptr ? (PH + PW + PDn + 127) / 128 : 0;
+    hipLaunchKernelGGL(tri_tables_kernel, dim3((unsigned)(nb1 + nb2)), dim3(128), 0, st, table, ptable, nb1, H, W, D, Ho, Wo, Do, sc);
     const T* src = (const T*)dy;
     const T* src2 = (const T*)dy2;
     if (sd == 2) {                                               // depth: [B Ho Wo][Do -> D][C]
