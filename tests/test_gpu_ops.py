@@ -305,6 +305,36 @@ def test_upconv_subpixel(ops, dtype, tol, B, Ci, Co, H, W, D):
     assert rel_err(bd.grad, br.grad) < max(tol / 5, 1e-4)
 
 
+@pytest.mark.parametrize('gen', [1, 0])
+def test_upconv_wgrad_long_brick_runs(ops, gen):
+    """the un-embedding's weight gradient with few workgroups (LTU_UPW_BLOCKS = 8: one workgroup walks 16 bricks = 32 half-brick units, the
+    steady state of the LDS-DMA ring) against torch; gen 0 = the first-generation kernel (LTU_UPW_RING = 0)"""
+    from lintransunet_amd import _lib
+    B, Ci, Co, H, W, D = 2, 64, 72, 5, 6, 9
+    g = G(17)
+    bf = lambda t: t.bfloat16().float()
+    x = bf(torch.randn(B, Ci, H, W, D, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1)
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(F.interpolate(xr, scale_factor=2), wr, br, padding=1)
+    go = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(go)
+    _lib.config_set('LTU_UPW_BLOCKS', 8)
+    _lib.config_set('LTU_UPW_RING', gen)
+    try:
+        xd = to_cl(x, torch.bfloat16).requires_grad_(True)
+        wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        yd = ops.upconv3d(xd, wd, bd)
+        yd.backward(to_cl(go, torch.bfloat16))
+        torch.cuda.synchronize()
+    finally:
+        _lib.config_set('LTU_UPW_BLOCKS', None)
+        _lib.config_set('LTU_UPW_RING', None)
+    assert rel_err(wd.grad, wr.grad) < 3e-3
+    assert rel_err(bd.grad, br.grad) < 3e-3
+
+
 def test_conv3d_stem_padding(ops):
     """stem: 4 real input channels carried in an 8-channel tensor (window embedding)"""
     g = G(4)
