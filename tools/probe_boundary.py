@@ -1,6 +1,8 @@
 """Does a graph-launch boundary on one stream stall while another stream is busy?  (round 5: the main chain of the step idles ~0.86 ms
 behind every hand-over of a weight-gradient batch although half of the CUs are free - profiles/r05_handover.txt.)
-Main stream: graphs of N tiny kernels; side stream: a graph of wide streaming kernels started by an event of the main stream."""
+Main stream: graphs of N tiny kernels; side stream: a graph of wide streaming kernels started by an event of the main stream, then of
+narrow kernels that hold half of the CUs (tools/probe/spin.hip; build it first:
+hipcc --offload-arch=gfx950 -O3 -fPIC -shared tools/probe/spin.hip -o tools/probe/libspin.so)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lintransunet_amd import ops
