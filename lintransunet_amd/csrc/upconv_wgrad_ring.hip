@@ -1,4 +1,4 @@
-// Weight gradient of the sub-pixel un-embedding (nearest x2 + 3x3x3 conv, model/Unet_3Dblock.py UpEmbed): second generation of
+// Weight gradient of the sub-pixel un-embedding (nearest x2 + 3x3x3 conv: UpEmbedBlock, model/Unet_3Dblock.py:388-432): second generation of
 // upconv_wgrad_class_bf16_kernel (conv_halo.hip).  Same arithmetic - dWeff[class][slot] = sum_q G_class(q)^T X(q + off), every wave keeps
 // all 64 (class, slot) products of its 16 x 16 sub-tile (v_mfma_f32_16x16x32_bf16) and folds them onto the 27 taps in registers - but the
 // first generation spent 8.3 us per 4x4x8 brick on 1.7 us of MFMA work (un-embedding of ROI bridge 1: 250 us on 128 workgroups):
